@@ -1,0 +1,200 @@
+/*
+ * qilaplace_hip.h -- C ABI of libqilhip.so, the MI355X (gfx950) implementation of
+ * QILaplace.jl's MPO x MPS apply / coefficient / compress / encode hot path.
+ *
+ * The reference (SUTD-MDQS/QILaplace.jl v0.1.1) has NO FFI layer: its boundary is
+ * Julia multiple dispatch on ITensors-backed containers.  Each entry point below
+ * names the reference method it stands in for (file:line relative to the
+ * reference tree); INTEGRATION.md shows the `ccall` methods a maintainer adds so
+ * `apply`, `*`, `coefficient`, `compress!`, `signal_mps` ... dispatch here.
+ *
+ * Data layout at the boundary (fixed, canonical; all COLUMN-MAJOR, first index
+ * fastest, complex = interleaved (re, im) doubles):
+ *     MPS site   A[alpha, s, beta]          dims (chi_l, 2, chi_r)
+ *     MPO site   W[a, s_in, s_out, b]       dims (D_l, 2, 2, D_r)
+ *         s_in  = the reference's primed leg  s'  (contracted with the MPS)
+ *         s_out = the reference's unprimed leg s  (survives)    src/linalg/apply.jl:98-101
+ * Edge tensors carry explicit dimension-1 bonds.  Paired-register objects
+ * (ZTMPS / PairedSiteMPO) are passed as their interleaved 2n-tensor chain
+ * main_1, copy_1, main_2, ... (src/mps.jl:421-444, src/linalg/apply.jl:16-32)
+ * with `paired = 1`.
+ *
+ * Ownership: handles returned through `out` parameters belong to the caller and
+ * must be released with the matching *_destroy.  The library never keeps a host
+ * pointer after a call returns.  Device buffers belong to the handle.
+ *
+ * Errors: every function returns a qil_status; qil_last_error() gives the
+ * thread-local message.  The host shims re-raise QIL_EINVAL_* as ArgumentError
+ * and QIL_EDOMAIN as DomainError (Julia) / ValueError and ArithmeticError (Python).
+ *
+ * Threading: one HIP stream per qil_context; calls on one context are serialised
+ * by the caller, calls on different contexts are independent.  There is no global
+ * RNG (the reference's rsvd reseeds Julia's global RNG, src/linalg/rsvd.jl:74):
+ * seeds are explicit parameters.
+ */
+#ifndef QILAPLACE_HIP_H
+#define QILAPLACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qil_context qil_context;
+typedef struct qil_mps qil_mps;   /* SignalMPS (src/mps.jl:70-79) or ZTMPS chain (:98-117) */
+typedef struct qil_mpo qil_mpo;   /* SingleSiteMPO / PairedSiteMPO (src/mpo.jl:26-74)       */
+
+typedef enum { QIL_F64 = 0, QIL_C64 = 1 } qil_dtype;
+
+typedef enum {
+    QIL_OK = 0,
+    QIL_EINVAL_LENGTH = 1, /* ArgumentError: site-count mismatch (apply.jl:76-80, 202-203; mps.jl:671-672) */
+    QIL_EINVAL_SITES = 2,  /* ArgumentError: site-identity mismatch (apply.jl:81-85, 130)                 */
+    QIL_EINVAL_CONFIG = 3, /* ArgumentError: bad bit configuration (mps.jl:612, 619-628, 634-643)         */
+    QIL_EDOMAIN = 4,       /* DomainError: N < 2 in compress! (mps.jl:918), bad center (:800, :820)       */
+    QIL_ENOMEM = 5,
+    QIL_EHIP = 6,          /* a HIP runtime call failed; message carries hipGetErrorString                */
+    QIL_EINVAL_ARG = 7,    /* null handle, bad dtype / method / direction (SignalConverters.jl:200-201)   */
+    QIL_EEMPTY = 8         /* rsvd: left or right index set empty (rsvd.jl:56-60)                         */
+} qil_status;
+
+typedef enum { QIL_METHOD_SVD = 0, QIL_METHOD_RSVD = 1 } qil_method;     /* method=:svd / :rsvd   */
+typedef enum { QIL_DIR_RIGHT = 0, QIL_DIR_LEFT = 1 } qil_direction;      /* :right / :left        */
+
+/* "no cap": the reference's typemax(Int) defaults for maxdim */
+#define QIL_MAXDIM_NONE INT64_MAX
+
+/* ------------------------------------------------------------------ library / context */
+const char* qil_last_error(void);
+const char* qil_version(void);
+/* number of visible HIP devices (does not initialise a context) */
+int qil_device_count(int* out);
+
+/* One context = one device + one HIP stream + a caching device-memory pool.
+ * `stream` may be NULL (the context creates its own non-blocking stream) or an
+ * existing hipStream_t to enqueue on (e.g. torch's current stream).            */
+int qil_context_create(int device, void* stream, qil_context** out);
+int qil_context_destroy(qil_context* ctx);
+int qil_context_synchronize(qil_context* ctx);
+/* release cached (free) device blocks back to the driver */
+int qil_context_trim(qil_context* ctx);
+int qil_context_mem_info(qil_context* ctx, int64_t* pool_bytes_in_use, int64_t* pool_bytes_cached,
+                         int64_t* device_free, int64_t* device_total);
+
+/* HIP-event timing on the context's stream (hipEventRecord / hipEventElapsedTime). */
+int qil_timer_start(qil_context* ctx);
+int qil_timer_stop(qil_context* ctx, double* elapsed_ms);   /* synchronises the stop event */
+/* Per-kernel profile: when enabled every launch of the site-contraction kernel is
+ * bracketed by its own event pair; read returns launches and summed device ms since
+ * the last reset (synchronises).                                                   */
+int qil_profile_enable(qil_context* ctx, int on);
+int qil_profile_read(qil_context* ctx, int64_t* n_launches, double* total_ms, int reset);
+
+/* ------------------------------------------------------------------ containers (T1-T3) */
+/* Construct from HOST tensors.  bond_dims: the n-1 internal bonds.  site_ids: n
+ * labels playing the role of the reference's Index identities (may be NULL =>
+ * 1..n).  site_ptrs[i]: host tensor i in the canonical layout above.
+ * Replaces SignalMPS(data, sites, bonds; amplitude) src/mps.jl:121-146 and
+ * ZTMPS(...) :148-184 (paired = 1, n even).                                       */
+int qil_mps_create(qil_context* ctx, int64_t n, int dtype, int paired, const int64_t* bond_dims,
+                   const int64_t* site_ids, const void* const* site_ptrs, double amplitude,
+                   qil_mps** out);
+/* Same, but tensors left uninitialised on the device (fill through qil_mps_site_device_ptr). */
+int qil_mps_alloc(qil_context* ctx, int64_t n, int dtype, int paired, const int64_t* bond_dims,
+                  const int64_t* site_ids, double amplitude, qil_mps** out);
+int qil_mps_destroy(qil_mps* psi);
+int qil_mps_clone(const qil_mps* psi, qil_mps** out);
+int qil_mps_nsites(const qil_mps* psi, int64_t* n);
+int qil_mps_dtype(const qil_mps* psi, int* dtype);
+int qil_mps_is_paired(const qil_mps* psi, int* paired);
+int qil_mps_bond_dims(const qil_mps* psi, int64_t* bond_dims /* n-1 */);
+int qil_mps_site_ids(const qil_mps* psi, int64_t* site_ids /* n */);
+int qil_mps_amplitude(const qil_mps* psi, double* amplitude);
+int qil_mps_set_amplitude(qil_mps* psi, double amplitude);
+int qil_mps_site_nbytes(const qil_mps* psi, int64_t i, int64_t* nbytes);
+int qil_mps_download_site(const qil_mps* psi, int64_t i, void* host_dst);
+int qil_mps_upload_site(qil_mps* psi, int64_t i, const void* host_src);
+int qil_mps_site_device_ptr(const qil_mps* psi, int64_t i, void** dev_ptr);
+/* seeded device-side fill with i.i.d. N(0,1)/sqrt(2 chi_l) entries (synthetic workloads) */
+int qil_mps_fill_random(qil_mps* psi, uint64_t seed);
+
+/* SingleSiteMPO(data, sites, bonds) src/mpo.jl:30-43 / PairedSiteMPO :62-73 (paired = 1) */
+int qil_mpo_create(qil_context* ctx, int64_t n, int dtype, int paired, const int64_t* bond_dims,
+                   const int64_t* site_ids, const void* const* site_ptrs, qil_mpo** out);
+int qil_mpo_alloc(qil_context* ctx, int64_t n, int dtype, int paired, const int64_t* bond_dims,
+                  const int64_t* site_ids, qil_mpo** out);
+int qil_mpo_destroy(qil_mpo* W);
+int qil_mpo_nsites(const qil_mpo* W, int64_t* n);
+int qil_mpo_dtype(const qil_mpo* W, int* dtype);
+int qil_mpo_is_paired(const qil_mpo* W, int* paired);
+int qil_mpo_bond_dims(const qil_mpo* W, int64_t* bond_dims /* n-1 */);
+int qil_mpo_site_ids(const qil_mpo* W, int64_t* site_ids /* n */);
+int qil_mpo_site_nbytes(const qil_mpo* W, int64_t i, int64_t* nbytes);
+int qil_mpo_download_site(const qil_mpo* W, int64_t i, void* host_dst);
+int qil_mpo_site_device_ptr(const qil_mpo* W, int64_t i, void** dev_ptr);
+int qil_mpo_fill_random(qil_mpo* W, uint64_t seed);
+
+/* ------------------------------------------------------------------ apply (A1-A3) */
+/* apply(W::SingleSiteMPO, psi::SignalMPS) src/linalg/apply.jl:75-122 and
+ * apply(W::PairedSiteMPO, psi::ZTMPS) :201-218 (and `*`, :233-236).
+ *   B_i[(a,alpha), s, (b,beta)] = sum_{s'} W_i[a, s', s, b] * A_i[alpha, s', beta]
+ * written once, directly in the fused layout row = alpha + chi_l*a, col = beta + chi_r*b.
+ * No truncation (the reference ignores cutoff/maxdim kwargs, apply.jl:75).  Output
+ * shares psi's site ids and amplitude (apply.jl:121, :216); dtype = promote(W, psi).
+ * Errors: QIL_EINVAL_LENGTH (apply.jl:76-80, 202-203), QIL_EINVAL_SITES (:81-85).  */
+int qil_apply(const qil_mpo* W, const qil_mps* psi, qil_mps** out);
+/* Same, into an existing handle of identical shape/dtype (no allocation). */
+int qil_apply_into(const qil_mpo* W, const qil_mps* psi, qil_mps* out);
+/* apply(W1, W2) MPO x MPO, "W1 first, then W2", window semantics of apply.jl:124-199
+ * (paired: :220-230).  QIL_EINVAL_SITES when the supports are disjoint (:130).     */
+int qil_apply_mpo_mpo(const qil_mpo* W1, const qil_mpo* W2, qil_mpo** out);
+
+/* ------------------------------------------------------------------ read-out (C1, C2, K3) */
+/* coefficient(psi, cfg) src/mps.jl:669-693 for nb configurations at once.
+ * bits: host, nb x n bytes, query-major, bits[q*n + i] in {0,1} for site i+1 (site 1
+ * first = MSB of a signal index; paired: interleaved main_1, copy_1, ...).
+ * out: host, nb complex doubles (re, im) = amplitude * prod_i A_i[:, bit_i, :].
+ * Errors: QIL_EINVAL_CONFIG for a bit outside [0,1] (mps.jl:612).                  */
+int qil_coefficient_batch(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out);
+/* <bits| W psi> without materialising W*psi (same numbers as
+ * qil_coefficient_batch(qil_apply(W, psi))).                                      */
+int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi, int64_t nb,
+                                const uint8_t* bits, double* out);
+/* mps_to_vector(psi; reverse) src/mps.jl:716-743: 2^n values of psi's dtype, times amplitude. */
+int qil_mps_to_vector(const qil_mps* psi, int reverse, void* host_out);
+/* norm(psi) src/mps.jl:754-771 (without amplitude). */
+int qil_norm(const qil_mps* psi, double* out);
+
+/* ------------------------------------------------------------------ truncation (K1, K2) */
+/* canonicalize!(psi, direction; center, cutoff=1e-12, maxdim) src/mps.jl:787-847.
+ * center = 0 selects the default (N for :right, 1 for :left); 1-based otherwise.    */
+int qil_canonicalize(qil_mps* psi, int direction, int64_t center, double cutoff, int64_t maxdim);
+/* compress!(psi; maxdim, tol=1e-12, sweeps=1) src/mps.jl:913-999.  In place.        */
+int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps);
+
+/* ------------------------------------------------------------------ encode (E1-E4) */
+/* signal_mps(x; method, cutoff, maxdim, k, p, q, random_seed, mindim)
+ * src/signals/SignalConverters.jl:228-233.  x: host, len values of `dtype`.        */
+int qil_signal_mps(qil_context* ctx, const void* x, int64_t len, int dtype, int method,
+                   double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed,
+                   int64_t mindim, qil_mps** out);
+/* signal_ztmps(x; cutoff=1e-10, maxdim, kwargs...) SignalConverters.jl:247-283. */
+int qil_signal_ztmps(qil_context* ctx, const void* x, int64_t len, int dtype, int method,
+                     double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed,
+                     int64_t mindim, qil_mps** out);
+/* rsvd(A, Linds...; k, p, q, random_seed, cutoff, maxdim, mindim) src/linalg/rsvd.jl:38-121
+ * on the matricised operand A (m x n, host, column-major).  Outputs (host, caller
+ * allocated for rank min(k+p, m, n)): U m x r, S r, Vh r x n; *rank = r kept.        */
+int qil_rsvd(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, int64_t k,
+             int64_t p, int q, uint64_t seed, double cutoff, int64_t maxdim, int64_t mindim,
+             int64_t* rank, void* U, double* S, void* Vh);
+/* truncated svd(A; cutoff, maxdim, mindim) with the ITensors truncation rule (the
+ * call sites mps.jl:929,946; SignalConverters.jl:84,266).  Same output contract.   */
+int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, double cutoff,
+                  int64_t maxdim, int64_t mindim, int64_t* rank, void* U, double* S, void* Vh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QILAPLACE_HIP_H */

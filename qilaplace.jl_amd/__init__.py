@@ -1,0 +1,27 @@
+"""qilaplace.jl_amd -- MI355X-native MPO x MPS apply / coefficient / compress / encode path
+of QILaplace.jl, behind the reference's operator names.
+
+The directory name contains a dot, so import it through the root-level shim:
+
+    import qilaplace_jl_amd as qil
+    psi = qil.signal_mps(x)                 # encode on the GPU
+    out = W * psi                           # fused single-pass site contraction (HIP)
+    qil.coefficient(out, "0101...")
+
+Everything numeric runs in lib/libqilhip.so (HIP, gfx950); importing this package fails
+loudly if that library has not been built.
+"""
+from ._lib import QilError, QilDomainError, LIB_PATH, last_error  # noqa: F401
+from .containers import (Context, default_context, set_default_context, device_count,  # noqa: F401
+                         SignalMPS, ZTMPS, SingleSiteMPO, PairedSiteMPO)
+from .ops import (apply, coefficient, coefficient_batch, apply_coefficient_batch,  # noqa: F401
+                  mps_to_vector, norm, canonicalize, compress, signal_mps, signal_ztmps, rsvd,
+                  svd_trunc)
+
+__all__ = [
+    "Context", "default_context", "set_default_context", "device_count",
+    "SignalMPS", "ZTMPS", "SingleSiteMPO", "PairedSiteMPO",
+    "apply", "coefficient", "coefficient_batch", "apply_coefficient_batch", "mps_to_vector", "norm",
+    "canonicalize", "compress", "signal_mps", "signal_ztmps", "rsvd", "svd_trunc",
+    "QilError", "QilDomainError",
+]

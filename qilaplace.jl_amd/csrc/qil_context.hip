@@ -1,0 +1,511 @@
+// Context, error handling, caching device pool, containers (T1-T3 of SURVEY.md section 8a).
+#include <cstdarg>
+
+#include "qil_internal.h"
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+
+void qil_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int qil_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* qil_last_error(void) { return g_err; }
+extern "C" const char* qil_version(void) { return "qilhip 0.1.0 (gfx950)"; }
+
+extern "C" int qil_device_count(int* out) {
+    QIL_REQUIRE(out, QIL_EINVAL_ARG, "qil_device_count: null out");
+    QIL_HIP(hipGetDeviceCount(out));
+    return QIL_OK;
+}
+
+// ---------------------------------------------------------------- context
+int qil_ctx_activate(qil_context* ctx) {
+    QIL_REQUIRE(ctx, QIL_EINVAL_ARG, "null context");
+    QIL_HIP(hipSetDevice(ctx->device));
+    return QIL_OK;
+}
+
+extern "C" int qil_context_create(int device, void* stream, qil_context** out) {
+    QIL_REQUIRE(out, QIL_EINVAL_ARG, "qil_context_create: null out");
+    int count = 0;
+    QIL_HIP(hipGetDeviceCount(&count));
+    QIL_REQUIRE(device >= 0 && device < count, QIL_EINVAL_ARG,
+                "qil_context_create: device %d out of range (%d visible)", device, count);
+    QIL_HIP(hipSetDevice(device));
+    qil_context* ctx = new qil_context();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return qil_fail(QIL_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        ctx->owns_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    hipEventCreate(&ctx->t0);
+    hipEventCreate(&ctx->t1);
+    *out = ctx;
+    return QIL_OK;
+}
+
+extern "C" int qil_context_synchronize(qil_context* ctx) {
+    QIL_TRY(qil_ctx_activate(ctx));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    return QIL_OK;
+}
+
+extern "C" int qil_context_trim(qil_context* ctx) {
+    QIL_TRY(qil_ctx_activate(ctx));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->free_blocks) hipFree(kv.second);
+    ctx->free_blocks.clear();
+    ctx->bytes_cached = 0;
+    return QIL_OK;
+}
+
+extern "C" int qil_context_destroy(qil_context* ctx) {
+    if (!ctx) return QIL_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->free_blocks) hipFree(kv.second);
+    for (auto& kv : ctx->live_blocks) hipFree(kv.first);  // leaked handles
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->dev_scratch) hipFree(ctx->dev_scratch);
+    if (ctx->desc_host) hipHostFree(ctx->desc_host);
+    if (ctx->desc_dev) hipFree(ctx->desc_dev);
+    for (int i = 0; i < qil_context::kDescSlots; ++i)
+        if (ctx->desc_event[i]) hipEventDestroy(ctx->desc_event[i]);
+    for (auto& pr : ctx->prof_events) {
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->t0) hipEventDestroy(ctx->t0);
+    if (ctx->t1) hipEventDestroy(ctx->t1);
+    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return QIL_OK;
+}
+
+extern "C" int qil_context_mem_info(qil_context* ctx, int64_t* in_use, int64_t* cached, int64_t* dfree,
+                                    int64_t* dtotal) {
+    QIL_TRY(qil_ctx_activate(ctx));
+    size_t f = 0, t = 0;
+    QIL_HIP(hipMemGetInfo(&f, &t));
+    if (in_use) *in_use = (int64_t)ctx->bytes_in_use;
+    if (cached) *cached = (int64_t)ctx->bytes_cached;
+    if (dfree) *dfree = (int64_t)f;
+    if (dtotal) *dtotal = (int64_t)t;
+    return QIL_OK;
+}
+
+int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = ctx->free_blocks.find(bytes);
+    if (it != ctx->free_blocks.end()) {
+        *out = it->second;
+        ctx->free_blocks.erase(it);
+        ctx->bytes_cached -= bytes;
+    } else {
+        hipError_t e = hipMalloc(out, bytes);
+        if (e == hipErrorOutOfMemory && !ctx->free_blocks.empty()) {
+            // give cached blocks back and retry once
+            (void)hipGetLastError();
+            hipStreamSynchronize(ctx->stream);
+            for (auto& kv : ctx->free_blocks) hipFree(kv.second);
+            ctx->free_blocks.clear();
+            ctx->bytes_cached = 0;
+            e = hipMalloc(out, bytes);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return qil_fail(e == hipErrorOutOfMemory ? QIL_ENOMEM : QIL_EHIP,
+                            "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        }
+    }
+    ctx->live_blocks[*out] = bytes;
+    ctx->bytes_in_use += bytes;
+    return QIL_OK;
+}
+
+// Blocks are recycled in stream order (single stream per context), so a block freed here can be
+// handed out again immediately: work that still reads it was enqueued earlier on the same stream.
+int qil_ctx_free(qil_context* ctx, void* p) {
+    if (!p) return QIL_OK;
+    auto it = ctx->live_blocks.find(p);
+    if (it == ctx->live_blocks.end()) return qil_fail(QIL_EINVAL_ARG, "qil_ctx_free: unknown block");
+    size_t bytes = it->second;
+    ctx->live_blocks.erase(it);
+    ctx->bytes_in_use -= bytes;
+    ctx->free_blocks.emplace(bytes, p);
+    ctx->bytes_cached += bytes;
+    return QIL_OK;
+}
+
+int qil_ctx_pinned(qil_context* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->pinned_bytes) {
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned) hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        size_t nb = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
+        QIL_HIP(hipHostMalloc(&ctx->pinned, nb, hipHostMallocDefault));
+        ctx->pinned_bytes = nb;
+    }
+    *out = ctx->pinned;
+    return QIL_OK;
+}
+
+int qil_ctx_dev_scratch(qil_context* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->dev_scratch_bytes) {
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->dev_scratch) hipFree(ctx->dev_scratch);
+        ctx->dev_scratch = nullptr;
+        size_t nb = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
+        QIL_HIP(hipMalloc(&ctx->dev_scratch, nb));
+        ctx->dev_scratch_bytes = nb;
+    }
+    *out = ctx->dev_scratch;
+    return QIL_OK;
+}
+
+int qil_ctx_desc_acquire(qil_context* ctx, size_t bytes, void** host, void** dev, int* slot) {
+    QIL_REQUIRE(bytes <= qil_context::kDescSlotBytes, QIL_EINVAL_ARG,
+                "descriptor table of %zu bytes exceeds the slot size", bytes);
+    if (!ctx->desc_host) {
+        const size_t tot = qil_context::kDescSlotBytes * qil_context::kDescSlots;
+        QIL_HIP(hipHostMalloc(&ctx->desc_host, tot, hipHostMallocDefault));
+        QIL_HIP(hipMalloc(&ctx->desc_dev, tot));
+        for (int i = 0; i < qil_context::kDescSlots; ++i)
+            QIL_HIP(hipEventCreateWithFlags(&ctx->desc_event[i], hipEventDisableTiming));
+    }
+    const int k = ctx->desc_next;
+    ctx->desc_next = (k + 1) % qil_context::kDescSlots;
+    if (ctx->desc_used[k]) QIL_HIP(hipEventSynchronize(ctx->desc_event[k]));
+    *host = static_cast<char*>(ctx->desc_host) + (size_t)k * qil_context::kDescSlotBytes;
+    *dev = static_cast<char*>(ctx->desc_dev) + (size_t)k * qil_context::kDescSlotBytes;
+    *slot = k;
+    return QIL_OK;
+}
+
+int qil_ctx_desc_commit(qil_context* ctx, int slot) {
+    QIL_HIP(hipEventRecord(ctx->desc_event[slot], ctx->stream));
+    ctx->desc_used[slot] = true;
+    return QIL_OK;
+}
+
+// ---------------------------------------------------------------- timers / profile
+extern "C" int qil_timer_start(qil_context* ctx) {
+    QIL_TRY(qil_ctx_activate(ctx));
+    QIL_HIP(hipEventRecord(ctx->t0, ctx->stream));
+    return QIL_OK;
+}
+
+extern "C" int qil_timer_stop(qil_context* ctx, double* ms) {
+    QIL_TRY(qil_ctx_activate(ctx));
+    QIL_REQUIRE(ms, QIL_EINVAL_ARG, "qil_timer_stop: null out");
+    QIL_HIP(hipEventRecord(ctx->t1, ctx->stream));
+    QIL_HIP(hipEventSynchronize(ctx->t1));
+    float f = 0.f;
+    QIL_HIP(hipEventElapsedTime(&f, ctx->t0, ctx->t1));
+    *ms = (double)f;
+    return QIL_OK;
+}
+
+extern "C" int qil_profile_enable(qil_context* ctx, int on) {
+    QIL_REQUIRE(ctx, QIL_EINVAL_ARG, "null context");
+    ctx->profile = on != 0;
+    return QIL_OK;
+}
+
+static int get_event(qil_context* ctx, hipEvent_t* e) {
+    if (!ctx->event_pool.empty()) {
+        *e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return QIL_OK;
+    }
+    QIL_HIP(hipEventCreate(e));
+    return QIL_OK;
+}
+
+int qil_ctx_prof_begin(qil_context* ctx) {
+    if (!ctx->profile) return QIL_OK;
+    hipEvent_t a, b;
+    QIL_TRY(get_event(ctx, &a));
+    QIL_TRY(get_event(ctx, &b));
+    ctx->prof_events.emplace_back(a, b);
+    QIL_HIP(hipEventRecord(a, ctx->stream));
+    return QIL_OK;
+}
+
+int qil_ctx_prof_end(qil_context* ctx) {
+    if (!ctx->profile) return QIL_OK;
+    QIL_HIP(hipEventRecord(ctx->prof_events.back().second, ctx->stream));
+    return QIL_OK;
+}
+
+extern "C" int qil_profile_read(qil_context* ctx, int64_t* n_launches, double* total_ms, int reset) {
+    QIL_TRY(qil_ctx_activate(ctx));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    for (auto& pr : ctx->prof_events) {
+        float f = 0.f;
+        QIL_HIP(hipEventElapsedTime(&f, pr.first, pr.second));
+        tot += f;
+    }
+    if (n_launches) *n_launches = (int64_t)ctx->prof_events.size();
+    if (total_ms) *total_ms = tot;
+    if (reset) {
+        for (auto& pr : ctx->prof_events) {
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        ctx->prof_events.clear();
+    }
+    return QIL_OK;
+}
+
+// ---------------------------------------------------------------- containers
+int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int paired, int phys_rank,
+                    const int64_t* bond_dims, const int64_t* site_ids) {
+    QIL_REQUIRE(ctx, QIL_EINVAL_ARG, "null context");
+    QIL_REQUIRE(n >= 1, QIL_EINVAL_LENGTH, "a tensor chain needs at least one site (got %lld)", (long long)n);
+    QIL_REQUIRE(dtype == QIL_F64 || dtype == QIL_C64, QIL_EINVAL_ARG, "unknown dtype %d", dtype);
+    QIL_REQUIRE(!paired || n % 2 == 0, QIL_EINVAL_LENGTH,
+                "paired chains need an even number of tensors (got %lld)", (long long)n);
+    QIL_REQUIRE(n == 1 || bond_dims, QIL_EINVAL_ARG, "null bond_dims");
+    c->ctx = ctx;
+    c->dtype = dtype;
+    c->paired = paired ? 1 : 0;
+    c->phys_rank = phys_rank;
+    c->dims.assign((size_t)n + 1, 1);
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        QIL_REQUIRE(bond_dims[i] >= 1, QIL_EINVAL_ARG, "bond %lld has dimension %lld", (long long)(i + 1),
+                    (long long)bond_dims[i]);
+        c->dims[(size_t)i + 1] = bond_dims[i];
+    }
+    c->site_ids.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) c->site_ids[(size_t)i] = site_ids ? site_ids[i] : i + 1;
+    c->site.assign((size_t)n, nullptr);
+    QIL_TRY(qil_ctx_activate(ctx));
+    for (int64_t i = 0; i < n; ++i) {
+        int s = qil_ctx_alloc(ctx, c->site_bytes(i), &c->site[(size_t)i]);
+        if (s != QIL_OK) {
+            qil_chain_release(c);
+            return s;
+        }
+    }
+    return QIL_OK;
+}
+
+int qil_chain_release(qil_chain* c) {
+    if (!c || !c->ctx) return QIL_OK;
+    for (void*& p : c->site) {
+        if (p) qil_ctx_free(c->ctx, p);
+        p = nullptr;
+    }
+    return QIL_OK;
+}
+
+int qil_chain_set_site(qil_chain* c, int64_t i, void* p, int64_t dl, int64_t dr) {
+    if (c->site[(size_t)i]) QIL_TRY(qil_ctx_free(c->ctx, c->site[(size_t)i]));
+    c->site[(size_t)i] = p;
+    c->dims[(size_t)i] = dl;
+    c->dims[(size_t)i + 1] = dr;
+    return QIL_OK;
+}
+
+template <class H>
+static int chain_create(qil_context* ctx, int64_t n, int dtype, int paired, int phys_rank,
+                        const int64_t* bond_dims, const int64_t* site_ids, const void* const* site_ptrs,
+                        H** out) {
+    QIL_REQUIRE(out, QIL_EINVAL_ARG, "null out");
+    H* h = new H();
+    int s = qil_chain_alloc(ctx, h, n, dtype, paired, phys_rank, bond_dims, site_ids);
+    if (s != QIL_OK) {
+        delete h;
+        return s;
+    }
+    if (site_ptrs) {
+        for (int64_t i = 0; i < n; ++i) {
+            if (!site_ptrs[i]) {
+                qil_chain_release(h);
+                delete h;
+                return qil_fail(QIL_EINVAL_ARG, "site %lld: null host pointer", (long long)(i + 1));
+            }
+            hipError_t e = hipMemcpyAsync(h->site[(size_t)i], site_ptrs[i], h->site_bytes(i),
+                                          hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) {
+                qil_chain_release(h);
+                delete h;
+                return qil_fail(QIL_EHIP, "upload of site %lld failed: %s", (long long)(i + 1),
+                                hipGetErrorString(e));
+            }
+        }
+        // host buffers may be pageable and are not retained: finish the copies before returning
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            qil_chain_release(h);
+            delete h;
+            return qil_fail(QIL_EHIP, "upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = h;
+    return QIL_OK;
+}
+
+extern "C" int qil_mps_create(qil_context* ctx, int64_t n, int dtype, int paired, const int64_t* bond_dims,
+                              const int64_t* site_ids, const void* const* site_ptrs, double amplitude,
+                              qil_mps** out) {
+    QIL_REQUIRE(site_ptrs, QIL_EINVAL_ARG, "qil_mps_create: null site_ptrs");
+    QIL_TRY(chain_create<qil_mps>(ctx, n, dtype, paired, 1, bond_dims, site_ids, site_ptrs, out));
+    (*out)->amplitude = amplitude;
+    return QIL_OK;
+}
+
+extern "C" int qil_mps_alloc(qil_context* ctx, int64_t n, int dtype, int paired, const int64_t* bond_dims,
+                             const int64_t* site_ids, double amplitude, qil_mps** out) {
+    QIL_TRY(chain_create<qil_mps>(ctx, n, dtype, paired, 1, bond_dims, site_ids, nullptr, out));
+    (*out)->amplitude = amplitude;
+    return QIL_OK;
+}
+
+extern "C" int qil_mpo_create(qil_context* ctx, int64_t n, int dtype, int paired, const int64_t* bond_dims,
+                              const int64_t* site_ids, const void* const* site_ptrs, qil_mpo** out) {
+    QIL_REQUIRE(site_ptrs, QIL_EINVAL_ARG, "qil_mpo_create: null site_ptrs");
+    return chain_create<qil_mpo>(ctx, n, dtype, paired, 2, bond_dims, site_ids, site_ptrs, out);
+}
+
+extern "C" int qil_mpo_alloc(qil_context* ctx, int64_t n, int dtype, int paired, const int64_t* bond_dims,
+                             const int64_t* site_ids, qil_mpo** out) {
+    return chain_create<qil_mpo>(ctx, n, dtype, paired, 2, bond_dims, site_ids, nullptr, out);
+}
+
+static int chain_destroy(qil_chain* c) {
+    if (!c) return QIL_OK;
+    if (c->ctx) hipSetDevice(c->ctx->device);
+    qil_chain_release(c);
+    return QIL_OK;
+}
+
+extern "C" int qil_mps_destroy(qil_mps* psi) {
+    chain_destroy(psi);
+    delete psi;
+    return QIL_OK;
+}
+extern "C" int qil_mpo_destroy(qil_mpo* W) {
+    chain_destroy(W);
+    delete W;
+    return QIL_OK;
+}
+
+extern "C" int qil_mps_clone(const qil_mps* psi, qil_mps** out) {
+    QIL_REQUIRE(psi && out, QIL_EINVAL_ARG, "qil_mps_clone: null argument");
+    QIL_TRY(chain_create<qil_mps>(psi->ctx, psi->n(), psi->dtype, psi->paired, 1, psi->dims.data() + 1,
+                                  psi->site_ids.data(), nullptr, out));
+    (*out)->amplitude = psi->amplitude;
+    for (int64_t i = 0; i < psi->n(); ++i)
+        QIL_HIP(hipMemcpyAsync((*out)->site[(size_t)i], psi->site[(size_t)i], psi->site_bytes(i),
+                               hipMemcpyDeviceToDevice, psi->ctx->stream));
+    return QIL_OK;
+}
+
+#define CHAIN_GETTERS(PFX, TYPE)                                                                        \
+    extern "C" int PFX##_nsites(const TYPE* c, int64_t* n) {                                            \
+        QIL_REQUIRE(c && n, QIL_EINVAL_ARG, #PFX "_nsites: null argument");                             \
+        *n = c->n();                                                                                    \
+        return QIL_OK;                                                                                  \
+    }                                                                                                   \
+    extern "C" int PFX##_dtype(const TYPE* c, int* d) {                                                 \
+        QIL_REQUIRE(c && d, QIL_EINVAL_ARG, #PFX "_dtype: null argument");                              \
+        *d = c->dtype;                                                                                  \
+        return QIL_OK;                                                                                  \
+    }                                                                                                   \
+    extern "C" int PFX##_is_paired(const TYPE* c, int* p) {                                             \
+        QIL_REQUIRE(c && p, QIL_EINVAL_ARG, #PFX "_is_paired: null argument");                          \
+        *p = c->paired;                                                                                 \
+        return QIL_OK;                                                                                  \
+    }                                                                                                   \
+    extern "C" int PFX##_bond_dims(const TYPE* c, int64_t* b) {                                         \
+        QIL_REQUIRE(c && (b || c->n() == 1), QIL_EINVAL_ARG, #PFX "_bond_dims: null argument");         \
+        for (int64_t i = 0; i + 1 < c->n(); ++i) b[i] = c->dims[(size_t)i + 1];                         \
+        return QIL_OK;                                                                                  \
+    }                                                                                                   \
+    extern "C" int PFX##_site_ids(const TYPE* c, int64_t* s) {                                          \
+        QIL_REQUIRE(c && s, QIL_EINVAL_ARG, #PFX "_site_ids: null argument");                           \
+        for (int64_t i = 0; i < c->n(); ++i) s[i] = c->site_ids[(size_t)i];                             \
+        return QIL_OK;                                                                                  \
+    }                                                                                                   \
+    extern "C" int PFX##_site_nbytes(const TYPE* c, int64_t i, int64_t* nb) {                           \
+        QIL_REQUIRE(c && nb, QIL_EINVAL_ARG, #PFX "_site_nbytes: null argument");                       \
+        QIL_REQUIRE(i >= 0 && i < c->n(), QIL_EINVAL_ARG, "site index %lld out of range", (long long)i); \
+        *nb = (int64_t)c->site_bytes(i);                                                                \
+        return QIL_OK;                                                                                  \
+    }                                                                                                   \
+    extern "C" int PFX##_download_site(const TYPE* c, int64_t i, void* dst) {                           \
+        QIL_REQUIRE(c && dst, QIL_EINVAL_ARG, #PFX "_download_site: null argument");                    \
+        QIL_REQUIRE(i >= 0 && i < c->n(), QIL_EINVAL_ARG, "site index %lld out of range", (long long)i); \
+        QIL_TRY(qil_ctx_activate(c->ctx));                                                              \
+        QIL_HIP(hipMemcpyAsync(dst, c->site[(size_t)i], c->site_bytes(i), hipMemcpyDeviceToHost,        \
+                               c->ctx->stream));                                                        \
+        QIL_HIP(hipStreamSynchronize(c->ctx->stream));                                                  \
+        return QIL_OK;                                                                                  \
+    }                                                                                                   \
+    extern "C" int PFX##_site_device_ptr(const TYPE* c, int64_t i, void** p) {                          \
+        QIL_REQUIRE(c && p, QIL_EINVAL_ARG, #PFX "_site_device_ptr: null argument");                    \
+        QIL_REQUIRE(i >= 0 && i < c->n(), QIL_EINVAL_ARG, "site index %lld out of range", (long long)i); \
+        *p = c->site[(size_t)i];                                                                        \
+        return QIL_OK;                                                                                  \
+    }
+
+CHAIN_GETTERS(qil_mps, qil_mps)
+CHAIN_GETTERS(qil_mpo, qil_mpo)
+
+extern "C" int qil_mps_upload_site(qil_mps* c, int64_t i, const void* src) {
+    QIL_REQUIRE(c && src, QIL_EINVAL_ARG, "qil_mps_upload_site: null argument");
+    QIL_REQUIRE(i >= 0 && i < c->n(), QIL_EINVAL_ARG, "site index %lld out of range", (long long)i);
+    QIL_TRY(qil_ctx_activate(c->ctx));
+    QIL_HIP(hipMemcpyAsync(c->site[(size_t)i], src, c->site_bytes(i), hipMemcpyHostToDevice, c->ctx->stream));
+    QIL_HIP(hipStreamSynchronize(c->ctx->stream));
+    return QIL_OK;
+}
+
+extern "C" int qil_mps_amplitude(const qil_mps* psi, double* a) {
+    QIL_REQUIRE(psi && a, QIL_EINVAL_ARG, "qil_mps_amplitude: null argument");
+    *a = psi->amplitude;
+    return QIL_OK;
+}
+extern "C" int qil_mps_set_amplitude(qil_mps* psi, double a) {
+    QIL_REQUIRE(psi, QIL_EINVAL_ARG, "qil_mps_set_amplitude: null argument");
+    psi->amplitude = a;
+    return QIL_OK;
+}
+
+static int chain_fill_random(qil_chain* c, uint64_t seed) {
+    QIL_REQUIRE(c, QIL_EINVAL_ARG, "fill_random: null handle");
+    QIL_TRY(qil_ctx_activate(c->ctx));
+    for (int64_t i = 0; i < c->n(); ++i) {
+        double scale = 1.0 / sqrt(2.0 * (double)c->dims[(size_t)i]);
+        QIL_TRY(qil_dev_fill_normal(c->ctx, c->dtype, c->site[(size_t)i], c->site_elems(i),
+                                    seed * 0x9E3779B97F4A7C15ull + (uint64_t)i, scale));
+    }
+    return QIL_OK;
+}
+extern "C" int qil_mps_fill_random(qil_mps* psi, uint64_t seed) { return chain_fill_random(psi, seed); }
+extern "C" int qil_mpo_fill_random(qil_mpo* W, uint64_t seed) { return chain_fill_random(W, seed); }

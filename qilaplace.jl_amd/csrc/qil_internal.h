@@ -1,0 +1,132 @@
+// Internal declarations shared by the libqilhip.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_complex.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "qilaplace_hip.h"
+
+// ---------------------------------------------------------------- errors
+void qil_set_error(const char* fmt, ...);
+int qil_fail(int code, const char* fmt, ...);
+
+#define QIL_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return qil_fail(_e == hipErrorOutOfMemory ? QIL_ENOMEM : QIL_EHIP,             \
+                            "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),         \
+                            __FILE__, __LINE__);                                           \
+    } while (0)
+
+#define QIL_TRY(expr)                 \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != QIL_OK) return _s;  \
+    } while (0)
+
+#define QIL_REQUIRE(cond, code, ...)                       \
+    do {                                                   \
+        if (!(cond)) return qil_fail((code), __VA_ARGS__); \
+    } while (0)
+
+// ---------------------------------------------------------------- context
+struct qil_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    // caching pool: exact-size free lists (apply outputs recur with identical sizes)
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    size_t bytes_in_use = 0, bytes_cached = 0;
+    // pinned staging for small descriptor / bit uploads
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    void* dev_scratch = nullptr;  // per-call device workspace (stream-ordered reuse)
+    size_t dev_scratch_bytes = 0;
+    // ring of small host(pinned)/device descriptor slots for grouped launches: a slot is reused
+    // only after the event recorded behind its last consumer has completed
+    static constexpr int kDescSlots = 8;
+    static constexpr size_t kDescSlotBytes = 1 << 16;
+    void* desc_host = nullptr;
+    void* desc_dev = nullptr;
+    hipEvent_t desc_event[kDescSlots] = {};
+    bool desc_used[kDescSlots] = {};
+    int desc_next = 0;
+    // timers
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<hipEvent_t> event_pool;
+    int num_cus = 256;
+};
+
+int qil_ctx_activate(qil_context* ctx);  // hipSetDevice
+int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out);
+int qil_ctx_free(qil_context* ctx, void* p);
+int qil_ctx_pinned(qil_context* ctx, size_t bytes, void** out);       // grows, stream-synchronising
+int qil_ctx_dev_scratch(qil_context* ctx, size_t bytes, void** out);  // grows
+// acquire a descriptor slot (host staging + device copy target); call qil_ctx_desc_commit after
+// enqueueing the last kernel that reads the device side
+int qil_ctx_desc_acquire(qil_context* ctx, size_t bytes, void** host, void** dev, int* slot);
+int qil_ctx_desc_commit(qil_context* ctx, int slot);
+int qil_ctx_prof_begin(qil_context* ctx);
+int qil_ctx_prof_end(qil_context* ctx);
+
+// ---------------------------------------------------------------- containers
+static inline size_t qil_elem_size(int dtype) { return dtype == QIL_C64 ? 16 : 8; }
+
+struct qil_chain {
+    qil_context* ctx = nullptr;
+    int dtype = QIL_F64;
+    int paired = 0;
+    int phys_rank = 1;               // 1 = MPS (A[a,s,b]), 2 = MPO (W[a,si,so,b])
+    std::vector<int64_t> dims;       // n+1 bond dims incl. the two dim-1 edges
+    std::vector<int64_t> site_ids;   // n labels
+    std::vector<void*> site;         // device pointers, one allocation per site
+    double amplitude = 1.0;
+    int64_t n() const { return (int64_t)site.size(); }
+    int64_t site_elems(int64_t i) const {
+        return dims[i] * (phys_rank == 1 ? 2 : 4) * dims[i + 1];
+    }
+    size_t site_bytes(int64_t i) const { return (size_t)site_elems(i) * qil_elem_size(dtype); }
+};
+struct qil_mps : qil_chain {};
+struct qil_mpo : qil_chain {};
+
+int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int paired, int phys_rank,
+                    const int64_t* bond_dims, const int64_t* site_ids);
+int qil_chain_release(qil_chain* c);
+// replace site i's buffer (takes ownership of `p`), updating the bond dims
+int qil_chain_set_site(qil_chain* c, int64_t i, void* p, int64_t dl, int64_t dr);
+
+// ---------------------------------------------------------------- device linear algebra (qil_linalg.hip)
+// All matrices column-major on the device, dtype QIL_F64/QIL_C64.
+// C[m x n] = opA(A) * opB(B); op: 0 = N, 1 = T, 2 = H, 3 = conj (no transpose).  alpha = 1, beta = 0.
+int qil_dev_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+                 const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc);
+// At (n x m, ldt) = A^T (conj = 0) or A^H (conj = 1)
+int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t n, const void* A, int64_t lda,
+                      void* At, int64_t ldt);
+// Thin SVD of A (m x n, lda) on the device: U (m x r0), S (r0, host), Vh (r0 x n), r0 = min(m,n).
+// A is destroyed.  Singular values sorted descending.
+int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* U,
+                int64_t ldu, double* S_host, void* Vh, int64_t ldvh);
+// Thin QR with non-negative real diagonal of R: A (m x n, m >= n) -> Q (m x n) in place; R (n x n) optional.
+int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda,
+                        void* R, int64_t ldr);
+// ITensors truncation rule (host): number of singular values kept.
+int64_t qil_truncation_rank(const double* S, int64_t n, double cutoff, bool use_cutoff, int64_t maxdim,
+                            int64_t mindim);
+// scale columns (side=1: A[:, j] *= s[j]) or rows (side=0: A[i, :] *= s[i]) by real s (device copy made)
+int qil_dev_scale(qil_context* ctx, int dtype, int side, int64_t m, int64_t n, void* A, int64_t lda,
+                  const double* s_host);
+int qil_dev_fill_normal(qil_context* ctx, int dtype, void* p, int64_t n_elems, uint64_t seed,
+                        double scale);

@@ -1,0 +1,594 @@
+// Device dense linear algebra used by compress!/canonicalize!/signal_mps/rsvd:
+//   GEMM (f64 / c64, N/T/H operands), one-sided Jacobi SVD, Gram-Schmidt QR with positive
+//   diagonal, counter-based Gaussian fill, and the ITensors truncation rule.
+//
+// The reference delegates all of this to ITensors.jl -> LAPACK/BLAS (not in its tree):
+//   svd   src/mps.jl:929,946; src/signals/SignalConverters.jl:84,266; src/linalg/rsvd.jl:103
+//   qr    src/linalg/rsvd.jl:83,90,94 (positive=true)
+//   `*`   every contraction on the path
+// Only gauge-invariant results are comparable with the reference.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "qil_internal.h"
+
+namespace {
+
+struct c64 {
+    double re, im;
+};
+
+__device__ __forceinline__ double conj_t(double v) { return v; }
+__device__ __forceinline__ c64 conj_t(c64 v) { return c64{v.re, -v.im}; }
+__device__ __forceinline__ double fma_t(double a, double b, double acc) { return fma(a, b, acc); }
+__device__ __forceinline__ c64 fma_t(c64 a, c64 b, c64 acc) {
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(a.im, b.re, acc.im);
+    return acc;
+}
+__device__ __forceinline__ double abs2_t(double v) { return v * v; }
+__device__ __forceinline__ double abs2_t(c64 v) { return v.re * v.re + v.im * v.im; }
+__device__ __forceinline__ double scale_t(double v, double s) { return v * s; }
+__device__ __forceinline__ c64 scale_t(c64 v, double s) { return c64{v.re * s, v.im * s}; }
+__device__ __forceinline__ double sub_t(double a, double b) { return a - b; }
+__device__ __forceinline__ c64 sub_t(c64 a, c64 b) { return c64{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ double add_t(double a, double b) { return a + b; }
+__device__ __forceinline__ c64 add_t(c64 a, c64 b) { return c64{a.re + b.re, a.im + b.im}; }
+
+// ------------------------------------------------------------------ GEMM
+// 64 x 64 output tile per 256-thread workgroup, 4 x 4 outputs per thread, K tiles of 16 in LDS.
+constexpr int GT = 64, GK = 16;
+
+template <class T, int OP>
+__device__ __forceinline__ T load_op(const T* __restrict__ M, long long ld, long long r, long long c) {
+    // element (r, c) of op(M); OP: 0 = N, 1 = T, 2 = H, 3 = conj (no transpose)
+    if (OP == 0) return M[r + ld * c];
+    if (OP == 3) return conj_t(M[r + ld * c]);
+    T v = M[c + ld * r];
+    return OP == 2 ? conj_t(v) : v;
+}
+
+template <class T, int OPA, int OPB>
+__global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, long long k,
+                                                   const T* __restrict__ A, long long lda,
+                                                   const T* __restrict__ B, long long ldb, T* __restrict__ C,
+                                                   long long ldc) {
+    __shared__ T As[GK][GT + 1];
+    __shared__ T Bs[GK][GT + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const long long row0 = (long long)blockIdx.x * GT, col0 = (long long)blockIdx.y * GT;
+    T acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = T{};
+    for (long long k0 = 0; k0 < k; k0 += GK) {
+        // stage op(A)[row0.., k0..] and op(B)[k0.., col0..]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int i, kk;
+            if (OPA == 0 || OPA == 3) {
+                i = tid & 63;
+                kk = (tid >> 6) + 4 * r;
+            } else {
+                kk = tid & 15;
+                i = (tid >> 4) + 16 * r;
+            }
+            const long long gr = row0 + i, gk = k0 + kk;
+            As[kk][i] = (gr < m && gk < k) ? load_op<T, OPA>(A, lda, gr, gk) : T{};
+            int j, kb;
+            if (OPB == 0 || OPB == 3) {
+                kb = tid & 15;
+                j = (tid >> 4) + 16 * r;
+            } else {
+                j = tid & 63;
+                kb = (tid >> 6) + 4 * r;
+            }
+            const long long gc = col0 + j, gk2 = k0 + kb;
+            Bs[kb][j] = (gc < n && gk2 < k) ? load_op<T, OPB>(B, ldb, gk2, gc) : T{};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
+            T a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][tx + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][ty + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma_t(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long gr = row0 + tx + 16 * i, gc = col0 + ty + 16 * j;
+            if (gr < m && gc < n) C[gr + ldc * gc] = acc[i][j];
+        }
+}
+
+template <class T>
+int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, long long k, const T* A,
+                  long long lda, const T* B, long long ldb, T* C, long long ldc) {
+    if (m == 0 || n == 0) return QIL_OK;
+    const dim3 grid((unsigned)((m + GT - 1) / GT), (unsigned)((n + GT - 1) / GT)), block(256);
+#define QIL_GEMM_CASE(OA, OB)                                                                           \
+    if (opA == OA && opB == OB) {                                                                       \
+        hipLaunchKernelGGL((gemm_kernel<T, OA, OB>), grid, block, 0, ctx->stream, m, n, k, A, lda, B, ldb, C, \
+                           ldc);                                                                        \
+        QIL_HIP(hipGetLastError());                                                                     \
+        return QIL_OK;                                                                                  \
+    }
+    QIL_GEMM_CASE(0, 0)
+    QIL_GEMM_CASE(0, 1)
+    QIL_GEMM_CASE(0, 2)
+    QIL_GEMM_CASE(1, 0)
+    QIL_GEMM_CASE(2, 0)
+    QIL_GEMM_CASE(1, 1)
+    QIL_GEMM_CASE(2, 2)
+    QIL_GEMM_CASE(1, 2)
+    QIL_GEMM_CASE(2, 1)
+    QIL_GEMM_CASE(3, 0)
+    QIL_GEMM_CASE(0, 3)
+#undef QIL_GEMM_CASE
+    return qil_fail(QIL_EINVAL_ARG, "gemm: bad op codes %d, %d", opA, opB);
+}
+
+// ------------------------------------------------------------------ block reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// sums `NV` doubles per thread across a 256-thread workgroup; result valid in all threads
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* NV * 4 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) lds[i * 4 + wave] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = lds[i * 4 + 0] + lds[i * 4 + 1] + lds[i * 4 + 2] + lds[i * 4 + 3];
+}
+
+// ------------------------------------------------------------------ one-sided Jacobi SVD
+// One round of the round-robin tournament: workgroup i orthogonalises columns (p, q) of A
+// (m x n) and applies the same rotation to V (n x n).
+__device__ __forceinline__ void rotate_pair(double& x, double& y, double c, double s, double pr, double) {
+    // pr = sign(x.y): the rotation angle is computed for |gamma|
+    const double xn = c * x - s * pr * y, yn = s * pr * x + c * y;
+    x = xn;
+    y = yn;
+}
+__device__ __forceinline__ void rotate_pair(c64& x, c64& y, double c, double s, double pr, double pi) {
+    // x' = c x - s e^{-i phi} y ;  y' = s e^{i phi} x + c y,  e^{i phi} = pr + i pi
+    const c64 ey{pr * y.re + pi * y.im, pr * y.im - pi * y.re};  // e^{-i phi} y
+    const c64 ex{pr * x.re - pi * x.im, pr * x.im + pi * x.re};  // e^{ i phi} x
+    const c64 xn{c * x.re - s * ey.re, c * x.im - s * ey.im};
+    const c64 yn{s * ex.re + c * y.re, s * ex.im + c * y.im};
+    x = xn;
+    y = yn;
+}
+__device__ __forceinline__ void dot_parts(double x, double y, double& gr, double& gi) {
+    gr += x * y;
+    (void)gi;
+}
+__device__ __forceinline__ void dot_parts(c64 x, c64 y, double& gr, double& gi) {
+    // conj(x) * y
+    gr += x.re * y.re + x.im * y.im;
+    gi += x.re * y.im - x.im * y.re;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long lda, long long m,
+                                                    T* __restrict__ V, long long ldv, int n, int npad,
+                                                    int round, double tol, int* __restrict__ rotated) {
+    __shared__ double red[16];
+    const int i = blockIdx.x;
+    int p, q;
+    if (i == 0) {
+        p = npad - 1;
+        q = round;
+    } else {
+        p = (round + i) % (npad - 1);
+        q = (round + npad - 1 - i) % (npad - 1);
+    }
+    if (p >= n || q >= n) return;
+    if (p > q) {
+        const int t = p;
+        p = q;
+        q = t;
+    }
+    T* ap = A + lda * p;
+    T* aq = A + lda * q;
+    double v[4] = {0, 0, 0, 0};  // alpha, beta, gamma_re, gamma_im
+    for (long long r = threadIdx.x; r < m; r += 256) {
+        const T x = ap[r], y = aq[r];
+        v[0] += abs2_t(x);
+        v[1] += abs2_t(y);
+        dot_parts(x, y, v[2], v[3]);
+    }
+    block_sum<4>(v, red);
+    const double alpha = v[0], beta = v[1];
+    const double g = sqrt(v[2] * v[2] + v[3] * v[3]);
+    if (!(g > tol * sqrt(alpha * beta)) || g == 0.0) return;
+    if (threadIdx.x == 0) *rotated = 1;
+    const double zeta = (beta - alpha) / (2.0 * g);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    const double pr = v[2] / g, pi = v[3] / g;
+    for (long long r = threadIdx.x; r < m; r += 256) {
+        T x = ap[r], y = aq[r];
+        rotate_pair(x, y, c, s, pr, pi);
+        ap[r] = x;
+        aq[r] = y;
+    }
+    T* vp = V + ldv * p;
+    T* vq = V + ldv * q;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        T x = vp[r], y = vq[r];
+        rotate_pair(x, y, c, s, pr, pi);
+        vp[r] = x;
+        vq[r] = y;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void col_norms(const T* __restrict__ A, long long lda, long long m,
+                                                 double* __restrict__ out) {
+    __shared__ double red[4];
+    const T* a = A + lda * blockIdx.x;
+    double v[1] = {0};
+    for (long long r = threadIdx.x; r < m; r += 256) v[0] += abs2_t(a[r]);
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrt(v[0]);
+}
+
+template <class T>
+__global__ void set_identity(T* __restrict__ V, long long ldv, int n) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < (long long)n * n;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(t % n), c = (int)(t / n);
+        T v{};
+        if (r == c) reinterpret_cast<double*>(&v)[0] = 1.0;
+        V[r + ldv * c] = v;
+    }
+}
+
+// dst[:, j] = src[:, perm[j]] * scale[j]   (conjT = 0)   or   dst[j, i] = conj(src[i, perm[j]]) * scale[j]
+template <class T>
+__global__ void gather_cols(const T* __restrict__ src, long long lds_, long long rows,
+                            const int* __restrict__ perm, const double* __restrict__ scale, T* __restrict__ dst,
+                            long long ldd, int r0, int conjT) {
+    const long long total = rows * r0;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long i = t % rows;
+        const int j = (int)(t / rows);
+        T v = src[i + lds_ * perm[j]];
+        if (scale) v = scale_t(v, scale[j]);
+        if (conjT)
+            dst[j + ldd * i] = conj_t(v);
+        else
+            dst[i + ldd * j] = v;
+    }
+}
+
+template <class T, bool CONJ = true>
+__global__ void conj_transpose(const T* __restrict__ A, long long lda, long long m, long long n,
+                               T* __restrict__ At, long long ldt) {
+    const long long total = m * n;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long j = t % n, i = t / n;  // write-coalesced
+        const T v = A[i + lda * j];
+        At[j + ldt * i] = CONJ ? conj_t(v) : v;
+    }
+}
+
+template <class T>
+int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* U, long long ldu,
+             double* S_host, T* Vh, long long ldvh) {
+    const long long r0 = std::min(m, n);
+    if (r0 == 0) return QIL_OK;
+    // Work on the orientation with the fewer columns: one-sided Jacobi rotates columns.
+    const bool flip = m < n;
+    T* Wk = A;           // work matrix (rows x cols), columns get orthogonalised
+    long long ldw = lda, rows = m, cols = n;
+    void* tbuf = nullptr;
+    if (flip) {
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * sizeof(T), &tbuf));
+        Wk = static_cast<T*>(tbuf);
+        ldw = n;
+        rows = n;
+        cols = m;
+        hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)),
+                           dim3(256), 0, ctx->stream, A, lda, m, n, Wk, ldw);
+    }
+    void *vbuf = nullptr, *flag = nullptr, *nrm = nullptr, *permd = nullptr, *scd = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &vbuf));
+    QIL_TRY(qil_ctx_alloc(ctx, 256, &flag));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)cols * sizeof(double), &nrm));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)cols * sizeof(int), &permd));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)cols * sizeof(double), &scd));
+    T* V = static_cast<T*>(vbuf);
+    hipLaunchKernelGGL(set_identity<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
+                       dim3(256), 0, ctx->stream, V, cols, (int)cols);
+    const int ncol = (int)cols;
+    const int npad = ncol + (ncol & 1);
+    if (ncol > 1) {
+        const double tol = 1e-15;
+        for (int sweep = 0; sweep < 40; ++sweep) {
+            QIL_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+            for (int round = 0; round < npad - 1; ++round)
+                hipLaunchKernelGGL(jacobi_round<T>, dim3(npad / 2), dim3(256), 0, ctx->stream, Wk, ldw, rows, V,
+                                   cols, ncol, npad, round, tol, (int*)flag);
+            int h = 0;
+            QIL_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            if (!h) break;
+        }
+    }
+    hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)cols), dim3(256), 0, ctx->stream, Wk, ldw, rows, (double*)nrm);
+    std::vector<double> sig((size_t)cols);
+    QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)cols * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int> perm((size_t)cols);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return sig[(size_t)a] > sig[(size_t)b]; });
+    std::vector<double> inv((size_t)cols);
+    for (long long j = 0; j < cols; ++j) {
+        const double s = sig[(size_t)perm[(size_t)j]];
+        S_host[j] = s;
+        inv[(size_t)j] = s > 0 ? 1.0 / s : 0.0;
+    }
+    QIL_HIP(hipMemcpyAsync(permd, perm.data(), (size_t)cols * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(scd, inv.data(), (size_t)cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const unsigned gb = (unsigned)std::min<long long>((rows * cols + 255) / 256, 65536);
+    const unsigned gv = (unsigned)std::min<long long>((cols * cols + 255) / 256, 65536);
+    if (!flip) {
+        // A = (Wk D^-1) D V^H
+        hipLaunchKernelGGL(gather_cols<T>, dim3(gb), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
+                           (const int*)permd, (const double*)scd, U, ldu, (int)cols, 0);
+        hipLaunchKernelGGL(gather_cols<T>, dim3(gv), dim3(256), 0, ctx->stream, (const T*)V, cols, cols,
+                           (const int*)permd, (const double*)nullptr, Vh, ldvh, (int)cols, 1);
+    } else {
+        // A^H = (Wk D^-1) D V^H  =>  A = V D (Wk D^-1)^H
+        hipLaunchKernelGGL(gather_cols<T>, dim3(gv), dim3(256), 0, ctx->stream, (const T*)V, cols, cols,
+                           (const int*)permd, (const double*)nullptr, U, ldu, (int)cols, 0);
+        hipLaunchKernelGGL(gather_cols<T>, dim3(gb), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
+                           (const int*)permd, (const double*)scd, Vh, ldvh, (int)cols, 1);
+    }
+    QIL_HIP(hipGetLastError());
+    // perm/inv are host vectors read by async copies: finish before they go out of scope
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    if (tbuf) qil_ctx_free(ctx, tbuf);
+    qil_ctx_free(ctx, vbuf);
+    qil_ctx_free(ctx, flag);
+    qil_ctx_free(ctx, nrm);
+    qil_ctx_free(ctx, permd);
+    qil_ctx_free(ctx, scd);
+    return QIL_OK;
+}
+
+// ------------------------------------------------------------------ Gram-Schmidt QR (CGS2), positive diagonal
+// c[i] = Q[:, i]^H y   for i < j          (one workgroup per previous column)
+template <class T>
+__global__ __launch_bounds__(256) void gs_project(const T* __restrict__ Q, long long ldq, long long m,
+                                                  const T* __restrict__ y, T* __restrict__ c) {
+    __shared__ double red[8];
+    const T* qi = Q + ldq * blockIdx.x;
+    double v[2] = {0, 0};
+    for (long long r = threadIdx.x; r < m; r += 256) dot_parts(qi[r], y[r], v[0], v[1]);
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        T out{};
+        reinterpret_cast<double*>(&out)[0] = v[0];
+        if (sizeof(T) == 16) reinterpret_cast<double*>(&out)[1] = v[1];
+        c[blockIdx.x] = out;
+    }
+}
+
+// y -= Q[:, :j] c ;  racc[:j] += c     (one thread per row)
+template <class T>
+__global__ void gs_subtract(const T* __restrict__ Q, long long ldq, long long m, int j, T* __restrict__ y,
+                            const T* __restrict__ c, T* __restrict__ racc) {
+    const long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (r < m) {
+        T acc = y[r];
+        for (int i = 0; i < j; ++i) {
+            const T qc = fma_t(Q[r + ldq * i], c[i], T{});
+            acc = sub_t(acc, qc);
+        }
+        y[r] = acc;
+    }
+    if (racc && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < j; i += blockDim.x) racc[i] = add_t(racc[i], c[i]);
+}
+
+// y /= ||y|| ; rdiag = ||y||
+template <class T>
+__global__ __launch_bounds__(256) void gs_normalize(T* __restrict__ y, long long m, T* __restrict__ rdiag) {
+    __shared__ double red[4];
+    double v[1] = {0};
+    for (long long r = threadIdx.x; r < m; r += 256) v[0] += abs2_t(y[r]);
+    block_sum<1>(v, red);
+    const double nrm = sqrt(v[0]);
+    const double inv = nrm > 0 ? 1.0 / nrm : 0.0;
+    for (long long r = threadIdx.x; r < m; r += 256) y[r] = scale_t(y[r], inv);
+    if (rdiag && threadIdx.x == 0) {
+        T out{};
+        reinterpret_cast<double*>(&out)[0] = nrm;
+        *rdiag = out;
+    }
+}
+
+template <class T>
+int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
+    void* cbuf = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)std::max<long long>(n, 1) * sizeof(T), &cbuf));
+    T* c = static_cast<T*>(cbuf);
+    if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
+    const unsigned rb = (unsigned)((m + 255) / 256);
+    for (int j = 0; j < (int)n; ++j) {
+        T* y = A + lda * j;
+        if (j > 0)
+            for (int pass = 0; pass < 2; ++pass) {
+                hipLaunchKernelGGL(gs_project<T>, dim3(j), dim3(256), 0, ctx->stream, (const T*)A, lda, m,
+                                   (const T*)y, c);
+                hipLaunchKernelGGL(gs_subtract<T>, dim3(rb), dim3(256), 0, ctx->stream, (const T*)A, lda, m, j, y,
+                                   (const T*)c, R ? R + ldr * j : (T*)nullptr);
+            }
+        hipLaunchKernelGGL(gs_normalize<T>, dim3(1), dim3(256), 0, ctx->stream, y, m,
+                           R ? R + j + ldr * j : (T*)nullptr);
+    }
+    QIL_HIP(hipGetLastError());
+    qil_ctx_free(ctx, cbuf);
+    return QIL_OK;
+}
+
+// ------------------------------------------------------------------ misc kernels
+template <class T>
+__global__ void scale_kernel(T* __restrict__ A, long long lda, long long m, long long n,
+                             const double* __restrict__ s, int side) {
+    const long long total = m * n;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long i = t % m, j = t / m;
+        A[i + lda * j] = scale_t(A[i + lda * j], side ? s[j] : s[i]);
+    }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// counter-based N(0,1): element i draws from hash(seed, 2i), hash(seed, 2i+1) via Box-Muller
+__global__ void fill_normal_kernel(double* __restrict__ p, long long n, uint64_t seed, double scale) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x) {
+        const uint64_t h1 = splitmix64(seed ^ splitmix64(2ull * (uint64_t)t));
+        const uint64_t h2 = splitmix64(seed ^ splitmix64(2ull * (uint64_t)t + 1ull));
+        const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0, 1)
+        const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);          // [0, 1)
+        p[t] = scale * sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ exported (internal) entry points
+int qil_dev_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+                 const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc) {
+    if (dtype == QIL_C64)
+        return gemm_dispatch<c64>(ctx, opA, opB, m, n, k, (const c64*)A, lda, (const c64*)B, ldb, (c64*)C, ldc);
+    // for real data H == T and conj == N
+    static const int real_op[4] = {0, 1, 1, 0};
+    return gemm_dispatch<double>(ctx, real_op[opA & 3], real_op[opB & 3], m, n, k, (const double*)A, lda,
+                                 (const double*)B, ldb, (double*)C, ldc);
+}
+
+int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t n, const void* A, int64_t lda,
+                      void* At, int64_t ldt) {
+    if (m == 0 || n == 0) return QIL_OK;
+    const unsigned g = (unsigned)std::min<long long>((m * n + 255) / 256, 65536);
+    if (dtype == QIL_C64) {
+        if (conj)
+            hipLaunchKernelGGL((conj_transpose<c64, true>), dim3(g), dim3(256), 0, ctx->stream, (const c64*)A, lda,
+                               m, n, (c64*)At, ldt);
+        else
+            hipLaunchKernelGGL((conj_transpose<c64, false>), dim3(g), dim3(256), 0, ctx->stream, (const c64*)A, lda,
+                               m, n, (c64*)At, ldt);
+    } else {
+        hipLaunchKernelGGL((conj_transpose<double, false>), dim3(g), dim3(256), 0, ctx->stream, (const double*)A,
+                           lda, m, n, (double*)At, ldt);
+    }
+    QIL_HIP(hipGetLastError());
+    return QIL_OK;
+}
+
+int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* U,
+                int64_t ldu, double* S_host, void* Vh, int64_t ldvh) {
+    if (dtype == QIL_C64) return svd_impl<c64>(ctx, m, n, (c64*)A, lda, (c64*)U, ldu, S_host, (c64*)Vh, ldvh);
+    return svd_impl<double>(ctx, m, n, (double*)A, lda, (double*)U, ldu, S_host, (double*)Vh, ldvh);
+}
+
+int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* R,
+                        int64_t ldr) {
+    QIL_REQUIRE(m >= n, QIL_EINVAL_ARG, "qr: needs m >= n (got %lld x %lld)", (long long)m, (long long)n);
+    if (dtype == QIL_C64) return qr_impl<c64>(ctx, m, n, (c64*)A, lda, (c64*)R, ldr);
+    return qr_impl<double>(ctx, m, n, (double*)A, lda, (double*)R, ldr);
+}
+
+int64_t qil_truncation_rank(const double* S, int64_t n, double cutoff, bool use_cutoff, int64_t maxdim,
+                            int64_t mindim) {
+    // ITensors / NDTensors truncate! on P = S^2 (descending) [upstream-recall; pinned by the bond
+    // dimensions printed in the reference's tutorials, see oracle/linalg.py]
+    if (n <= 0) return 0;
+    if (!(S[0] > 0.0)) return 1;
+    if (n == 1) return 1;
+    if (mindim < 1) mindim = 1;
+    int64_t k = n;
+    double truncerr = 0.0;
+    while (k > maxdim) {
+        truncerr += S[k - 1] * S[k - 1];
+        --k;
+    }
+    if (use_cutoff) {
+        double scale = 0.0;
+        for (int64_t i = 0; i < n; ++i) scale += S[i] * S[i];
+        if (scale == 0.0) scale = 1.0;
+        while (k > mindim && truncerr + S[k - 1] * S[k - 1] <= cutoff * scale) {
+            truncerr += S[k - 1] * S[k - 1];
+            --k;
+        }
+    }
+    return k < 1 ? 1 : k;
+}
+
+int qil_dev_scale(qil_context* ctx, int dtype, int side, int64_t m, int64_t n, void* A, int64_t lda,
+                  const double* s_host) {
+    if (m == 0 || n == 0) return QIL_OK;
+    const int64_t len = side ? n : m;
+    void* sd = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)len * sizeof(double), &sd));
+    QIL_HIP(hipMemcpyAsync(sd, s_host, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));  // s_host is caller memory
+    const unsigned g = (unsigned)std::min<long long>((m * n + 255) / 256, 65536);
+    if (dtype == QIL_C64)
+        hipLaunchKernelGGL(scale_kernel<c64>, dim3(g), dim3(256), 0, ctx->stream, (c64*)A, lda, m, n,
+                           (const double*)sd, side);
+    else
+        hipLaunchKernelGGL(scale_kernel<double>, dim3(g), dim3(256), 0, ctx->stream, (double*)A, lda, m, n,
+                           (const double*)sd, side);
+    QIL_HIP(hipGetLastError());
+    qil_ctx_free(ctx, sd);
+    return QIL_OK;
+}
+
+int qil_dev_fill_normal(qil_context* ctx, int dtype, void* p, int64_t n_elems, uint64_t seed, double scale) {
+    const long long nd = n_elems * (dtype == QIL_C64 ? 2 : 1);
+    if (nd == 0) return QIL_OK;
+    // complex entries: re, im i.i.d. N(0, 1/2) * scale so that E|z|^2 = scale^2
+    const double sc = dtype == QIL_C64 ? scale * M_SQRT1_2 : scale;
+    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)std::min<long long>((nd + 255) / 256, 65536)), dim3(256),
+                       0, ctx->stream, (double*)p, nd, seed, sc);
+    QIL_HIP(hipGetLastError());
+    return QIL_OK;
+}

@@ -1,0 +1,369 @@
+// Read-out kernels: coefficient (C1), lazy <bits|W psi>, mps_to_vector (C2), norm (K3).
+//
+//   coefficient(psi, cfg)   src/mps.jl:669-678   amplitude * prod_i A_i[:, cfg_i, :]
+//   mps_to_vector           src/mps.jl:716-743
+//   norm                    src/mps.jl:754-771
+//
+// The reference contracts the row vector with the WHOLE site tensor and projects afterwards
+// (mps.jl:675); here the physical slice is selected first (half the bytes, same arithmetic).
+// Every query is a left-to-right vector-matrix chain: HBM-read bound on the selected slices.
+// One workgroup owns one query and walks all sites inside ONE launch; each output entry is a
+// dot product along the contiguous alpha axis, reduced with wavefront shuffles.
+#include "qil_internal.h"
+
+namespace {
+
+struct c64 {
+    double re, im;
+};
+
+__device__ __forceinline__ double cmul_add(double acc, double a, double b) { return fma(a, b, acc); }
+__device__ __forceinline__ c64 cmul_add(c64 acc, c64 a, c64 b) {
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(a.im, b.re, acc.im);
+    return acc;
+}
+__device__ __forceinline__ c64 cmul_add(c64 acc, c64 a, double b) {
+    acc.re = fma(a.re, b, acc.re);
+    acc.im = fma(a.im, b, acc.im);
+    return acc;
+}
+__device__ __forceinline__ c64 cmul_add(c64 acc, double a, c64 b) {
+    acc.re = fma(a, b.re, acc.re);
+    acc.im = fma(a, b.im, acc.im);
+    return acc;
+}
+__device__ __forceinline__ double shfl_xor_t(double v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ c64 shfl_xor_t(c64 v, int m) {
+    return c64{__shfl_xor(v.re, m, 64), __shfl_xor(v.im, m, 64)};
+}
+__device__ __forceinline__ double add_t(double a, double b) { return a + b; }
+__device__ __forceinline__ c64 add_t(c64 a, c64 b) { return c64{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ double one_t(double) { return 1.0; }
+__device__ __forceinline__ c64 one_t(c64) { return c64{1.0, 0.0}; }
+__device__ __forceinline__ c64 to_c64(double v) { return c64{v, 0.0}; }
+__device__ __forceinline__ c64 to_c64(c64 v) { return v; }
+__device__ __forceinline__ double conj_t(double v) { return v; }
+__device__ __forceinline__ c64 conj_t(c64 v) { return c64{v.re, -v.im}; }
+
+struct ChainSite {
+    const void* A;  // MPS site
+    const void* W;  // MPO site (lazy path) or null
+    int cl, cr, Dl, Dr;
+};
+
+constexpr int kThreads = 256;
+
+// v_out[beta] = sum_alpha v_in[alpha] * A[alpha, bit, beta]; groups of G lanes share one beta.
+template <class T>
+__global__ __launch_bounds__(kThreads) void coefficient_chain(const ChainSite* __restrict__ sites, int n,
+                                                              const uint8_t* __restrict__ bits,
+                                                              T* __restrict__ scratch, long long maxchi,
+                                                              c64* __restrict__ out, double amplitude) {
+    const long long q = blockIdx.x;
+    T* v_in = scratch + (2 * q) * maxchi;
+    T* v_out = v_in + maxchi;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int nwaves = kThreads / 64;
+    if (threadIdx.x == 0) v_in[0] = one_t(T{});
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const ChainSite S = sites[i];
+        const int bit = bits[q * n + i];
+        const T* __restrict__ M = static_cast<const T*>(S.A) + (long long)S.cl * bit;
+        int G = 64;  // lanes per dot product: smallest power of two >= cl (cap 64)
+        while (G > 1 && (G >> 1) >= S.cl) G >>= 1;
+        const int per_wave = 64 / G;
+        const int grp = lane / G, gl = lane - grp * G;
+        for (int beta = wave * per_wave + grp; beta < S.cr; beta += nwaves * per_wave) {
+            const T* col = M + 2LL * S.cl * beta;
+            T acc{};
+            for (int al = gl; al < S.cl; al += G) acc = cmul_add(acc, v_in[al], col[al]);
+            for (int m = G >> 1; m >= 1; m >>= 1) acc = add_t(acc, shfl_xor_t(acc, m));
+            if (gl == 0) v_out[beta] = acc;
+        }
+        // the block's own global writes become visible to its other waves here
+        __threadfence_block();
+        __syncthreads();
+        T* t = v_in;
+        v_in = v_out;
+        v_out = t;
+    }
+    if (threadIdx.x == 0) {
+        c64 r = to_c64(v_in[0]);
+        out[q] = c64{r.re * amplitude, r.im * amplitude};
+    }
+}
+
+// Lazy path: carry M[a, alpha] (Dl x cl) per query.
+//   M'[b, beta] = sum_{s'} sum_{a, alpha} W[a, s', bit, b] M[a, alpha] A[alpha, s', beta]
+// two stages per site, both through global scratch owned by the workgroup:
+//   X[s'][b, alpha] = sum_a W[a, s', bit, b] M[a, alpha]
+//   M'[b, beta]     = sum_{s'} sum_alpha X[s'][b, alpha] A[alpha, s', beta]
+template <class TW, class TA>
+__global__ __launch_bounds__(kThreads) void lazy_coefficient_chain(const ChainSite* __restrict__ sites, int n,
+                                                                   const uint8_t* __restrict__ bits,
+                                                                   c64* __restrict__ scratch, long long msz,
+                                                                   c64* __restrict__ out, double amplitude) {
+    const long long q = blockIdx.x;
+    c64* M = scratch + (4 * q) * msz;   // [alpha + cl * a]  (alpha fastest)
+    c64* Mn = M + msz;
+    c64* X = M + 2 * msz;               // 2 * msz: X[s'][alpha + cl * b]
+    if (threadIdx.x == 0) M[0] = c64{1.0, 0.0};
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const ChainSite S = sites[i];
+        const int bit = bits[q * n + i];
+        const TW* __restrict__ W = static_cast<const TW*>(S.W);
+        const TA* __restrict__ A = static_cast<const TA*>(S.A);
+        // stage 1: X[sp][alpha + cl*b] = sum_a W[a + Dl*(sp + 2*(bit + 2*b))] * M[alpha + cl*a]
+        const long long n1 = 2LL * S.cl * S.Dr;
+        for (long long t = threadIdx.x; t < n1; t += kThreads) {
+            const int alpha = (int)(t % S.cl);
+            long long u = t / S.cl;
+            const int b = (int)(u % S.Dr);
+            const int sp = (int)(u / S.Dr);
+            const TW* w = W + (long long)S.Dl * (sp + 2 * (bit + 2LL * b));
+            c64 acc{};
+            for (int a = 0; a < S.Dl; ++a) acc = cmul_add(acc, M[alpha + (long long)S.cl * a], w[a]);
+            X[sp * msz + alpha + (long long)S.cl * b] = acc;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // stage 2: Mn[beta + cr*b] = sum_sp sum_alpha X[sp][alpha + cl*b] * A[alpha + cl*(sp + 2*beta)]
+        const long long n2 = (long long)S.cr * S.Dr;
+        for (long long t = threadIdx.x; t < n2; t += kThreads) {
+            const int beta = (int)(t % S.cr);
+            const int b = (int)(t / S.cr);
+            c64 acc{};
+            for (int sp = 0; sp < 2; ++sp) {
+                const c64* x = X + sp * msz + (long long)S.cl * b;
+                const TA* acol = A + (long long)S.cl * (sp + 2LL * beta);
+                for (int alpha = 0; alpha < S.cl; ++alpha) acc = cmul_add(acc, x[alpha], acol[alpha]);
+            }
+            Mn[beta + (long long)S.cr * b] = acc;
+        }
+        __threadfence_block();
+        __syncthreads();
+        c64* t = M;
+        M = Mn;
+        Mn = t;
+    }
+    if (threadIdx.x == 0) out[q] = c64{M[0].re * amplitude, M[0].im * amplitude};
+}
+
+// One step of the dense contraction: T_k[beta + cr*idx'] = sum_alpha T_{k-1}[alpha + cl*idx] * A[alpha, s, beta]
+//   reverse = 0: idx' = 2*idx + s (site 1 = MSB);  reverse = 1: idx' = idx + s * 2^(k-1) (site 1 = LSB)
+template <class T>
+__global__ void to_vector_step(const T* __restrict__ Tin, const T* __restrict__ A, T* __restrict__ Tout, int cl,
+                               int cr, long long nprev, int reverse) {
+    const long long total = nprev * 2 * cr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int beta = (int)(t % cr);
+        const long long u = t / cr;  // (idx, s) with s fastest
+        const int s = (int)(u & 1);
+        const long long idx = u >> 1;
+        const long long idxp = reverse ? idx + (long long)s * nprev : 2 * idx + s;
+        const T* row = Tin + (long long)cl * idx;
+        const T* col = A + (long long)cl * (s + 2LL * beta);
+        T acc{};
+        for (int al = 0; al < cl; ++al) acc = cmul_add(acc, row[al], col[al]);
+        Tout[beta + (long long)cr * idxp] = acc;
+    }
+}
+
+__global__ void scale_real(double* p, long long n, double s) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x)
+        p[t] *= s;
+}
+
+int upload_bits(qil_context* ctx, int64_t nb, int64_t n, const uint8_t* bits, uint8_t** dbits) {
+    for (int64_t t = 0; t < nb * n; ++t)
+        QIL_REQUIRE(bits[t] <= 1, QIL_EINVAL_CONFIG, "coefficient: bit value %d outside [0,1]", (int)bits[t]);
+    void* p = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nb * n), &p));
+    hipError_t e = hipMemcpyAsync(p, bits, (size_t)(nb * n), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `bits` is caller memory
+    if (e != hipSuccess) {
+        qil_ctx_free(ctx, p);
+        return qil_fail(QIL_EHIP, "bit upload failed: %s", hipGetErrorString(e));
+    }
+    *dbits = static_cast<uint8_t*>(p);
+    return QIL_OK;
+}
+
+}  // namespace
+
+extern "C" int qil_coefficient_batch(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out) {
+    QIL_REQUIRE(psi && (nb == 0 || (bits && out)), QIL_EINVAL_ARG, "coefficient: null argument");
+    if (nb == 0) return QIL_OK;
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    const int64_t n = psi->n();
+    std::vector<ChainSite> tab((size_t)n);
+    long long maxchi = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        tab[(size_t)i] = ChainSite{psi->site[(size_t)i], nullptr, (int)psi->dims[(size_t)i],
+                                   (int)psi->dims[(size_t)i + 1], 1, 1};
+        maxchi = std::max<long long>(maxchi, psi->dims[(size_t)i + 1]);
+    }
+    uint8_t* dbits = nullptr;
+    QIL_TRY(upload_bits(ctx, nb, n, bits, &dbits));
+    const size_t esz = qil_elem_size(psi->dtype);
+    void *scratch = nullptr, *dout = nullptr, *pin = nullptr, *dtab = nullptr;
+    int slot = 0;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * nb * maxchi) * esz, &scratch));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout));
+    QIL_TRY(qil_ctx_desc_acquire(ctx, tab.size() * sizeof(ChainSite), &pin, &dtab, &slot));
+    memcpy(pin, tab.data(), tab.size() * sizeof(ChainSite));
+    QIL_HIP(hipMemcpyAsync(dtab, pin, tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, ctx->stream));
+    if (psi->dtype == QIL_C64)
+        hipLaunchKernelGGL(coefficient_chain<c64>, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream,
+                           (const ChainSite*)dtab, (int)n, dbits, (c64*)scratch, maxchi, (c64*)dout,
+                           psi->amplitude);
+    else
+        hipLaunchKernelGGL(coefficient_chain<double>, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream,
+                           (const ChainSite*)dtab, (int)n, dbits, (double*)scratch, maxchi, (c64*)dout,
+                           psi->amplitude);
+    QIL_HIP(hipGetLastError());
+    QIL_TRY(qil_ctx_desc_commit(ctx, slot));
+    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    qil_ctx_free(ctx, scratch);
+    qil_ctx_free(ctx, dout);
+    qil_ctx_free(ctx, dbits);
+    return QIL_OK;
+}
+
+extern "C" int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi, int64_t nb,
+                                           const uint8_t* bits, double* out) {
+    QIL_REQUIRE(W && psi && (nb == 0 || (bits && out)), QIL_EINVAL_ARG, "apply_coefficient: null argument");
+    QIL_REQUIRE(W->ctx == psi->ctx, QIL_EINVAL_ARG, "apply: MPO and MPS belong to different contexts");
+    QIL_REQUIRE(W->n() == psi->n(), QIL_EINVAL_LENGTH,
+                "apply: MPO and MPS must have the same number of sites. Found length(W)=%lld, length(psi)=%lld",
+                (long long)W->n(), (long long)psi->n());
+    QIL_REQUIRE(W->site_ids == psi->site_ids, QIL_EINVAL_SITES,
+                "apply: MPO and MPS must have the same site indices.");
+    if (nb == 0) return QIL_OK;
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    const int64_t n = psi->n();
+    std::vector<ChainSite> tab((size_t)n);
+    long long msz = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        tab[(size_t)i] = ChainSite{psi->site[(size_t)i], W->site[(size_t)i], (int)psi->dims[(size_t)i],
+                                   (int)psi->dims[(size_t)i + 1], (int)W->dims[(size_t)i],
+                                   (int)W->dims[(size_t)i + 1]};
+        // M: Dr*cr, X[s']: Dr*cl
+        msz = std::max<long long>(msz, W->dims[(size_t)i + 1] * psi->dims[(size_t)i + 1]);
+        msz = std::max<long long>(msz, W->dims[(size_t)i + 1] * psi->dims[(size_t)i]);
+    }
+    uint8_t* dbits = nullptr;
+    QIL_TRY(upload_bits(ctx, nb, n, bits, &dbits));
+    void *scratch = nullptr, *dout = nullptr, *pin = nullptr, *dtab = nullptr;
+    int slot = 0;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(4 * nb * msz) * 16, &scratch));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout));
+    QIL_TRY(qil_ctx_desc_acquire(ctx, tab.size() * sizeof(ChainSite), &pin, &dtab, &slot));
+    memcpy(pin, tab.data(), tab.size() * sizeof(ChainSite));
+    QIL_HIP(hipMemcpyAsync(dtab, pin, tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, ctx->stream));
+    const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;
+#define LAUNCH_LAZY(TW, TA)                                                                             \
+    hipLaunchKernelGGL((lazy_coefficient_chain<TW, TA>), dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, \
+                       (const ChainSite*)dtab, (int)n, dbits, (c64*)scratch, msz, (c64*)dout, psi->amplitude)
+    if (wc && ac) LAUNCH_LAZY(c64, c64);
+    else if (wc) LAUNCH_LAZY(c64, double);
+    else if (ac) LAUNCH_LAZY(double, c64);
+    else LAUNCH_LAZY(double, double);
+#undef LAUNCH_LAZY
+    QIL_HIP(hipGetLastError());
+    QIL_TRY(qil_ctx_desc_commit(ctx, slot));
+    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    qil_ctx_free(ctx, scratch);
+    qil_ctx_free(ctx, dout);
+    qil_ctx_free(ctx, dbits);
+    return QIL_OK;
+}
+
+extern "C" int qil_mps_to_vector(const qil_mps* psi, int reverse, void* host_out) {
+    QIL_REQUIRE(psi && host_out, QIL_EINVAL_ARG, "mps_to_vector: null argument");
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    const int64_t n = psi->n();
+    QIL_REQUIRE(n <= 34, QIL_EINVAL_LENGTH, "mps_to_vector: %lld sites is too many for a dense vector", (long long)n);
+    const size_t esz = qil_elem_size(psi->dtype);
+    long long maxel = 1;
+    for (int64_t k = 0; k < n; ++k) maxel = std::max<long long>(maxel, (1LL << (k + 1)) * psi->dims[(size_t)k + 1]);
+    void *bufA = nullptr, *bufB = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxel * esz, &bufA));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxel * esz, &bufB));
+    // T_0 = [1]
+    const double one[2] = {1.0, 0.0};
+    QIL_HIP(hipMemcpyAsync(bufA, one, esz, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    void *cur = bufA, *nxt = bufB;
+    long long nprev = 1;
+    for (int64_t k = 0; k < n; ++k) {
+        const int cl = (int)psi->dims[(size_t)k], cr = (int)psi->dims[(size_t)k + 1];
+        const long long total = nprev * 2 * cr;
+        const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 65536);
+        if (psi->dtype == QIL_C64)
+            hipLaunchKernelGGL(to_vector_step<c64>, dim3(blocks), dim3(256), 0, ctx->stream, (const c64*)cur,
+                               (const c64*)psi->site[(size_t)k], (c64*)nxt, cl, cr, nprev, reverse ? 1 : 0);
+        else
+            hipLaunchKernelGGL(to_vector_step<double>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               (const double*)cur, (const double*)psi->site[(size_t)k], (double*)nxt, cl, cr,
+                               nprev, reverse ? 1 : 0);
+        std::swap(cur, nxt);
+        nprev *= 2;
+    }
+    const long long N = 1LL << n;
+    const long long nd = N * (psi->dtype == QIL_C64 ? 2 : 1);
+    hipLaunchKernelGGL(scale_real, dim3((unsigned)std::min<long long>((nd + 255) / 256, 65536)), dim3(256), 0,
+                       ctx->stream, (double*)cur, nd, psi->amplitude);
+    QIL_HIP(hipGetLastError());
+    QIL_HIP(hipMemcpyAsync(host_out, cur, (size_t)N * esz, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    qil_ctx_free(ctx, bufA);
+    qil_ctx_free(ctx, bufB);
+    return QIL_OK;
+}
+
+// norm(psi) = sqrt(|<psi|psi>|): E' = A^H (E A) per site, two GEMMs on the matricised site tensor.
+extern "C" int qil_norm(const qil_mps* psi, double* out) {
+    QIL_REQUIRE(psi && out, QIL_EINVAL_ARG, "norm: null argument");
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    const int64_t n = psi->n();
+    const size_t esz = qil_elem_size(psi->dtype);
+    long long maxchi = 1;
+    for (int64_t i = 0; i <= n; ++i) maxchi = std::max<long long>(maxchi, psi->dims[(size_t)i]);
+    void *E = nullptr, *En = nullptr, *T = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(maxchi * maxchi) * esz, &E));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(maxchi * maxchi) * esz, &En));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * maxchi * maxchi) * esz, &T));
+    const double one[2] = {1.0, 0.0};
+    QIL_HIP(hipMemcpyAsync(E, one, esz, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+        // T (cl x 2cr) = E (cl x cl) * A (cl x 2cr);   E[alpha', alpha]
+        QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 0, 0, cl, 2 * cr, cl, E, cl, psi->site[(size_t)i], cl, T, cl));
+        // E' (cr x cr) = A^H ((2cl) x cr)^H * T ((2cl) x cr);  E'[beta', beta]
+        QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 2, 0, cr, cr, 2 * cl, psi->site[(size_t)i], 2 * cl, T, 2 * cl, En, cr));
+        std::swap(E, En);
+    }
+    double h[2] = {0, 0};
+    QIL_HIP(hipMemcpyAsync(h, E, esz, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    *out = sqrt(sqrt(h[0] * h[0] + h[1] * h[1]));
+    qil_ctx_free(ctx, E);
+    qil_ctx_free(ctx, En);
+    qil_ctx_free(ctx, T);
+    return QIL_OK;
+}

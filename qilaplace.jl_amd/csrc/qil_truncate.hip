@@ -1,0 +1,546 @@
+// Truncation and encoding on the device: canonicalize! (K2), compress! (K1), truncated SVD,
+// rsvd (E3), signal_mps (E1/E2), signal_ztmps (E4).
+//
+//   canonicalize!   src/mps.jl:787-847 (ZTMPS :866-901)
+//   compress!       src/mps.jl:913-973 (ZTMPS :975-999)
+//   rsvd            src/linalg/rsvd.jl:38-121
+//   signal_mps      src/signals/SignalConverters.jl:16-46, 49-104 (:svd), 107-196 (:rsvd), 228-233
+//   signal_ztmps    src/signals/SignalConverters.jl:247-283
+//
+// Matricisations are chosen so that every reshape is free in the canonical column-major layouts
+// and the one-sided Jacobi SVD always rotates the SHORT side (see the notes at each call site).
+#include <algorithm>
+#include <cmath>
+
+#include "qil_internal.h"
+
+namespace {
+
+struct c64 {
+    double re, im;
+};
+
+constexpr int64_t kNoCap = INT64_MAX;
+
+template <class F>
+struct Defer {
+    F f;
+    ~Defer() { f(); }
+};
+template <class F>
+Defer<F> defer(F f) {
+    return Defer<F>{f};
+}
+
+// dst (rows x cols, ldd) <- src (rows x cols, lds): strided device copy
+int copy_2d(qil_context* ctx, int dtype, int64_t rows, int64_t cols, const void* src, int64_t lds_, void* dst,
+            int64_t ldd) {
+    if (rows == 0 || cols == 0) return QIL_OK;
+    const size_t e = qil_elem_size(dtype);
+    QIL_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * e, src, (size_t)lds_ * e, (size_t)rows * e, (size_t)cols,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+    return QIL_OK;
+}
+
+// Truncated SVD of the device matrix A (m x n, lda; destroyed).  Outputs are fresh pool blocks:
+//   U  (m x r, ld m)   -- optionally scaled by S (absorb = 1)
+//   Vh (r x n, ld r)   -- optionally scaled by S (absorb = 2)
+int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, double cutoff,
+                  bool use_cutoff, int64_t maxdim, int64_t mindim, int absorb, int64_t* rank, void** U_out,
+                  void** Vh_out, std::vector<double>* S_out) {
+    const int64_t r0 = std::min(m, n);
+    const size_t e = qil_elem_size(dtype);
+    void *U = nullptr, *Vh = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * r0) * e, &U));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r0 * n) * e, &Vh));
+    std::vector<double> S((size_t)r0);
+    QIL_TRY(qil_dev_svd(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0));
+    const int64_t r = qil_truncation_rank(S.data(), r0, cutoff, use_cutoff, maxdim, mindim);
+    if (absorb == 1) QIL_TRY(qil_dev_scale(ctx, dtype, 1, m, r, U, m, S.data()));
+    if (absorb == 2) QIL_TRY(qil_dev_scale(ctx, dtype, 0, r, n, Vh, r0, S.data()));
+    if (r < r0) {  // compact Vh rows to leading dimension r
+        void* Vc = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * n) * e, &Vc));
+        QIL_TRY(copy_2d(ctx, dtype, r, n, Vh, r0, Vc, r));
+        qil_ctx_free(ctx, Vh);
+        Vh = Vc;
+    }
+    S.resize((size_t)r);
+    *rank = r;
+    *U_out = U;  // first r columns are the kept ones (contiguous)
+    *Vh_out = Vh;
+    if (S_out) *S_out = std::move(S);
+    return QIL_OK;
+}
+
+// ---------------------------------------------------------------- canonicalize!
+int canonicalize_impl(qil_mps* psi, int direction, int64_t center, double cutoff, int64_t maxdim) {
+    qil_context* ctx = psi->ctx;
+    const int64_t N = psi->n();
+    const int dt = psi->dtype;
+    const size_t e = qil_elem_size(dt);
+    if (direction == QIL_DIR_RIGHT) {
+        const int64_t c = center == 0 ? N : center;
+        QIL_REQUIRE(c >= 1 && c <= N, QIL_EDOMAIN, "Center out of range [1,%lld]", (long long)N);
+        for (int64_t i = 0; i + 1 < c; ++i) {  // mps.jl:802-817
+            const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+            const int64_t cr2 = psi->dims[(size_t)i + 2];
+            int64_t r = 0;
+            void *U = nullptr, *SV = nullptr;
+            // rows (alpha, s) | cols beta : the site buffer as it lies
+            QIL_TRY(svd_trunc_dev(ctx, dt, 2 * cl, cr, psi->site[(size_t)i], 2 * cl, cutoff, true, maxdim, 1, 2, &r,
+                                  &U, &SV, nullptr));
+            void* next = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * 2 * cr2) * e, &next));
+            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, r, 2 * cr2, cr, SV, r, psi->site[(size_t)i + 1], cr, next, r));
+            qil_ctx_free(ctx, SV);
+            QIL_TRY(qil_chain_set_site(psi, i, U, cl, r));
+            QIL_TRY(qil_chain_set_site(psi, i + 1, next, r, cr2));
+        }
+    } else if (direction == QIL_DIR_LEFT) {
+        const int64_t c = center == 0 ? 1 : center;
+        QIL_REQUIRE(c >= 1 && c <= N, QIL_EDOMAIN, "Center out of range [1,%lld]", (long long)N);
+        for (int64_t i = N - 1; i >= c; --i) {  // mps.jl:822-837
+            const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+            const int64_t cl0 = psi->dims[(size_t)i - 1];
+            int64_t r = 0;
+            void *US = nullptr, *Vh = nullptr;
+            // rows alpha | cols (s, beta)
+            QIL_TRY(svd_trunc_dev(ctx, dt, cl, 2 * cr, psi->site[(size_t)i], cl, cutoff, true, maxdim, 1, 1, &r,
+                                  &US, &Vh, nullptr));
+            void* prev = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl0 * 2 * r) * e, &prev));
+            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, 2 * cl0, r, cl, psi->site[(size_t)i - 1], 2 * cl0, US, cl, prev,
+                                 2 * cl0));
+            qil_ctx_free(ctx, US);
+            QIL_TRY(qil_chain_set_site(psi, i, Vh, r, cr));
+            QIL_TRY(qil_chain_set_site(psi, i - 1, prev, cl0, r));
+        }
+    } else {
+        return qil_fail(QIL_EINVAL_ARG, "Direction must be :right or :left");
+    }
+    return QIL_OK;
+}
+
+// ---------------------------------------------------------------- helper kernels (layout permutations)
+// site A[alpha + cl*(s + 2*k)] = Vyh[k + ldv*(s + 2*alpha)]      (signal_mps :svd, see below)
+template <class T>
+__global__ void site_from_vh(const T* __restrict__ Vyh, long long ldv, int cl, int k, T* __restrict__ A) {
+    const long long total = 2LL * cl * k;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int alpha = (int)(t % cl);
+        const long long u = t / cl;
+        const int s = (int)(u & 1);
+        const int kk = (int)(u >> 1);
+        A[t] = Vyh[kk + ldv * (s + 2LL * alpha)];
+    }
+}
+
+// canonical site A[lb + cl*(s + 2*rb)] from the chunk layout X[rb + cr*(s + 2*lb)]
+template <class T>
+__global__ void site_from_chunk(const T* __restrict__ X, int cl, int cr, T* __restrict__ A) {
+    const long long total = 2LL * cl * cr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int lb = (int)(t % cl);
+        const long long u = t / cl;
+        const int s = (int)(u & 1);
+        const int rb = (int)(u >> 1);
+        A[t] = X[rb + (long long)cr * (s + 2LL * lb)];
+    }
+}
+
+// T[(alpha, m), (c, beta)] = A[alpha, m, beta] * delta(m, c)   (signal_ztmps, SignalConverters.jl:263)
+template <class T>
+__global__ void fuse_delta(const T* __restrict__ A, int cl, int cr, T* __restrict__ Tm) {
+    const long long total = 4LL * cl * cr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t % (2LL * cl), col = t / (2LL * cl);
+        const int alpha = (int)(row % cl), m = (int)(row / cl);
+        const int c = (int)(col & 1);
+        const long long beta = col >> 1;
+        Tm[t] = (m == c) ? A[alpha + (long long)cl * (m + 2 * beta)] : T{};
+    }
+}
+
+inline unsigned nblk(long long total) { return (unsigned)std::min<long long>((total + 255) / 256, 65536); }
+
+// ---------------------------------------------------------------- rsvd on a device operand
+// `Z` holds M^T (plain transpose) column-major: Z is (n x m) for the m x n operand M ("M stored
+// row-major").  Produces, with k = kept rank,
+//   left  = U_M^T        (k x m, ld k)      -- U_M = Q * Uhat
+//   right = (S V_M^h)^T  (n x k, ld n)
+// Steps follow src/linalg/rsvd.jl:72-114; the small SVD is taken of B^T = Z conj(Q) (n x l), whose
+// short side is l, so the Jacobi rotations act on l columns and (S V^h)^T falls out of the rotated
+// work matrix directly.
+int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z, int64_t k, int64_t p, int q,
+                  uint64_t seed, double cutoff, int64_t maxdim, int64_t mindim, int64_t* rank, void** left,
+                  void** right, std::vector<double>* S_out) {
+    QIL_REQUIRE(m >= 1 && n >= 1, QIL_EEMPTY, "In `rsvd`, left or right index set is empty.");
+    const size_t e = qil_elem_size(dt);
+    const int64_t l = std::min(std::min(k + p, m), n);  // rsvd.jl:72
+    void *Om = nullptr, *Y = nullptr, *Zq = nullptr, *Bt = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Om));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * l) * e, &Y));
+    QIL_TRY(qil_dev_fill_normal(ctx, dt, Om, n * l, seed, 1.0));                        // rsvd.jl:74-76
+    QIL_TRY(qil_dev_gemm(ctx, dt, 1, 0, m, l, n, Z, n, Om, n, Y, m));                   // Y = M Omega (:79)
+    QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0));                      // Q (:83)
+    if (q > 0) QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Zq));
+    for (int it = 0; it < q; ++it) {                                                    // :86-95
+        QIL_TRY(qil_dev_gemm(ctx, dt, 3, 0, n, l, m, Z, n, Y, m, Zq, n));               // M^H Q = conj(Z) Q
+        QIL_TRY(qil_dev_qr_positive(ctx, dt, n, l, Zq, n, nullptr, 0));
+        QIL_TRY(qil_dev_gemm(ctx, dt, 1, 0, m, l, n, Z, n, Zq, n, Y, m));               // M Qz
+        QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0));
+    }
+    qil_ctx_free(ctx, Om);
+    if (Zq) qil_ctx_free(ctx, Zq);
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Bt));
+    QIL_TRY(qil_dev_gemm(ctx, dt, 0, 3, n, l, m, Z, n, Y, m, Bt, n));                   // B^T = Z conj(Q) (:98)
+    // B^T = Ub Sb Vbh  =>  Uhat = Vbh^T,  (S V^h)^T = Ub Sb
+    int64_t r = 0;
+    void *UbS = nullptr, *Vbh = nullptr;
+    QIL_TRY(svd_trunc_dev(ctx, dt, n, l, Bt, n, cutoff, true, maxdim, mindim, 1, &r, &UbS, &Vbh, S_out));  // :103
+    qil_ctx_free(ctx, Bt);
+    void* L = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * m) * e, &L));
+    QIL_TRY(qil_dev_gemm(ctx, dt, 0, 1, r, m, l, Vbh, r, Y, m, L, r));                  // U_M^T = Vbh Q^T (:114)
+    qil_ctx_free(ctx, Vbh);
+    qil_ctx_free(ctx, Y);
+    *rank = r;
+    *left = L;
+    *right = UbS;  // first r columns, ld n
+    return QIL_OK;
+}
+
+struct EncodeParams {
+    int method;
+    double cutoff;
+    int64_t maxdim, k, p;
+    int q;
+    uint64_t seed;
+    int64_t mindim;
+};
+
+// _tensor_to_mps_rsvd recursion (SignalConverters.jl:145-184).  Chunk layout (fastest -> slowest):
+// (rb, s_last, ..., s_first, lb) == M^T column-major for the split (lb, left sites | right sites, rb),
+// with M's row index ordered (s_mid fastest, ..., s_first, lb) and its column index (rb fastest,
+// s_last, ..., s_mid+1).  Both children come out in the same chunk layout with no transposition:
+// left = U_M^T (k x rows), right = (S V^h)^T (cols x k).
+int compress_tt(qil_context* ctx, int dt, void* X, int64_t lb, int64_t rb, int64_t first, int64_t last,
+                const EncodeParams& P, std::vector<void*>& sites, std::vector<int64_t>& dims) {
+    const size_t e = qil_elem_size(dt);
+    if (first == last) {
+        void* A = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(lb * 2 * rb) * e, &A));
+        if (dt == QIL_C64)
+            hipLaunchKernelGGL(site_from_chunk<c64>, dim3(nblk(2 * lb * rb)), dim3(256), 0, ctx->stream,
+                               (const c64*)X, (int)lb, (int)rb, (c64*)A);
+        else
+            hipLaunchKernelGGL(site_from_chunk<double>, dim3(nblk(2 * lb * rb)), dim3(256), 0, ctx->stream,
+                               (const double*)X, (int)lb, (int)rb, (double*)A);
+        QIL_HIP(hipGetLastError());
+        sites[(size_t)first] = A;
+        dims[(size_t)first] = lb;
+        dims[(size_t)first + 1] = rb;
+        qil_ctx_free(ctx, X);
+        return QIL_OK;
+    }
+    const int64_t mid = (first + last + 1) / 2 - 1;  // 1-based (first+last-1) div 2, SignalConverters.jl:161
+    const int64_t m = lb << (mid - first + 1), n = rb << (last - mid);
+    int64_t r = 0;
+    void *L = nullptr, *R = nullptr;
+    // explicit cutoff/maxdim override the rsvd defaults (SignalConverters.jl:133)
+    QIL_TRY(rsvd_rowmajor(ctx, dt, m, n, X, P.k, P.p, P.q, P.seed, P.cutoff, P.maxdim, P.mindim, &r, &L, &R,
+                          nullptr));
+    qil_ctx_free(ctx, X);
+    QIL_TRY(compress_tt(ctx, dt, L, lb, r, first, mid, P, sites, dims));
+    QIL_TRY(compress_tt(ctx, dt, R, r, rb, mid + 1, last, P, sites, dims));
+    return QIL_OK;
+}
+
+// _tensor_to_mps_svd (SignalConverters.jl:77-98).  The carried tensor X[(s_n..s_i), alpha] is viewed
+// for free as Y[low, (s_i, alpha)] = M^T (L x 2r): the Jacobi SVD rotates its 2r columns, the site
+// tensor is V_y^h permuted, and the carry S V^h is U_y S -- already in the layout of the next step.
+int svd_sweep(qil_context* ctx, int dt, void* X, int64_t n, const EncodeParams& P, std::vector<void*>& sites,
+              std::vector<int64_t>& dims) {
+    const size_t e = qil_elem_size(dt);
+    int64_t r = 1;
+    dims[0] = 1;
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        const int64_t L = 1LL << (n - 1 - i);
+        int64_t k = 0;
+        void *UyS = nullptr, *Vyh = nullptr;
+        QIL_TRY(svd_trunc_dev(ctx, dt, L, 2 * r, X, L, P.cutoff, true, P.maxdim, 1, 1, &k, &UyS, &Vyh, nullptr));
+        qil_ctx_free(ctx, X);
+        void* A = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * 2 * k) * e, &A));
+        if (dt == QIL_C64)
+            hipLaunchKernelGGL(site_from_vh<c64>, dim3(nblk(2 * r * k)), dim3(256), 0, ctx->stream,
+                               (const c64*)Vyh, (long long)k, (int)r, (int)k, (c64*)A);
+        else
+            hipLaunchKernelGGL(site_from_vh<double>, dim3(nblk(2 * r * k)), dim3(256), 0, ctx->stream,
+                               (const double*)Vyh, (long long)k, (int)r, (int)k, (double*)A);
+        QIL_HIP(hipGetLastError());
+        qil_ctx_free(ctx, Vyh);
+        sites[(size_t)i] = A;
+        dims[(size_t)i + 1] = k;
+        X = UyS;  // (L x k): X'[(s_n..s_{i+1}), alpha']
+        r = k;
+    }
+    // last site: X[(s_n), alpha] -> A[alpha, s_n, 1]  == chunk layout with rb = 1
+    void* A = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * 2) * e, &A));
+    if (dt == QIL_C64)
+        hipLaunchKernelGGL(site_from_chunk<c64>, dim3(1), dim3(256), 0, ctx->stream, (const c64*)X, (int)r, 1,
+                           (c64*)A);
+    else
+        hipLaunchKernelGGL(site_from_chunk<double>, dim3(1), dim3(256), 0, ctx->stream, (const double*)X, (int)r,
+                           1, (double*)A);
+    QIL_HIP(hipGetLastError());
+    qil_ctx_free(ctx, X);
+    sites[(size_t)n - 1] = A;
+    dims[(size_t)n] = 1;
+    return QIL_OK;
+}
+
+int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, const EncodeParams& P,
+                    qil_mps** out) {
+    QIL_REQUIRE(ctx && x && out, QIL_EINVAL_ARG, "signal_mps: null argument");
+    QIL_REQUIRE(dtype == QIL_F64 || dtype == QIL_C64, QIL_EINVAL_ARG, "signal_mps: unknown dtype %d", dtype);
+    QIL_REQUIRE(P.method == QIL_METHOD_SVD || P.method == QIL_METHOD_RSVD, QIL_EINVAL_ARG,
+                "tensor_to_mps: unknown method %d. Use :svd or :rsvd.", P.method);
+    QIL_REQUIRE(len >= 1, QIL_EINVAL_LENGTH, "signal_mps: empty signal");
+    QIL_TRY(qil_ctx_activate(ctx));
+    // _array_to_tensor (SignalConverters.jl:16-46): n = round(log2 N), zero-fill, normalise
+    const int64_t n = std::max<int64_t>(1, (int64_t)std::llround(std::log2((double)len)));
+    const int64_t N = 1LL << n;
+    QIL_REQUIRE(len <= N, QIL_EINVAL_LENGTH,
+                "_array_to_tensor: Length of signal vector must be a power of 2 (got %lld)", (long long)len);
+    const int ncomp = dtype == QIL_C64 ? 2 : 1;
+    std::vector<double> xh((size_t)(N * ncomp), 0.0);
+    const double* xs = static_cast<const double*>(x);
+    double ss = 0;
+    for (int64_t i = 0; i < len * ncomp; ++i) ss += xs[i] * xs[i];
+    const double amp = std::sqrt(ss);
+    for (int64_t i = 0; i < len * ncomp; ++i) xh[(size_t)i] = xs[i] / amp;
+    const size_t e = qil_elem_size(dtype);
+    void* X = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)N * e, &X));
+    QIL_HIP(hipMemcpyAsync(X, xh.data(), (size_t)N * e, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<void*> sites((size_t)n, nullptr);
+    std::vector<int64_t> dims((size_t)n + 1, 1);
+    int s;
+    if (n == 1) {
+        // single site: A[1, s, 1] = x_hat[s]
+        sites[0] = X;
+        s = QIL_OK;
+    } else if (P.method == QIL_METHOD_SVD) {
+        s = svd_sweep(ctx, dtype, X, n, P, sites, dims);
+    } else {
+        s = compress_tt(ctx, dtype, X, 1, 1, 0, n - 1, P, sites, dims);
+    }
+    if (s != QIL_OK) {
+        for (void* p : sites)
+            if (p) qil_ctx_free(ctx, p);
+        return s;
+    }
+    qil_mps* psi = new qil_mps();
+    psi->ctx = ctx;
+    psi->dtype = dtype;
+    psi->paired = 0;
+    psi->phys_rank = 1;
+    psi->dims = dims;
+    psi->site = sites;
+    psi->site_ids.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) psi->site_ids[(size_t)i] = i + 1;
+    psi->amplitude = amp;
+    *out = psi;
+    return QIL_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- exported
+extern "C" int qil_canonicalize(qil_mps* psi, int direction, int64_t center, double cutoff, int64_t maxdim) {
+    QIL_REQUIRE(psi, QIL_EINVAL_ARG, "canonicalize!: null handle");
+    QIL_REQUIRE(direction == QIL_DIR_RIGHT || direction == QIL_DIR_LEFT, QIL_EINVAL_ARG,
+                "Direction must be :right or :left");
+    QIL_TRY(qil_ctx_activate(psi->ctx));
+    // the ZTMPS method forwards `center` unchanged to the 2n-site chain (mps.jl:880-881)
+    return canonicalize_impl(psi, direction, center, cutoff, maxdim);
+}
+
+extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps) {
+    QIL_REQUIRE(psi, QIL_EINVAL_ARG, "compress!: null handle");
+    const int64_t N = psi->n();
+    QIL_REQUIRE(N >= 2, QIL_EDOMAIN, "SignalMPS must have at least 2 sites.");   // mps.jl:918
+    QIL_REQUIRE(sweeps >= 1, QIL_EINVAL_ARG, "compress!: sweeps must be >= 1");
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    const int dt = psi->dtype;
+    const size_t e = qil_elem_size(dt);
+    const double cutoff = tol * tol / ((double)(N - 1) * sweeps);               // mps.jl:920
+    QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, 1e-12, kNoCap));            // mps.jl:923
+    for (int sw = 0; sw < sweeps; ++sw) {
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: L -> R keeping U | S V (mps.jl:927-942); pass 1: R -> L keeping U S | V (:944-959)
+            for (int64_t t = 0; t < N - 1; ++t) {
+                const int64_t j = pass == 0 ? t : N - 2 - t;
+                const int64_t cl = psi->dims[(size_t)j], c = psi->dims[(size_t)j + 1], cr = psi->dims[(size_t)j + 2];
+                void* theta = nullptr;
+                QIL_TRY(qil_ctx_alloc(ctx, (size_t)(4 * cl * cr) * e, &theta));
+                QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, 2 * cl, 2 * cr, c, psi->site[(size_t)j], 2 * cl,
+                                     psi->site[(size_t)j + 1], c, theta, 2 * cl));
+                int64_t r = 0;
+                void *U = nullptr, *Vh = nullptr;
+                QIL_TRY(svd_trunc_dev(ctx, dt, 2 * cl, 2 * cr, theta, 2 * cl, cutoff, true, maxdim, 1,
+                                      pass == 0 ? 2 : 1, &r, &U, &Vh, nullptr));
+                qil_ctx_free(ctx, theta);
+                QIL_TRY(qil_chain_set_site(psi, j, U, cl, r));
+                QIL_TRY(qil_chain_set_site(psi, j + 1, Vh, r, cr));
+            }
+        }
+    }
+    QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, 1e-12, kNoCap));            // mps.jl:963
+    double nrm = 0;
+    QIL_TRY(qil_norm(psi, &nrm));                                               // mps.jl:967-971
+    if (nrm != 0) {
+        psi->amplitude *= nrm;
+        const double inv = 1.0 / nrm;
+        std::vector<double> s((size_t)psi->dims[1], inv);
+        QIL_TRY(qil_dev_scale(ctx, dt, 1, 2 * psi->dims[0], psi->dims[1], psi->site[0], 2 * psi->dims[0], s.data()));
+    }
+    return QIL_OK;
+}
+
+extern "C" int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, double cutoff,
+                             int64_t maxdim, int64_t mindim, int64_t* rank, void* U, double* S, void* Vh) {
+    QIL_REQUIRE(ctx && A && rank && U && S && Vh, QIL_EINVAL_ARG, "svd: null argument");
+    QIL_REQUIRE(m >= 1 && n >= 1, QIL_EEMPTY, "svd: empty matrix");
+    QIL_TRY(qil_ctx_activate(ctx));
+    const size_t e = qil_elem_size(dtype);
+    void* dA = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
+    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t r = 0;
+    void *dU = nullptr, *dVh = nullptr;
+    std::vector<double> Sv;
+    QIL_TRY(svd_trunc_dev(ctx, dtype, m, n, dA, m, cutoff, cutoff >= 0, maxdim, mindim, 0, &r, &dU, &dVh, &Sv));
+    QIL_HIP(hipMemcpyAsync(U, dU, (size_t)(m * r) * e, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(Vh, dVh, (size_t)(r * n) * e, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < r; ++i) S[i] = Sv[(size_t)i];
+    *rank = r;
+    qil_ctx_free(ctx, dA);
+    qil_ctx_free(ctx, dU);
+    qil_ctx_free(ctx, dVh);
+    return QIL_OK;
+}
+
+// rsvd(A, Linds...; kwargs) on a host operand A (m x n, column-major): src/linalg/rsvd.jl:38-121.
+extern "C" int qil_rsvd(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, int64_t k, int64_t p,
+                        int q, uint64_t seed, double cutoff, int64_t maxdim, int64_t mindim, int64_t* rank,
+                        void* U, double* S, void* Vh) {
+    QIL_REQUIRE(ctx && rank && U && S && Vh, QIL_EINVAL_ARG, "rsvd: null argument");
+    QIL_REQUIRE(m >= 1 && n >= 1 && A, QIL_EEMPTY,
+                "In `rsvd`, left or right index set is empty.");               // rsvd.jl:56-60
+    QIL_REQUIRE(k >= 1 && p >= 0 && q >= 0, QIL_EINVAL_ARG, "rsvd: need k >= 1, p >= 0, q >= 0");
+    QIL_TRY(qil_ctx_activate(ctx));
+    const size_t e = qil_elem_size(dtype);
+    void *dA = nullptr, *Z = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &Z));
+    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_TRY(qil_dev_transpose(ctx, dtype, 0, m, n, dA, m, Z, n));               // Z = A^T ("A row-major")
+    qil_ctx_free(ctx, dA);
+    if (maxdim <= 0) maxdim = k;                                                 // maxdim = k default (rsvd.jl:47)
+    int64_t r = 0;
+    void *L = nullptr, *R = nullptr;
+    std::vector<double> Sv;
+    QIL_TRY(rsvd_rowmajor(ctx, dtype, m, n, Z, k, p, q, seed, cutoff, maxdim, mindim < 1 ? 1 : mindim, &r, &L, &R,
+                          &Sv));
+    qil_ctx_free(ctx, Z);
+    // L = U^T (r x m); R = (S V^h)^T (n x r).  Return U (m x r) and V^h (r x n) = (R diag(1/S))^T.
+    std::vector<double> inv((size_t)r);
+    for (int64_t i = 0; i < r; ++i) inv[(size_t)i] = Sv[(size_t)i] > 0 ? 1.0 / Sv[(size_t)i] : 0.0;
+    QIL_TRY(qil_dev_scale(ctx, dtype, 1, n, r, R, n, inv.data()));
+    void *dU = nullptr, *dVh = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * r) * e, &dU));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * n) * e, &dVh));
+    QIL_TRY(qil_dev_transpose(ctx, dtype, 0, r, m, L, r, dU, m));
+    QIL_TRY(qil_dev_transpose(ctx, dtype, 0, n, r, R, n, dVh, r));
+    QIL_HIP(hipMemcpyAsync(U, dU, (size_t)(m * r) * e, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(Vh, dVh, (size_t)(r * n) * e, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < r; ++i) S[i] = Sv[(size_t)i];
+    *rank = r;
+    qil_ctx_free(ctx, L);
+    qil_ctx_free(ctx, R);
+    qil_ctx_free(ctx, dU);
+    qil_ctx_free(ctx, dVh);
+    return QIL_OK;
+}
+
+extern "C" int qil_signal_mps(qil_context* ctx, const void* x, int64_t len, int dtype, int method, double cutoff,
+                              int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed, int64_t mindim,
+                              qil_mps** out) {
+    EncodeParams P{method, cutoff, maxdim <= 0 ? kNoCap : maxdim, k, p, q, seed, mindim < 1 ? 1 : mindim};
+    return signal_mps_impl(ctx, x, len, dtype, P, out);
+}
+
+extern "C" int qil_signal_ztmps(qil_context* ctx, const void* x, int64_t len, int dtype, int method,
+                                double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed,
+                                int64_t mindim, qil_mps** out) {
+    QIL_REQUIRE(out, QIL_EINVAL_ARG, "signal_ztmps: null out");
+    EncodeParams P{method, cutoff, maxdim <= 0 ? kNoCap : maxdim, k, p, q, seed, mindim < 1 ? 1 : mindim};
+    qil_mps* sig = nullptr;
+    QIL_TRY(signal_mps_impl(ctx, x, len, dtype, P, &sig));                        // SignalConverters.jl:251
+    const int64_t n = sig->n();
+    const size_t e = qil_elem_size(dtype);
+    qil_mps* zt = new qil_mps();
+    zt->ctx = ctx;
+    zt->dtype = dtype;
+    zt->paired = 1;
+    zt->phys_rank = 1;
+    zt->dims.assign((size_t)(2 * n) + 1, 1);
+    zt->site.assign((size_t)(2 * n), nullptr);
+    zt->site_ids.resize((size_t)(2 * n));
+    for (int64_t i = 0; i < 2 * n; ++i) zt->site_ids[(size_t)i] = i + 1;
+    zt->amplitude = sig->amplitude;
+    int status = QIL_OK;
+    for (int64_t i = 0; i < n && status == QIL_OK; ++i) {                          // :261-276
+        const int64_t cl = sig->dims[(size_t)i], cr = sig->dims[(size_t)i + 1];
+        void* T = nullptr;
+        status = qil_ctx_alloc(ctx, (size_t)(4 * cl * cr) * e, &T);
+        if (status != QIL_OK) break;
+        if (dtype == QIL_C64)
+            hipLaunchKernelGGL(fuse_delta<c64>, dim3(nblk(4 * cl * cr)), dim3(256), 0, ctx->stream,
+                               (const c64*)sig->site[(size_t)i], (int)cl, (int)cr, (c64*)T);
+        else
+            hipLaunchKernelGGL(fuse_delta<double>, dim3(nblk(4 * cl * cr)), dim3(256), 0, ctx->stream,
+                               (const double*)sig->site[(size_t)i], (int)cl, (int)cr, (double*)T);
+        int64_t r = 0;
+        void *U = nullptr, *SV = nullptr;
+        status = svd_trunc_dev(ctx, dtype, 2 * cl, 2 * cr, T, 2 * cl, P.cutoff, true, P.maxdim, 1, 2, &r, &U, &SV,
+                               nullptr);
+        qil_ctx_free(ctx, T);
+        if (status != QIL_OK) break;
+        zt->site[(size_t)(2 * i)] = U;        // core_main [b_{i-1}, s_main, c]
+        zt->site[(size_t)(2 * i + 1)] = SV;   // core_copy [c, s_copy, b_i]
+        zt->dims[(size_t)(2 * i)] = cl;
+        zt->dims[(size_t)(2 * i + 1)] = r;
+        zt->dims[(size_t)(2 * i + 2)] = cr;
+    }
+    qil_mps_destroy(sig);
+    if (status != QIL_OK) {
+        qil_mps_destroy(zt);
+        return status;
+    }
+    *out = zt;
+    return QIL_OK;
+}

@@ -1,0 +1,244 @@
+"""Host-side operator API mirroring the reference's method names (drop-in boundary):
+
+  apply / `*`        src/linalg/apply.jl:75-122, 124-199, 201-230, 233-236
+  coefficient        src/mps.jl:669-693 (parsers :616-645)
+  mps_to_vector      src/mps.jl:716-743
+  norm               src/mps.jl:754-771
+  canonicalize       src/mps.jl:787-847, 866-901   (Julia: canonicalize!)
+  compress           src/mps.jl:913-999            (Julia: compress!)
+  signal_mps         src/signals/SignalConverters.jl:228-233
+  signal_ztmps       src/signals/SignalConverters.jl:247-283
+  rsvd               src/linalg/rsvd.jl:38-121
+
+All arithmetic happens in libqilhip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+import warnings
+
+import numpy as np
+
+from . import _lib as L
+from .containers import (SignalMPS, ZTMPS, SingleSiteMPO, PairedSiteMPO, default_context, _np_dtype)
+
+
+def _wrap_like(psi, handle):
+    return type(psi)(ctx=psi.ctx, _handle=handle)
+
+
+# ---------------------------------------------------------------- apply
+def apply(W, psi, out=None, **kwargs):
+    """apply(W, psi; kwargs...) -> psi_out.  ``cutoff``/``maxdim`` kwargs are accepted and
+    ignored, exactly like the reference (apply.jl:75): apply never truncates."""
+    if isinstance(W, SingleSiteMPO) and isinstance(psi, SingleSiteMPO):
+        if W.paired != psi.paired:
+            raise TypeError("apply: cannot mix SingleSiteMPO and PairedSiteMPO")
+        h = C.c_void_p()
+        L.check(L.lib.qil_apply_mpo_mpo(W.handle, psi.handle, C.byref(h)))
+        return type(W)(ctx=W.ctx, _handle=h)
+    if not (isinstance(W, SingleSiteMPO) and isinstance(psi, SignalMPS)):
+        raise TypeError("apply: unsupported operand types")
+    if W.paired != psi.paired:
+        raise TypeError("apply: PairedSiteMPO acts on ZTMPS, SingleSiteMPO on SignalMPS")
+    if out is not None:
+        L.check(L.lib.qil_apply_into(W.handle, psi.handle, out.handle))
+        return out
+    h = C.c_void_p()
+    L.check(L.lib.qil_apply(W.handle, psi.handle, C.byref(h)))
+    return _wrap_like(psi, h)
+
+
+def _mul(self, other):
+    return apply(self, other)
+
+
+SingleSiteMPO.__mul__ = _mul          # W * psi, W1 * W2  (apply.jl:233-236)
+
+
+# ---------------------------------------------------------------- coefficient
+def _parse_config(spec, n):
+    """Front-ends of `coefficient` (src/mps.jl:616-645, 680-693)."""
+    if isinstance(spec, str):
+        s = spec.strip().strip("[](){}").strip()
+        if not s:
+            raise ValueError("coefficient: configuration string is empty")
+        if re.search(r"[,\s]", s):
+            toks = [t for t in re.split(r"[,\s]+", s) if t]
+            if not toks:
+                raise ValueError("coefficient: configuration string did not contain any entries")
+            return [int(t) for t in toks]
+        if any(c not in "01" for c in s):
+            raise ValueError("coefficient: bit strings may contain only '0' or '1'")
+        return [1 if c == "1" else 0 for c in s]
+    if isinstance(spec, (int, np.integer)) and not isinstance(spec, bool):
+        v = int(spec)
+        if v < 0:
+            raise ValueError("coefficient: integer configuration must be non-negative")
+        if v >> n:
+            raise ValueError(f"coefficient: integer {v} requires more than {n} bits")
+        return [(v >> (n - 1 - i)) & 1 for i in range(n)]
+    return [int(b) for b in spec]
+
+
+def _ntensors(psi):
+    return psi.ntensors if isinstance(psi, (ZTMPS, PairedSiteMPO)) else len(psi)
+
+
+def _bits_array(psi, bits):
+    n = _ntensors(psi)
+    b = np.asarray(bits)
+    if b.ndim != 2 or b.shape[1] != n:
+        got = b.shape[1] if b.ndim == 2 else b.shape
+        raise ValueError(f"coefficient: expected {n} entries, got {got}")
+    if b.size and (b.min() < 0 or b.max() > 1):
+        bad = int(b[(b < 0) | (b > 1)][0])
+        raise ValueError(f"coefficient: bit value {bad} outside [0,1]")
+    return np.ascontiguousarray(b, dtype=np.uint8)
+
+
+def coefficient_batch(psi, bits):
+    """Vectorised `coefficient`: bits is (nb, n_tensors) of {0,1}; returns (nb,) values
+    (complex for complex MPS, real otherwise), each amplitude * prod_i A_i[:, bit_i, :]."""
+    b = _bits_array(psi, bits)
+    nb = b.shape[0]
+    out = np.zeros(nb, dtype=np.complex128)
+    L.check(L.lib.qil_coefficient_batch(psi.handle, nb, b.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                        out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out if psi.dtype == np.complex128 else out.real.copy()
+
+
+def coefficient(psi, config):
+    """coefficient(psi, config): config is a list/tuple of bits, a bit string ("101" or
+    "[1,0,1]") or a non-negative integer read as an n-bit big-endian pattern."""
+    n = _ntensors(psi)
+    bits = _parse_config(config, n)
+    if len(bits) != n:
+        raise ValueError(f"coefficient: expected {n} entries, got {len(bits)}")
+    return coefficient_batch(psi, [bits])[0]
+
+
+def apply_coefficient_batch(W, psi, bits):
+    """<bits| W psi> without materialising W*psi (lazy path; same numbers as
+    coefficient_batch(apply(W, psi), bits))."""
+    b = _bits_array(psi, bits)
+    nb = b.shape[0]
+    out = np.zeros(nb, dtype=np.complex128)
+    L.check(L.lib.qil_apply_coefficient_batch(W.handle, psi.handle, nb,
+                                              b.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                              out.ctypes.data_as(C.POINTER(C.c_double))))
+    if psi.dtype == np.complex128 or W.dtype == np.complex128:
+        return out
+    return out.real.copy()
+
+
+# ---------------------------------------------------------------- dense read-out, norm
+def mps_to_vector(psi, reverse=False):
+    n = _ntensors(psi)
+    out = np.empty(2 ** n, dtype=psi.dtype)
+    L.check(L.lib.qil_mps_to_vector(psi.handle, 1 if reverse else 0, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def norm(psi) -> float:
+    v = C.c_double()
+    L.check(L.lib.qil_norm(psi.handle, C.byref(v)))
+    return v.value
+
+
+# ---------------------------------------------------------------- truncation
+def _maxdim(m):
+    return L.QIL_MAXDIM_NONE if m is None else int(m)
+
+
+def canonicalize(psi, direction, center=None, cutoff=1e-12, maxdim=None):
+    """canonicalize!(psi, direction; center, cutoff, maxdim) -- in place, returns psi."""
+    if direction not in ("right", "left"):
+        raise ValueError("Direction must be :right or :left")
+    L.check(L.lib.qil_canonicalize(psi.handle, L.QIL_DIR_RIGHT if direction == "right" else L.QIL_DIR_LEFT,
+                                   0 if center is None else int(center), float(cutoff), _maxdim(maxdim)))
+    return psi
+
+
+def compress(psi, maxdim=None, tol=1e-12, sweeps=1):
+    """compress!(psi; maxdim, tol, sweeps) -- in place, returns psi."""
+    L.check(L.lib.qil_compress(psi.handle, _maxdim(maxdim), float(tol), int(sweeps)))
+    return psi
+
+
+# ---------------------------------------------------------------- encode
+def _encode(fn, cls, x, method, cutoff, maxdim, k, p, q, random_seed, mindim, ctx):
+    if method not in ("svd", "rsvd"):
+        raise ValueError(f"tensor_to_mps: unknown method {method}. Use :svd or :rsvd.")
+    ctx = ctx or default_context()
+    x = np.asarray(x)
+    code = L.QIL_C64 if np.iscomplexobj(x) else L.QIL_F64
+    xs = np.ascontiguousarray(x, dtype=_np_dtype(code))
+    N = len(xs)
+    n = max(1, int(round(np.log2(N))))
+    if N < 2 ** n:
+        warnings.warn(f"_array_to_tensor: input length {N} is not a power of 2; zero-filling to {2**n}")
+    h = C.c_void_p()
+    L.check(fn(ctx.handle, xs.ctypes.data_as(C.c_void_p), N, code,
+               L.QIL_METHOD_SVD if method == "svd" else L.QIL_METHOD_RSVD, float(cutoff), _maxdim(maxdim),
+               int(k), int(p), int(q), C.c_uint64(random_seed), int(mindim), C.byref(h)))
+    return cls(ctx=ctx, _handle=h)
+
+
+def signal_mps(x, method="svd", cutoff=1e-15, maxdim=None, k=20, p=10, q=0, random_seed=1234, mindim=1,
+               ctx=None):
+    """signal_mps(x; method=:svd, cutoff, maxdim, k, p, q, random_seed, mindim)."""
+    return _encode(L.lib.qil_signal_mps, SignalMPS, x, method, cutoff, maxdim, k, p, q, random_seed, mindim, ctx)
+
+
+def signal_ztmps(x, cutoff=1e-10, maxdim=None, method="svd", k=20, p=10, q=0, random_seed=1234, mindim=1,
+                 ctx=None):
+    """signal_ztmps(x; cutoff=1e-10, maxdim, kwargs...)."""
+    return _encode(L.lib.qil_signal_ztmps, ZTMPS, x, method, cutoff, maxdim, k, p, q, random_seed, mindim, ctx)
+
+
+def _factor_out(m, n, r0, code):
+    dt = _np_dtype(code)
+    return (np.empty((m, r0), dtype=dt, order="F"), np.empty(r0, dtype=np.float64),
+            np.empty(r0 * n, dtype=dt))
+
+
+def rsvd(A, k=20, p=10, q=0, random_seed=1234, cutoff=1e-15, maxdim=None, mindim=1, ctx=None):
+    """rsvd(A, Linds...; k, p, q, random_seed, cutoff, maxdim=k, mindim) on the matricised
+    operand A (m x n).  Returns (U, S, Vh) with A ~= U diag(S) Vh."""
+    ctx = ctx or default_context()
+    A = np.asarray(A)
+    if A.ndim != 2 or A.shape[0] == 0 or A.shape[1] == 0:
+        raise ValueError("In `rsvd`, left or right index set is empty.")
+    code = L.QIL_C64 if np.iscomplexobj(A) else L.QIL_F64
+    Af = np.asfortranarray(A, dtype=_np_dtype(code))
+    m, n = Af.shape
+    r0 = min(k + p, m, n)
+    U, S, Vh = _factor_out(m, n, r0, code)
+    r = C.c_int64()
+    L.check(L.lib.qil_rsvd(ctx.handle, Af.ctypes.data_as(C.c_void_p), m, n, code, int(k), int(p), int(q),
+                           C.c_uint64(random_seed), float(cutoff), int(k if maxdim is None else maxdim),
+                           int(mindim), C.byref(r), U.ctypes.data_as(C.c_void_p),
+                           S.ctypes.data_as(C.POINTER(C.c_double)), Vh.ctypes.data_as(C.c_void_p)))
+    r = r.value
+    return U[:, :r].copy(), S[:r].copy(), Vh[: r * n].reshape((r, n), order="F").copy()
+
+
+def svd_trunc(A, cutoff=None, maxdim=None, mindim=1, ctx=None):
+    """Truncated svd with the ITensors rule (keep largest; drop tail while the discarded squared
+    weight <= cutoff * total; cap maxdim; floor mindim)."""
+    ctx = ctx or default_context()
+    A = np.asarray(A)
+    code = L.QIL_C64 if np.iscomplexobj(A) else L.QIL_F64
+    Af = np.asfortranarray(A, dtype=_np_dtype(code))
+    m, n = Af.shape
+    r0 = min(m, n)
+    U, S, Vh = _factor_out(m, n, r0, code)
+    r = C.c_int64()
+    L.check(L.lib.qil_svd_trunc(ctx.handle, Af.ctypes.data_as(C.c_void_p), m, n, code,
+                                -1.0 if cutoff is None else float(cutoff), _maxdim(maxdim), int(mindim),
+                                C.byref(r), U.ctypes.data_as(C.c_void_p),
+                                S.ctypes.data_as(C.POINTER(C.c_double)), Vh.ctypes.data_as(C.c_void_p)))
+    r = r.value
+    return U[:, :r].copy(), S[:r].copy(), Vh[: r * n].reshape((r, n), order="F").copy()

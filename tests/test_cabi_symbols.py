@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/qilaplace_hip.h declares; host-side argument parsing mirrors the reference."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "qilaplace_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qil_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    syms = _declared_symbols()
+    for must in ("qil_apply", "qil_apply_into", "qil_apply_mpo_mpo", "qil_coefficient_batch",
+                 "qil_compress", "qil_canonicalize", "qil_signal_mps", "qil_signal_ztmps", "qil_rsvd",
+                 "qil_mps_to_vector", "qil_norm", "qil_mps_create", "qil_mpo_create", "qil_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import qilaplace_jl_amd as qil
+    lib = ctypes.CDLL(qil.LIB_PATH)
+    missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+
+
+def test_python_prototypes_cover_the_header():
+    import importlib
+    L = importlib.import_module("qilaplace_jl_amd._lib")
+    declared = set(_declared_symbols())
+    bound = set(L.PROTOTYPES) | {"qil_last_error", "qil_version"}
+    assert declared == bound, (declared ^ bound)
+
+
+def test_config_parsing_matches_reference_front_ends():
+    import importlib
+    ops = importlib.import_module("qilaplace_jl_amd.ops")
+    for cfg in ([1, 0, 1], (1, 0, 1), "101", "[1,0,1]", "1 0 1", 0b101):
+        assert ops._parse_config(cfg, 3) == [1, 0, 1]
+    with pytest.raises(ValueError, match="more than 3 bits"):
+        ops._parse_config(8, 3)
+    with pytest.raises(ValueError, match="non-negative"):
+        ops._parse_config(-1, 3)
+    with pytest.raises(ValueError, match="only '0' or '1'"):
+        ops._parse_config("1a1", 3)
+    with pytest.raises(ValueError, match="empty"):
+        ops._parse_config("[]", 3)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "qilaplace.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
+    bench = open(os.path.join(ROOT, "qilaplace_jl_amd.py")).read()
+    assert "oracle" not in bench

@@ -1,0 +1,412 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the numpy oracle on the same
+seeded inputs, against the committed golden pins, and against closed forms.
+
+Tolerances (fp64): apply / coefficient / dense read-out 1e-12 relative (exact linear algebra,
+different summation order only); transforms vs closed forms 1e-10 (QFT, n <= 5 builders at
+cutoff 1e-14 ... 1e-7 for DT / 2e-7 for zT, the reference's own bounds, MPO-cutoff limited);
+truncating ops compared through gauge-invariant quantities only."""
+import numpy as np
+import pytest
+
+import oracle as O
+from oracle.analytic import int_to_bits
+from helpers import (random_mps_data, random_mpo_data, saturated_profile, dense_mps, all_bits,
+                     interleave)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qil():
+    import qilaplace_jl_amd as q
+    assert q.device_count() >= 1
+    return q
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(np.asarray(b)).max())
+
+
+# ---------------------------------------------------------------- containers
+def test_roundtrip_and_metadata(qil):
+    rng = np.random.default_rng(1)
+    d = random_mps_data([2, 3, 5, 2], rng, np.complex128)
+    psi = qil.SignalMPS(d, amplitude=2.5)
+    assert len(psi) == 5 and psi.bond_dims == [2, 3, 5, 2] and psi.amplitude == 2.5
+    assert psi.dtype == np.complex128 and not psi.paired and psi.site_ids == [1, 2, 3, 4, 5]
+    for i, t in enumerate(d):
+        assert np.array_equal(psi.site(i), t)
+    w = random_mpo_data([3, 2], rng, np.float64)
+    W = qil.SingleSiteMPO(w, sites=[7, 8, 9])
+    assert W.bond_dims == [3, 2] and W.site_ids == [7, 8, 9] and W.dtype == np.float64
+    assert np.array_equal(W.site(1), w[1])
+    c = psi.copy()
+    c.amplitude = 1.0
+    assert psi.amplitude == 2.5 and np.array_equal(c.site(2), d[2])
+    with pytest.raises(ValueError):
+        qil.SignalMPS([np.zeros((1, 2, 3)), np.zeros((2, 2, 1))])
+    with pytest.raises(ValueError):
+        qil.ZTMPS(random_mps_data([2, 2], rng))             # odd tensor count
+
+
+# ---------------------------------------------------------------- apply (A1)
+@pytest.mark.parametrize("wdt,adt", [(np.float64, np.float64), (np.complex128, np.float64),
+                                     (np.float64, np.complex128), (np.complex128, np.complex128)])
+def test_apply_sitewise_bit_layout(qil, wdt, adt):
+    """Site tensors equal the oracle's element-wise (same fused layout), ragged bond dims."""
+    rng = np.random.default_rng(11)
+    a = random_mps_data([2, 5, 13, 7, 3, 2], rng, adt)
+    w = random_mpo_data([3, 9, 17, 6, 4, 2], rng, wdt)
+    got = qil.apply(qil.SingleSiteMPO(w), qil.SignalMPS(a, amplitude=1.75))
+    ref = O.apply(O.SingleSiteMPO(w), O.SignalMPS(a, amplitude=1.75))
+    assert got.bond_dims == ref.bond_dims and got.amplitude == 1.75
+    assert got.dtype == np.result_type(wdt, adt)
+    for i in range(len(ref)):
+        assert rel(got.site(i), ref.data[i]) < 1e-14
+
+
+def test_apply_saturated_profile_n12(qil):
+    rng = np.random.default_rng(12)
+    L = 12
+    a = random_mps_data(saturated_profile(L, 16), rng)
+    w = random_mpo_data(saturated_profile(L, 32, base=4), rng)
+    W, psi = qil.SingleSiteMPO(w), qil.SignalMPS(a)
+    got = W * psi
+    ref = O.apply(O.SingleSiteMPO(w), O.SignalMPS(a))
+    for i in range(L):
+        assert rel(got.site(i), ref.data[i]) < 1e-14
+    into = qil.SignalMPS.alloc(got.bond_dims, dtype=np.complex128)
+    qil.apply(W, psi, out=into)
+    for i in (0, 5, 6, 11):
+        assert np.array_equal(into.site(i), got.site(i))
+
+
+def test_apply_edge_shapes(qil):
+    rng = np.random.default_rng(13)
+    # single site, bond-dim-1 chains, chi_l not dividing the 256-row tile, D_r beyond one b-chunk
+    for abonds, wbonds in (([], []), ([1, 1], [1, 1]), ([70, 3], [5, 40]), ([3, 300], [2, 1])):
+        a = random_mps_data(abonds, rng)
+        w = random_mpo_data(wbonds, rng)
+        got = qil.apply(qil.SingleSiteMPO(w), qil.SignalMPS(a))
+        ref = O.apply(O.SingleSiteMPO(w), O.SignalMPS(a))
+        for i in range(len(ref)):
+            assert rel(got.site(i), ref.data[i]) < 1e-14
+
+
+def test_apply_errors(qil):
+    rng = np.random.default_rng(3)
+    psi = qil.SignalMPS(random_mps_data([2, 2], rng))
+    with pytest.raises(ValueError, match="same number of sites"):
+        qil.apply(qil.SingleSiteMPO.identity(4), psi)
+    with pytest.raises(ValueError, match="same site indices"):
+        qil.apply(qil.SingleSiteMPO.identity(3, sites=[4, 5, 6]), psi)
+    with pytest.raises(ValueError, match="compatible sizes"):
+        qil.apply(qil.PairedSiteMPO.identity(3), qil.ZTMPS(random_mps_data([2, 2, 2], rng)))
+    with pytest.raises(TypeError):
+        qil.apply(qil.PairedSiteMPO.identity(1), qil.SignalMPS(random_mps_data([2], rng)))
+
+
+def test_apply_paired_identity_and_amplitude(qil):               # test_apply.jl:277-300
+    rng = np.random.default_rng(5)
+    d = random_mps_data([2, 3, 2, 3, 2], rng)
+    out = qil.apply(qil.PairedSiteMPO.identity(3), qil.ZTMPS(d, amplitude=2.5))
+    assert isinstance(out, qil.ZTMPS) and out.amplitude == 2.5 and len(out) == 3
+    assert rel(dense_mps(out.to_host()), dense_mps(d)) < 1e-14
+
+
+def test_mpo_mpo_composition(qil):                                # test_apply.jl:302-455
+    rng = np.random.default_rng(9)
+    w1, w2 = random_mpo_data([2, 3, 2], rng), random_mpo_data([3, 2, 2], rng, np.float64)
+    got = qil.apply(qil.SingleSiteMPO(w1), qil.SingleSiteMPO(w2))
+    ref = O.apply(O.SingleSiteMPO(w1), O.SingleSiteMPO(w2))
+    assert got.bond_dims == ref.bond_dims
+    for i in range(4):
+        assert rel(got.site(i), ref.data[i]) < 1e-14
+    ws = random_mpo_data([2], rng, np.float64)
+    wl = random_mpo_data([2, 2, 2], rng)
+    for first, second in (("s", "l"), ("l", "s")):
+        mk = {"s": (ws, [2, 3]), "l": (wl, [1, 2, 3, 4])}
+        g = qil.apply(qil.SingleSiteMPO(*mk[first]), qil.SingleSiteMPO(*mk[second]))
+        r = O.apply(O.SingleSiteMPO(*mk[first]), O.SingleSiteMPO(*mk[second]))
+        assert g.site_ids == [1, 2, 3, 4]
+        for i in range(4):
+            assert rel(g.site(i), r.data[i]) < 1e-14
+    with pytest.raises(ValueError, match="No matching sites"):
+        qil.apply(qil.SingleSiteMPO.identity(2, sites=[7, 8]), qil.SingleSiteMPO(wl, sites=[1, 2, 3, 4]))
+
+
+# ---------------------------------------------------------------- read-out (C1, C2, K3)
+def test_coefficient_front_ends_and_errors(qil):                  # test_mps.jl:404-445
+    data = []
+    for b in (1, 0, 1):
+        A = np.zeros((1, 2, 1)); A[0, b, 0] = 1.0; data.append(A)
+    psi = qil.SignalMPS(data, amplitude=3.0)
+    for cfg in ([1, 0, 1], (1, 0, 1), "101", "[1,0,1]", "1 0 1", 0b101):
+        assert abs(qil.coefficient(psi, cfg) - 3.0) < 1e-12
+    assert abs(psi[1, 0, 1] - 3.0) < 1e-12 and abs(qil.coefficient(psi, "100")) < 1e-12
+    with pytest.raises(ValueError, match="expected 3 entries"):
+        qil.coefficient(psi, [1, 0])
+    with pytest.raises(ValueError, match="outside"):
+        qil.coefficient(psi, [1, 0, 2])
+    with pytest.raises(ValueError, match="more than 3 bits"):
+        qil.coefficient(psi, 8)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+def test_coefficient_batch_vs_oracle(qil, dt):
+    rng = np.random.default_rng(21)
+    L = 10
+    a = random_mps_data([2, 4, 8, 16, 70, 16, 8, 3, 2], rng, dt)
+    psi = qil.SignalMPS(a, amplitude=0.7)
+    bits = rng.integers(0, 2, size=(300, L))
+    assert rel(qil.coefficient_batch(psi, bits), O.coefficient_batch(O.SignalMPS(a, amplitude=0.7), bits)) < 1e-12
+    assert rel(qil.mps_to_vector(psi), O.mps_to_vector(O.SignalMPS(a, amplitude=0.7))) < 1e-12
+    assert rel(qil.mps_to_vector(psi, reverse=True),
+               O.mps_to_vector(O.SignalMPS(a, amplitude=0.7), reverse=True)) < 1e-12
+    assert abs(qil.norm(psi) - O.norm(O.SignalMPS(a))) < 1e-12
+
+
+def test_lazy_coefficient_equals_materialised(qil):
+    rng = np.random.default_rng(22)
+    L = 8
+    a = random_mps_data(saturated_profile(L, 8), rng)
+    w = random_mpo_data(saturated_profile(L, 12, base=4), rng)
+    W, psi = qil.SingleSiteMPO(w), qil.SignalMPS(a, amplitude=1.3)
+    bits = rng.integers(0, 2, size=(128, L))
+    mat = qil.coefficient_batch(W * psi, bits)
+    lazy = qil.apply_coefficient_batch(W, psi, bits)
+    ref = O.coefficient_batch(O.apply(O.SingleSiteMPO(w), O.SignalMPS(a, amplitude=1.3)), bits)
+    assert rel(mat, ref) < 1e-12 and rel(lazy, ref) < 1e-12
+
+
+# ---------------------------------------------------------------- transforms through the HIP apply
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 10])
+def test_qft_vs_fft(qil, n):                                      # test_qft_transformer.jl:427-464
+    rng = np.random.default_rng(100 + n)
+    N = 2 ** n
+    sig = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    ref_psi = O.signal_mps(sig)
+    Wd = O.build_qft_mpo(n)
+    out = qil.SingleSiteMPO(Wd.data) * qil.SignalMPS(ref_psi.data, amplitude=ref_psi.amplitude)
+    fn = qil.mps_to_vector(out, reverse=True)
+    tol = 1e-10 if n <= 5 else 1e-7 * np.linalg.norm(sig)         # MPO cutoff 1e-14 => 1e-7 amplitude
+    assert np.linalg.norm(fn - np.fft.fft(sig) / np.sqrt(N)) < tol
+    k = rng.integers(0, N, size=8)
+    bits = np.array([int_to_bits(int(v), n, "lsb") for v in k])
+    assert np.abs(qil.coefficient_batch(out, bits) - (np.fft.fft(sig) / np.sqrt(N))[k]).max() < tol
+
+
+def test_readme_quickstart_config1(qil):
+    """BASELINE.json configs[0]: n=10 sin_decay, signal_mps :svd cutoff=1e-9, build_qft_mpo, W*psi."""
+    n = 10
+    N = 2 ** n
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    psi = qil.signal_mps(x, method="svd", cutoff=1e-9)
+    W = qil.SingleSiteMPO(O.build_qft_mpo(n, cutoff=1e-14).data)
+    out = W * psi
+    got = qil.coefficient_batch(out, np.array([int_to_bits(k, n, "lsb") for k in range(N)]))
+    ref = np.fft.fft(x) / np.sqrt(N)
+    assert np.abs(got - ref).max() < 1e-4 * np.abs(ref).max()     # encode cutoff 1e-9 limited
+    ora = O.coefficient_batch(O.apply(O.build_qft_mpo(n), O.SignalMPS(psi.to_host(), amplitude=psi.amplitude)),
+                              np.array([int_to_bits(k, n, "lsb") for k in range(N)]))
+    assert rel(got, ora) < 1e-12
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("wr", [0.75, 5.0])
+def test_dt_and_zt_basis_states(qil, n, wr):                      # test_dt/zt_transformer.jl
+    N = 2 ** n
+    Wdt = qil.PairedSiteMPO(O.build_dt_mpo(n, wr).data)
+    Wzt = qil.PairedSiteMPO(O.build_zt_mpo(n, wr).data)
+    kl = np.array([interleave(int_to_bits(k, n, "lsb"), int_to_bits(l, n, "lsb"))
+                   for k in range(N) for l in range(N)])
+    for j in range(N):
+        data = []
+        for b in int_to_bits(j, n):
+            for _ in range(2):
+                A = np.zeros((1, 2, 1)); A[0, b, 0] = 1; data.append(A)
+        psi = qil.ZTMPS(data)
+        kj = np.array([interleave(int_to_bits(k, n, "lsb"), int_to_bits(j, n)) for k in range(N)])
+        got = qil.coefficient_batch(Wdt * psi, kj)
+        ref = O.analytical_dt(np.eye(N)[j], wr)
+        assert np.abs(got - ref).max() < 1e-7 * max(1.0, np.linalg.norm(ref))
+        got = qil.coefficient_batch(Wzt * psi, kl)
+        assert np.abs(got - O.analytical_zt(np.eye(N)[j], wr=wr).reshape(-1)).max() < 2e-7
+
+
+def test_tutorial_pins_through_hip(qil, pins):
+    # DT tutorial (docs/src/tutorials/dt.md): bonds and Laplace values
+    p = pins["dt_tutorial"]
+    n, dt, wr = p["n"], p["dt"], p["wr"]
+    N = 2 ** n
+    x = np.exp(-p["a"] * dt * np.arange(N))
+    psiz = qil.signal_ztmps(x, cutoff=1e-14, maxdim=64)
+    assert psiz.bonds_copy == p["ztmps_bonds_copy"] and psiz.bonds_main == p["ztmps_bonds_main"]
+    out = qil.PairedSiteMPO(O.build_dt_mpo(n, wr, cutoff=1e-14, maxdim=64).data) * psiz
+    assert out.bond_dims == p["applied_chain_bonds"]
+    L = []
+    for k in range(N):
+        bits = np.array([interleave(int_to_bits(k, n, "lsb"), int_to_bits(j, n)) for j in range(N)])
+        L.append(dt * np.sqrt(N) * qil.coefficient_batch(out, bits).sum())
+    assert abs(L[0] - p["L_s0"]) < 1e-13
+    assert np.abs(np.round(np.real(L), 5) - np.array(p["L_rounded5"])).max() < 1e-12
+    # zT tutorial (docs/src/tutorials/zt.md): 4x4 chi table
+    p = pins["zt_tutorial"]
+    n = p["n"]
+    N = 2 ** n
+    x = np.array([p["a"] ** j * np.cos(np.pi * p["w0_over_pi"] * j) for j in range(N)])
+    psiz = qil.signal_ztmps(x, cutoff=1e-14, maxdim=64)
+    b2 = int_to_bits(2, n)
+    assert abs(qil.coefficient(psiz, interleave(b2, b2)) - p["amp_match_j2"]) < 1e-14
+    out = qil.PairedSiteMPO(O.build_zt_mpo(n, 2 * np.pi, cutoff=1e-14, maxdim=64).data) * psiz
+    bits = np.array([interleave(int_to_bits(k, n, "lsb"), int_to_bits(l, n, "lsb"))
+                     for k in range(N) for l in range(N)])
+    chi = qil.coefficient_batch(out, bits).reshape(N, N)
+    assert np.abs(np.round(chi.real, 4) - np.array(p["chi_rounded4_re"])).max() < 1e-12
+    assert np.abs(np.round(chi.imag, 4) - np.array(p["chi_rounded4_im"])).max() < 1e-12
+    # signal tutorial: bonds (1,2,2), first sample
+    p = pins["signal_tutorial"]
+    psi = qil.signal_mps(np.array(p["x"]), method="svd", cutoff=1e-14)
+    assert psi.bond_dims == p["bonds"]
+    assert abs(qil.coefficient(psi, [0, 0, 0, 0]) - p["x"][0]) < 1e-13
+    # dft tutorial: applied bonds are products (no truncation in apply)
+    p = pins["dft_tutorial"]
+    psi = qil.signal_mps(np.sin(2 * np.pi * np.arange(16) / 16))
+    assert psi.bond_dims == p["signal_bonds"]
+    out = qil.SingleSiteMPO(O.build_qft_mpo(4, cutoff=1e-14, maxdim=100).data) * psi
+    assert out.bond_dims == p["applied_bonds"]
+
+
+# ---------------------------------------------------------------- truncation (K1, K2)
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+@pytest.mark.parametrize("direction", ["left", "right"])
+def test_canonicalize(qil, dt, direction):                        # test_mps.jl:156-180
+    rng = np.random.default_rng(4)
+    d = random_mps_data([2, 4, 7, 4, 2], rng, dt)
+    psi = qil.SignalMPS(d)
+    qil.canonicalize(psi, direction)
+    h = psi.to_host()
+    assert rel(dense_mps(h), dense_mps(d)) < 1e-10
+    if direction == "left":
+        for A in h[1:]:
+            M = A.reshape(A.shape[0], -1)
+            assert np.abs(M @ M.conj().T - np.eye(M.shape[0])).max() < 1e-10
+    else:
+        for A in h[:-1]:
+            M = A.reshape(-1, A.shape[2])
+            assert np.abs(M.conj().T @ M - np.eye(M.shape[1])).max() < 1e-10
+    with pytest.raises(ArithmeticError):
+        qil.canonicalize(psi, direction, center=9)
+    with pytest.raises(ValueError):
+        qil.canonicalize(psi, "up")
+
+
+def test_compress_postconditions(qil):                            # test_mps.jl:331-369
+    rng = np.random.default_rng(6)
+    d = random_mps_data([2, 4, 2], rng, normalize=False)
+    psi = qil.SignalMPS(d, amplitude=1.0)
+    qil.compress(psi, maxdim=2, tol=1e-8, sweeps=2)
+    assert max(psi.bond_dims) <= 2 and abs(qil.norm(psi) - 1.0) < 1e-8
+    ref = O.SignalMPS([t.copy() for t in d])
+    O.compress(ref, maxdim=2, tol=1e-8, sweeps=2)
+    assert psi.bond_dims == ref.bond_dims and abs(psi.amplitude - ref.amplitude) < 1e-10
+    assert rel(np.abs(qil.mps_to_vector(psi)), np.abs(O.mps_to_vector(ref))) < 1e-8
+    d2 = random_mps_data([2, 4, 2], rng, normalize=False)
+    psi2 = qil.SignalMPS(d2)
+    qil.compress(psi2, tol=1e-12)
+    assert rel(qil.mps_to_vector(psi2), dense_mps(d2).reshape(-1)) < 1e-10
+    zt = qil.ZTMPS(random_mps_data([2, 4, 4, 4, 2], rng, normalize=False))
+    qil.compress(zt, maxdim=2, tol=1e-8, sweeps=2)
+    assert max(zt.bond_dims) <= 2 and abs(qil.norm(zt) - 1.0) < 1e-8
+    with pytest.raises(ArithmeticError):
+        qil.compress(qil.SignalMPS([np.ones((1, 2, 1))]))
+
+
+def test_apply_then_compress_matches_oracle_bonds(qil):
+    n = 8
+    x = np.sin(2 * np.pi * np.arange(2 ** n) / 2 ** n * 3.0)
+    psi = qil.signal_mps(x, cutoff=1e-14)
+    out = qil.SingleSiteMPO(O.build_qft_mpo(n).data) * psi
+    full = qil.mps_to_vector(out)
+    qil.compress(out, tol=1e-5)
+    assert max(out.bond_dims) <= 2
+    assert np.abs(qil.mps_to_vector(out) - full).max() < 1e-5
+
+
+# ---------------------------------------------------------------- encode (E1-E4)
+def test_signal_mps_svd_and_rsvd(qil):                            # test_signal_converters.jl
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(64)
+    psi = qil.signal_mps(x)
+    assert abs(psi.amplitude - np.linalg.norm(x)) < 1e-12
+    assert psi.bond_dims == O.signal_mps(x).bond_dims
+    assert rel(qil.mps_to_vector(psi), x) < 1e-12
+    assert rel(qil.coefficient_batch(psi, all_bits(6)), x) < 1e-12
+    psi_r = qil.signal_mps(x, method="rsvd", k=16, p=8, q=2)
+    assert rel(qil.mps_to_vector(psi_r), x) < 1e-8
+    xc = x + 1j * rng.standard_normal(64)
+    assert rel(qil.mps_to_vector(qil.signal_mps(xc)), xc) < 1e-12
+    assert rel(qil.mps_to_vector(qil.signal_mps(xc, method="rsvd", k=16, p=8, q=1)), xc) < 1e-8
+    with pytest.raises(ValueError, match="unknown method"):
+        qil.signal_mps(x, method="qr")
+    with pytest.warns(UserWarning):
+        p6 = qil.signal_mps(np.arange(1.0, 7.0))
+    assert rel(qil.mps_to_vector(p6)[:6], np.arange(1.0, 7.0)) < 1e-12
+    # structured signal: bonds match the oracle's truncation
+    xs = O.generate_signal(10, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    assert qil.signal_mps(xs, cutoff=1e-9).bond_dims == O.signal_mps(xs, cutoff=1e-9).bond_dims
+    pr = qil.signal_mps(xs, method="rsvd", k=12, p=6, q=2, cutoff=1e-12)
+    assert rel(qil.mps_to_vector(pr), xs) < 1e-5
+
+
+def test_signal_ztmps(qil):
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal(16)
+    zt = qil.signal_ztmps(x, cutoff=1e-14)
+    ref = O.signal_ztmps(x, cutoff=1e-14)
+    assert zt.bonds_copy == ref.bonds_copy and zt.bonds_main == ref.bonds_main
+    bits = np.array([interleave(int_to_bits(j, 4), int_to_bits(j, 4)) for j in range(16)])
+    assert rel(qil.coefficient_batch(zt, bits), x) < 1e-12
+    assert abs(qil.coefficient(zt, [0, 1] + [0, 0] * 3)) < 1e-13
+
+
+def test_rsvd_low_rank_fixture(qil):                              # test_rsvd.jl:5-16, 27-62
+    rng = np.random.default_rng(12)
+    m = 100
+    U0, _ = np.linalg.qr(rng.standard_normal((m, 10)))
+    V0, _ = np.linalg.qr(rng.standard_normal((m, 10)))
+    s0 = np.exp(-np.arange(1, 11) / 2.0)
+    A = (U0 * s0) @ V0.T
+    U, S, Vh = qil.rsvd(A, k=15, p=5, q=2)
+    assert np.linalg.norm(A - (U * S) @ Vh) / np.linalg.norm(A) < 1e-10
+    assert np.all(np.diff(S) <= 0) and np.all(S >= 0)
+    assert np.abs(S[:10] - s0).max() < 1e-12
+    assert np.abs(U.T @ U - np.eye(len(S))).max() < 1e-10
+    assert np.abs(Vh @ Vh.T - np.eye(len(S))).max() < 1e-10
+    assert len(qil.rsvd(A, k=15, p=5, maxdim=4)[1]) == 4
+    assert len(qil.rsvd(A, k=15, p=5, cutoff=1e-4)[1]) < 10
+    assert np.array_equal(S, qil.rsvd(A, k=15, p=5, q=2)[1])   # seed determinism
+    Ac = A + 1j * (V0 * s0) @ U0.T
+    Uc, Sc, Vc = qil.rsvd(Ac, k=25, p=5, q=2)
+    assert np.linalg.norm(Ac - (Uc * Sc) @ Vc) / np.linalg.norm(Ac) < 1e-10
+    with pytest.raises(ValueError, match="empty"):
+        qil.rsvd(np.zeros((0, 4)))
+
+
+@pytest.mark.parametrize("shape", [(40, 12), (12, 40), (33, 33)])
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+def test_svd_trunc_vs_lapack(qil, shape, dt):
+    rng = np.random.default_rng(14)
+    A = rng.standard_normal(shape)
+    if dt == np.complex128:
+        A = A + 1j * rng.standard_normal(shape)
+    U, S, Vh = qil.svd_trunc(A)
+    assert np.abs(S - np.linalg.svd(A, compute_uv=False)).max() < 1e-12
+    assert np.abs((U * S) @ Vh - A).max() < 1e-12
+    assert np.abs(U.conj().T @ U - np.eye(len(S))).max() < 1e-12
+    s = np.array([1.0, 1e-3, 1e-8, 0.0])
+    Q1, _ = np.linalg.qr(rng.standard_normal((6, 4)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((5, 4)))
+    B = (Q1 * s) @ Q2.T
+    assert len(qil.svd_trunc(B, cutoff=1e-15)[1]) == 2            # the ITensors rule (oracle pin)
+    assert len(qil.svd_trunc(B, cutoff=1e-15, maxdim=1)[1]) == 1
