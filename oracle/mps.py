@@ -107,9 +107,9 @@ def lazy_coefficient_batch(W, psi, bits):
             Ms = M[sel]
             acc = 0
             for sp in (0, 1):
-                # sum_{a,alpha} M[a,alpha] W[a,sp,b,a'] A[alpha,sp,beta]
-                t = np.einsum("qax,ab->qbx", Ms, Wi[:, sp, b, :])
-                acc = acc + np.einsum("qbx,xy->qby", t, Ai[:, sp, :])
+                # sum_{a,alpha} W[a,sp,b,a'] M[a,alpha] A[alpha,sp,beta]  (two batched GEMMs)
+                t = np.matmul(np.ascontiguousarray(Wi[:, sp, b, :].T)[None], Ms)
+                acc = acc + np.matmul(t, np.ascontiguousarray(Ai[:, sp, :])[None])
             nM[sel] = acc
         M = nM
     return chain.amplitude * M[:, 0, 0]
