@@ -1,0 +1,184 @@
+# QILaplaceHIP.jl -- the `ccall` layer a QILaplace.jl maintainer adds so that `apply`, `*`,
+# `coefficient`, `compress!`, `canonicalize!`, `mps_to_vector`, `norm`, `signal_mps`, `signal_ztmps`
+# and `rsvd` dispatch to libqilhip.so on device-resident mirror types.
+#
+# NOT EXECUTABLE IN THE BUILD IMAGE (no julia binary there); the executable host mirror of the same
+# ABI is the Python package `qilaplace.jl_amd`.  Entry points: include/qilaplace_hip.h.
+module QILaplaceHIP
+
+using ITensors
+import ITensors: apply
+import Base: *, getindex, length
+import LinearAlgebra: norm
+using ..Mps: SignalMPS, ZTMPS, _as_signal_2n
+using ..Mpo: SingleSiteMPO, PairedSiteMPO
+using ..ApplyMPO: _as_single_site_mpo
+
+const LIB = get(ENV, "QILHIP_LIB", "libqilhip.so")
+
+# ---------------------------------------------------------------- status -> exception
+const QIL_OK = 0
+function check(status::Cint)
+    status == QIL_OK && return nothing
+    msg = unsafe_string(ccall((:qil_last_error, LIB), Cstring, ()))
+    status in (1, 2, 3, 7) && throw(ArgumentError(msg))   # QIL_EINVAL_LENGTH / SITES / CONFIG / ARG
+    status == 4 && throw(DomainError(msg))                # QIL_EDOMAIN  (mps.jl:800,820,918)
+    status == 5 && throw(OutOfMemoryError())
+    status == 8 && error(msg)                             # QIL_EEMPTY   (rsvd.jl:56-60)
+    error("libqilhip [status $status]: $msg")
+end
+
+# ---------------------------------------------------------------- context
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer=0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:qil_context_create, LIB), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, r))
+        finalizer(c -> ccall((:qil_context_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), new(r[]))
+    end
+end
+const DEFAULT_CTX = Ref{Union{Nothing,Context}}(nothing)
+ctx() = something(DEFAULT_CTX[], (DEFAULT_CTX[] = Context(0)))
+
+# ---------------------------------------------------------------- device mirrors
+# A device MPS keeps the ITensor Index bookkeeping of the object it was made from (sites are shared
+# by `apply`, apply.jl:121) and an opaque handle to the HBM-resident tensors.
+mutable struct DeviceMPS{I}
+    h::Ptr{Cvoid}
+    sites::Vector{I}          # for ZTMPS: interleaved main_1, copy_1, ...
+    paired::Bool
+end
+mutable struct DeviceMPO{I}
+    h::Ptr{Cvoid}
+    sites::Vector{I}
+    paired::Bool
+end
+_free!(x::DeviceMPS) = ccall((:qil_mps_destroy, LIB), Cint, (Ptr{Cvoid},), x.h)
+_free!(x::DeviceMPO) = ccall((:qil_mpo_destroy, LIB), Cint, (Ptr{Cvoid},), x.h)
+
+# canonical boundary layout: A[alpha, s, beta] / W[a, s', s, b], column-major, explicit dim-1 edges.
+# ITensor storage order varies per tensor, so permute to the canonical index order before crossing.
+function _dense_site(T::ITensor, left, phys, right)
+    inds_ = Index[]
+    left === nothing || push!(inds_, left)
+    append!(inds_, phys)
+    right === nothing || push!(inds_, right)
+    A = Array(T, inds_...)
+    dl = left === nothing ? 1 : dim(left)
+    dr = right === nothing ? 1 : dim(right)
+    return reshape(A, dl, (dim.(phys))..., dr)
+end
+
+_code(::Type{<:Real}) = Cint(0)
+_code(::Type{<:Complex}) = Cint(1)
+
+function to_device(psi::SignalMPS; paired::Bool=false)
+    n = length(psi.data)
+    T = promote_type(map(eltype, psi.data)...)
+    host = [Array{T}(_dense_site(psi.data[i], i == 1 ? nothing : psi.bonds[i-1], (psi.sites[i],),
+                                 i == n ? nothing : psi.bonds[i])) for i in 1:n]
+    bonds = Int64[dim(b) for b in psi.bonds]
+    ids = Int64.(hash.(psi.sites) .% typemax(Int64))      # Index identity -> site id
+    ptrs = Ptr{Cvoid}[pointer(a) for a in host]
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve host check(ccall((:qil_mps_create, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Cint, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Cvoid}}, Cdouble, Ref{Ptr{Cvoid}}),
+        ctx().h, n, _code(T), paired, bonds, ids, ptrs, psi.amplitude, r))
+    return finalizer(_free!, DeviceMPS(r[], copy(psi.sites), paired))
+end
+to_device(psi::ZTMPS) = to_device(_as_signal_2n(psi); paired=true)            # mps.jl:421-444
+
+function to_device(W::SingleSiteMPO; paired::Bool=false)
+    n = length(W.data)
+    T = promote_type(map(eltype, W.data)...)
+    host = [Array{T}(_dense_site(W.data[i], i == 1 ? nothing : W.bonds[i-1], (W.sites[i]', W.sites[i]),
+                                 i == n ? nothing : W.bonds[i])) for i in 1:n]   # (a, s' = in, s = out, b)
+    bonds = Int64[dim(b) for b in W.bonds]
+    ids = Int64.(hash.(W.sites) .% typemax(Int64))
+    ptrs = Ptr{Cvoid}[pointer(a) for a in host]
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve host check(ccall((:qil_mpo_create, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Cint, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}),
+        ctx().h, n, _code(T), paired, bonds, ids, ptrs, r))
+    return finalizer(_free!, DeviceMPO(r[], copy(W.sites), paired))
+end
+to_device(W::PairedSiteMPO) = to_device(_as_single_site_mpo(W); paired=true)  # apply.jl:16-32
+
+# ---------------------------------------------------------------- the operator API (same names)
+function apply(W::DeviceMPO, psi::DeviceMPS; kwargs...)                        # apply.jl:75, :201
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:qil_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), W.h, psi.h, r))
+    return finalizer(_free!, DeviceMPS(r[], psi.sites, psi.paired))
+end
+function apply(W1::DeviceMPO, W2::DeviceMPO; kwargs...)                        # apply.jl:124, :220
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:qil_apply_mpo_mpo, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), W1.h, W2.h, r))
+    return finalizer(_free!, DeviceMPO(r[], length(W1.sites) >= length(W2.sites) ? W1.sites : W2.sites, W1.paired))
+end
+*(W::DeviceMPO, psi::DeviceMPS) = apply(W, psi)                                # apply.jl:233-236
+*(W1::DeviceMPO, W2::DeviceMPO) = apply(W1, W2)
+
+function length(psi::DeviceMPS)
+    n = Ref{Int64}(0)
+    check(ccall((:qil_mps_nsites, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), psi.h, n))
+    return Int(n[])
+end
+
+# coefficient(psi, cfg): every front-end of mps.jl:616-645, 680-693 funnels into one bit matrix
+function coefficient(psi::DeviceMPS, bits::AbstractMatrix{<:Integer})          # nb x n, one row per query
+    nb, n = size(bits)
+    n == length(psi) || throw(ArgumentError("coefficient: expected $(length(psi)) entries, got $n"))
+    b = Matrix{UInt8}(permutedims(bits))                                        # query-major for the ABI
+    out = Vector{ComplexF64}(undef, nb)
+    check(ccall((:qil_coefficient_batch, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cdouble}),
+                psi.h, nb, b, out))
+    return out
+end
+coefficient(psi::DeviceMPS, cfg::AbstractVector{<:Integer}) = coefficient(psi, reshape(collect(cfg), 1, :))[1]
+coefficient(psi::DeviceMPS, cfg::Tuple{Vararg{Integer}}) = coefficient(psi, collect(cfg))
+coefficient(psi::DeviceMPS, cfg::Vararg{Integer}) = coefficient(psi, collect(cfg))
+coefficient(psi::DeviceMPS, s::AbstractString) = coefficient(psi, Mps._parse_config_string(s))
+coefficient(psi::DeviceMPS, v::Integer) = coefficient(psi, Mps._bits_from_integer(v, length(psi)))
+getindex(psi::DeviceMPS, cfg::Vararg{Integer}) = coefficient(psi, collect(cfg))
+
+function compress!(psi::DeviceMPS; maxdim::Int=typemax(Int), tol::Float64=1e-12, sweeps::Int=1)   # mps.jl:913
+    check(ccall((:qil_compress, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Cint), psi.h, maxdim, tol, sweeps))
+    return psi
+end
+function canonicalize!(psi::DeviceMPS, direction::Symbol; center=nothing, cutoff::Float64=1e-12,
+                       maxdim::Int=typemax(Int))                                                   # mps.jl:787
+    direction in (:right, :left) || throw(ArgumentError("Direction must be :right or :left"))
+    check(ccall((:qil_canonicalize, LIB), Cint, (Ptr{Cvoid}, Cint, Int64, Cdouble, Int64),
+                psi.h, direction == :right ? 0 : 1, something(center, 0), cutoff, maxdim))
+    return psi
+end
+function norm(psi::DeviceMPS)                                                                      # mps.jl:754
+    v = Ref{Cdouble}(0)
+    check(ccall((:qil_norm, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}), psi.h, v))
+    return v[]
+end
+function mps_to_vector(psi::DeviceMPS; reverse::Bool=false)                                        # mps.jl:716
+    d = Ref{Cint}(0)
+    check(ccall((:qil_mps_dtype, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), psi.h, d))
+    out = d[] == 1 ? Vector{ComplexF64}(undef, 2^length(psi)) : Vector{Float64}(undef, 2^length(psi))
+    check(ccall((:qil_mps_to_vector, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), psi.h, reverse, out))
+    return out
+end
+
+function signal_mps_device(x::AbstractVector{<:Number}; method::Symbol=:svd, cutoff::Real=1e-15,
+                           maxdim::Int=typemax(Int), k::Int=20, p::Int=10, q::Int=0,
+                           random_seed::Int=1234, mindim::Int=1, paired::Bool=false)  # SignalConverters.jl:228, :247
+    method in (:svd, :rsvd) || throw(ArgumentError("tensor_to_mps: unknown method $method. Use :svd or :rsvd."))
+    T = eltype(x) <: Complex ? ComplexF64 : Float64
+    xs = Vector{T}(x)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    f = paired ? :qil_signal_ztmps : :qil_signal_mps
+    check(ccall((f, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Cint, Cdouble, Int64, Int64, Int64, Cint, UInt64, Int64, Ref{Ptr{Cvoid}}),
+        ctx().h, xs, length(xs), _code(T), method == :svd ? 0 : 1, cutoff, maxdim, k, p, q, random_seed, mindim, r))
+    n = round(Int, log2(length(xs)))
+    sites = [Index(2; tags="site-$i") for i in 1:(paired ? 2n : n)]
+    return finalizer(_free!, DeviceMPS(r[], sites, paired))
+end
+
+end # module

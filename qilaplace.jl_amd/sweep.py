@@ -1,0 +1,77 @@
+"""Embarrassingly-parallel sweeps over independent work items (signals, damping values sigma).
+
+The reference loops serially over kinds / omega_r (scripts/benchmark/zt_full_runtime.jl:151-221;
+docs/src/tutorials/zt.jl:300-348 builds one MPO per omega_r).  Each (signal, sigma) pipeline
+encode -> build -> apply -> sample is self-contained, so items are dealt round-robin to the ranks
+(one process per GPU) with NO data-path collective; the only communication is one all_gather of
+the per-item coefficient batches at the end (KB-scale, latency-bound; RCCL over xGMI on GPUs,
+gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_items(n_items: int, world: int, rank: int):
+    """Static round-robin partition: rank r owns items r, r + world, r + 2 world, ..."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside [0, {world})")
+    return list(range(rank, n_items, world))
+
+
+def gather_results(local: dict, n_items: int, width: int, dist=None, device=None):
+    """All ranks contribute {item index -> complex vector of length `width`}; returns the
+    (n_items, width) complex array in item order on every rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out = np.zeros((n_items, width), dtype=np.complex128)
+        for i, v in local.items():
+            out[i] = v
+        return out
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = (n_items + world - 1) // world
+    buf = np.zeros((per, width, 2), dtype=np.float64)
+    for slot, i in enumerate(shard_items(n_items, world, rank)):
+        v = np.asarray(local[i], dtype=np.complex128)
+        buf[slot, :, 0], buf[slot, :, 1] = v.real, v.imag
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)                      # the one collective of the sweep
+    out = np.zeros((n_items, width), dtype=np.complex128)
+    for r, p in enumerate(parts):
+        p = p.cpu().numpy()
+        for slot, i in enumerate(shard_items(n_items, world, r)):
+            out[i] = p[slot, :, 0] + 1j * p[slot, :, 1]
+    return out
+
+
+def sweep(items, work_fn, width: int, dist=None, device=None):
+    """Run ``work_fn(item) -> complex vector (width,)`` on this rank's share of ``items`` and
+    gather all results in item order."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    local = {i: work_fn(items[i]) for i in shard_items(len(items), world, rank)}
+    return gather_results(local, len(items), width, dist if world > 1 else None, device)
+
+
+def damping_sweep(psi, sigmas, build_mpo, bits, dist=None, device=None):
+    """BASELINE.json configs[3]: one paired-register signal x many damping values.
+
+    psi        device ZTMPS (replicated on every rank; it is MBs)
+    sigmas     sequence of omega_r values
+    build_mpo  callable sigma -> list of numpy MPO site tensors W[a, s_in, s_out, b] (2n of them);
+               the transform builders are host-side producers
+    bits       (nb, 2n) sampled configurations
+    Returns (len(sigmas), nb) coefficients of W(sigma) * psi, in sigma order, on every rank."""
+    from .containers import PairedSiteMPO
+    from .ops import apply, coefficient_batch
+    bits = np.asarray(bits)
+
+    def work(sig):
+        W = PairedSiteMPO(build_mpo(sig), ctx=psi.ctx)
+        out = apply(W, psi)
+        return coefficient_batch(out, bits)
+
+    return sweep(list(sigmas), work, bits.shape[0], dist, device)

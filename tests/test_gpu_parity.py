@@ -414,3 +414,20 @@ def test_svd_trunc_vs_lapack(qil, shape, dt):
     B = (Q1 * s) @ Q2.T
     assert len(qil.svd_trunc(B, cutoff=1e-15)[1]) == 2            # the ITensors rule (oracle pin)
     assert len(qil.svd_trunc(B, cutoff=1e-15, maxdim=1)[1]) == 1
+
+
+# ---------------------------------------------------------------- sigma sweep (configs[3], one rank)
+def test_damping_sweep_single_rank(qil):
+    n = 5
+    N = 2 ** n
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    psi = qil.signal_ztmps(x, cutoff=1e-14)
+    sig = np.linspace(0.25, 4.0, 6)
+    bits = np.array([interleave(int_to_bits(k, n, "lsb"), int_to_bits(j, n)) for k in (0, 3, 17) for j in range(N)])
+    got = qil.damping_sweep(psi, sig, lambda s: O.build_dt_mpo(n, s).data, bits)
+    assert got.shape == (6, 3 * N)
+    xh = x / np.linalg.norm(x)
+    for r, s in enumerate(sig):
+        for t, k in enumerate((0, 3, 17)):
+            ref = psi.amplitude * xh * np.exp(-s * k * np.arange(N) / N) / np.sqrt(N)
+            assert np.abs(got[r, t * N:(t + 1) * N] - ref).max() < 1e-7 * max(1.0, np.abs(ref).max())
