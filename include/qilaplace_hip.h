@@ -194,6 +194,12 @@ int qil_rsvd(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, i
 int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, double cutoff,
                   int64_t maxdim, int64_t mindim, int64_t* rank, void* U, double* S, void* Vh);
 
+/* C (m x n) = opA(A) * opB(B) on host operands, column-major; op: 0 = N, 1 = T, 2 = H, 3 = conj.
+ * The f64-MFMA GEMM every contraction of the truncation/encode path goes through (the `*` of
+ * mps.jl:930,947; rsvd.jl:79,89,93,98,114); exported as a utility and test hook.                */
+int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+             const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,14 +16,14 @@ from .containers import (Context, default_context, set_default_context, device_c
                          SignalMPS, ZTMPS, SingleSiteMPO, PairedSiteMPO)
 from .ops import (apply, coefficient, coefficient_batch, apply_coefficient_batch,  # noqa: F401
                   mps_to_vector, norm, canonicalize, compress, signal_mps, signal_ztmps, rsvd,
-                  svd_trunc)
+                  svd_trunc, gemm)
 from .sweep import shard_items, sweep, damping_sweep, gather_results  # noqa: F401
 
 __all__ = [
     "Context", "default_context", "set_default_context", "device_count",
     "SignalMPS", "ZTMPS", "SingleSiteMPO", "PairedSiteMPO",
     "apply", "coefficient", "coefficient_batch", "apply_coefficient_batch", "mps_to_vector", "norm",
-    "canonicalize", "compress", "signal_mps", "signal_ztmps", "rsvd", "svd_trunc",
+    "canonicalize", "compress", "signal_mps", "signal_ztmps", "rsvd", "svd_trunc", "gemm",
     "shard_items", "sweep", "damping_sweep", "gather_results",
     "QilError", "QilDomainError",
 ]

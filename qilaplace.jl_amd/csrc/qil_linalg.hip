@@ -38,9 +38,16 @@ __device__ __forceinline__ c64 sub_t(c64 a, c64 b) { return c64{a.re - b.re, a.i
 __device__ __forceinline__ double add_t(double a, double b) { return a + b; }
 __device__ __forceinline__ c64 add_t(c64 a, c64 b) { return c64{a.re + b.re, a.im + b.im}; }
 
-// ------------------------------------------------------------------ GEMM
-// 64 x 64 output tile per 256-thread workgroup, 4 x 4 outputs per thread, K tiles of 16 in LDS.
-constexpr int GT = 64, GK = 16;
+// ------------------------------------------------------------------ GEMM on the f64 matrix cores
+// C (m x n) = opA(A) * opB(B), f64 or c64, through v_mfma_f64_16x16x4_f64.
+//   * 64 x 64 output tile per 256-thread workgroup; wave w owns a 32 x 32 quadrant = 2 x 2 MFMA tiles
+//   * K tiles of 16 staged in LDS as split re/im planes, rows padded to 80 doubles: row stride
+//     640 B == 128 (mod 256) so the two 16-lane halves of a 32-lane ds_read_b64 group hit disjoint banks
+//   * the MFMA is issued as (B^T tile) x (A^T tile) = (AB)^T tile: the D fragment then has the C ROW
+//     index on lane&15, so every 16 lanes store 128 B (f64) / 256 B (c64) contiguous in column-major C
+//   * complex product = 4 real MFMAs into 3 accumulators (rr, ii, ri): C = (rr - ii) + i ri
+constexpr int GT = 64, GK = 16, GLD = 80;
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <class T, int OP>
 __device__ __forceinline__ T load_op(const T* __restrict__ M, long long ld, long long r, long long c) {
@@ -51,23 +58,36 @@ __device__ __forceinline__ T load_op(const T* __restrict__ M, long long ld, long
     return OP == 2 ? conj_t(v) : v;
 }
 
+__device__ __forceinline__ void put_planes(double (*S)[GK][GLD], int kk, int i, double v) { S[0][kk][i] = v; }
+__device__ __forceinline__ void put_planes(double (*S)[GK][GLD], int kk, int i, c64 v) {
+    S[0][kk][i] = v.re;
+    S[1][kk][i] = v.im;
+}
+
 template <class T, int OPA, int OPB>
 __global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, long long k,
                                                    const T* __restrict__ A, long long lda,
                                                    const T* __restrict__ B, long long ldb, T* __restrict__ C,
                                                    long long ldc) {
-    __shared__ T As[GK][GT + 1];
-    __shared__ T Bs[GK][GT + 1];
+    constexpr bool CX = sizeof(T) == 16;
+    constexpr int NP = CX ? 2 : 1;
+    __shared__ double As[NP][GK][GLD];
+    __shared__ double Bs[NP][GK][GLD];
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const long long row0 = (long long)blockIdx.x * GT, col0 = (long long)blockIdx.y * GT;
-    T acc[4][4];
+    d4 rr[2][2], ii[2][2], ri[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = T{};
+        for (int b = 0; b < 2; ++b) {
+            rr[a][b] = d4{0, 0, 0, 0};
+            ii[a][b] = d4{0, 0, 0, 0};
+            ri[a][b] = d4{0, 0, 0, 0};
+        }
     for (long long k0 = 0; k0 < k; k0 += GK) {
-        // stage op(A)[row0.., k0..] and op(B)[k0.., col0..]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int i, kk;
@@ -79,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, lon
                 i = (tid >> 4) + 16 * r;
             }
             const long long gr = row0 + i, gk = k0 + kk;
-            As[kk][i] = (gr < m && gk < k) ? load_op<T, OPA>(A, lda, gr, gk) : T{};
+            put_planes(As, kk, i, (gr < m && gk < k) ? load_op<T, OPA>(A, lda, gr, gk) : T{});
             int j, kb;
             if (OPB == 0 || OPB == 3) {
                 kb = tid & 15;
@@ -89,30 +109,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, lon
                 kb = (tid >> 6) + 4 * r;
             }
             const long long gc = col0 + j, gk2 = k0 + kb;
-            Bs[kb][j] = (gc < n && gk2 < k) ? load_op<T, OPB>(B, ldb, gk2, gc) : T{};
+            put_planes(Bs, kb, j, (gc < n && gk2 < k) ? load_op<T, OPB>(B, ldb, gk2, gc) : T{});
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < GK; ++kk) {
-            T a[4], b[4];
+        for (int kk = 0; kk < GK; kk += 4) {
+            double are[2], aim[2], bre[2], bim[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kk][tx + 16 * i];
+            for (int t = 0; t < 2; ++t) {
+                are[t] = As[0][kk + l4][wr + 16 * t + l15];
+                bre[t] = Bs[0][kk + l4][wc + 16 * t + l15];
+                if (CX) {
+                    aim[t] = As[NP - 1][kk + l4][wr + 16 * t + l15];
+                    bim[t] = Bs[NP - 1][kk + l4][wc + 16 * t + l15];
+                }
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][ty + 16 * j];
+            for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fma_t(a[i], b[j], acc[i][j]);
+                for (int tj = 0; tj < 2; ++tj) {
+                    rr[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], are[ti], rr[ti][tj], 0, 0, 0);
+                    if (CX) {
+                        ii[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bim[tj], aim[ti], ii[ti][tj], 0, 0, 0);
+                        ri[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bim[tj], are[ti], ri[ti][tj], 0, 0, 0);
+                        ri[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], aim[ti], ri[ti][tj], 0, 0, 0);
+                    }
+                }
         }
         __syncthreads();
     }
+    // D fragment of (AB)^T: D'[j][i], i = lane & 15, j = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long gr = row0 + tx + 16 * i, gc = col0 + ty + 16 * j;
-            if (gr < m && gc < n) C[gr + ldc * gc] = acc[i][j];
-        }
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long gr = row0 + wr + 16 * ti + l15;
+                const long long gc = col0 + wc + 16 * tj + l4 + 4 * r;
+                if (gr < m && gc < n) {
+                    double* cp = reinterpret_cast<double*>(C + gr + ldc * gc);
+                    if (CX) {
+                        cp[0] = rr[ti][tj][r] - ii[ti][tj][r];
+                        cp[1] = ri[ti][tj][r];
+                    } else {
+                        cp[0] = rr[ti][tj][r];
+                    }
+                }
+            }
 }
 
 template <class T>
@@ -138,6 +182,11 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
     QIL_GEMM_CASE(2, 1)
     QIL_GEMM_CASE(3, 0)
     QIL_GEMM_CASE(0, 3)
+    QIL_GEMM_CASE(3, 3)
+    QIL_GEMM_CASE(3, 1)
+    QIL_GEMM_CASE(3, 2)
+    QIL_GEMM_CASE(1, 3)
+    QIL_GEMM_CASE(2, 3)
 #undef QIL_GEMM_CASE
     return qil_fail(QIL_EINVAL_ARG, "gemm: bad op codes %d, %d", opA, opB);
 }
@@ -502,6 +551,32 @@ int qil_dev_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64
     static const int real_op[4] = {0, 1, 1, 0};
     return gemm_dispatch<double>(ctx, real_op[opA & 3], real_op[opB & 3], m, n, k, (const double*)A, lda,
                                  (const double*)B, ldb, (double*)C, ldc);
+}
+
+// C = opA(A) * opB(B) on host operands (column-major): utility / test hook for the MFMA GEMM
+extern "C" int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+                        const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc) {
+    QIL_REQUIRE(ctx && A && B && C, QIL_EINVAL_ARG, "gemm: null argument");
+    QIL_REQUIRE(m >= 1 && n >= 1 && k >= 1, QIL_EINVAL_ARG, "gemm: empty operand");
+    QIL_REQUIRE(opA >= 0 && opA <= 3 && opB >= 0 && opB <= 3, QIL_EINVAL_ARG, "gemm: bad op code");
+    QIL_TRY(qil_ctx_activate(ctx));
+    const size_t e = qil_elem_size(dtype);
+    const int64_t a_cols = (opA == 0 || opA == 3) ? k : m, b_cols = (opB == 0 || opB == 3) ? n : k;
+    void *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(lda * a_cols) * e, &dA));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(ldb * b_cols) * e, &dB));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(ldc * n) * e, &dC));
+    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(lda * a_cols) * e, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dB, B, (size_t)(ldb * b_cols) * e, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemsetAsync(dC, 0, (size_t)(ldc * n) * e, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_TRY(qil_dev_gemm(ctx, dtype, opA, opB, m, n, k, dA, lda, dB, ldb, dC, ldc));
+    QIL_HIP(hipMemcpyAsync(C, dC, (size_t)(ldc * n) * e, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    qil_ctx_free(ctx, dA);
+    qil_ctx_free(ctx, dB);
+    qil_ctx_free(ctx, dC);
+    return QIL_OK;
 }
 
 int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t n, const void* A, int64_t lda,

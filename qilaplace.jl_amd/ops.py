@@ -242,3 +242,24 @@ def svd_trunc(A, cutoff=None, maxdim=None, mindim=1, ctx=None):
                                 S.ctypes.data_as(C.POINTER(C.c_double)), Vh.ctypes.data_as(C.c_void_p)))
     r = r.value
     return U[:, :r].copy(), S[:r].copy(), Vh[: r * n].reshape((r, n), order="F").copy()
+
+
+_OPS = {"N": 0, "T": 1, "H": 2, "C": 3}
+
+
+def gemm(A, B, opA="N", opB="N", ctx=None):
+    """op(A) @ op(B) on the GPU's f64 matrix cores (utility / test hook); op in N, T, H, C(onj)."""
+    ctx = ctx or default_context()
+    A, B = np.asarray(A), np.asarray(B)
+    code = L.QIL_C64 if (np.iscomplexobj(A) or np.iscomplexobj(B)) else L.QIL_F64
+    dt = _np_dtype(code)
+    Af, Bf = np.asfortranarray(A, dtype=dt), np.asfortranarray(B, dtype=dt)
+    m, k = (Af.shape if opA in "NC" else Af.shape[::-1])
+    k2, n = (Bf.shape if opB in "NC" else Bf.shape[::-1])
+    if k != k2:
+        raise ValueError(f"gemm: inner dimensions disagree ({k} vs {k2})")
+    Cm = np.empty((m, n), dtype=dt, order="F")
+    L.check(L.lib.qil_gemm(ctx.handle, code, _OPS[opA], _OPS[opB], m, n, k, Af.ctypes.data_as(C.c_void_p),
+                           Af.shape[0], Bf.ctypes.data_as(C.c_void_p), Bf.shape[0],
+                           Cm.ctypes.data_as(C.c_void_p), m))
+    return Cm

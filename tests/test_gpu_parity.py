@@ -431,3 +431,29 @@ def test_damping_sweep_single_rank(qil):
         for t, k in enumerate((0, 3, 17)):
             ref = psi.amplitude * xh * np.exp(-s * k * np.arange(N) / N) / np.sqrt(N)
             assert np.abs(got[r, t * N:(t + 1) * N] - ref).max() < 1e-7 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------- f64-MFMA GEMM (fragment layout check)
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+@pytest.mark.parametrize("opA", ["N", "T", "H", "C"])
+@pytest.mark.parametrize("opB", ["N", "T", "H", "C"])
+def test_gemm_mfma_all_ops(qil, dt, opA, opB):
+    rng = np.random.default_rng(31)
+    m, n, k = 70, 45, 37                       # ragged: exercises every tile edge
+
+    def mk(shape):
+        M = rng.standard_normal(shape)
+        return M + 1j * rng.standard_normal(shape) if dt == np.complex128 else M
+
+    f = {"N": lambda M: M, "T": lambda M: M.T, "H": lambda M: M.conj().T, "C": lambda M: M.conj()}
+    A = mk((m, k) if opA in "NC" else (k, m))
+    B = mk((k, n) if opB in "NC" else (n, k))      # asymmetric operands catch row/col swaps
+    got = qil.gemm(A, B, opA, opB)
+    ref = f[opA](A) @ f[opB](B)
+    assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_mfma_integer_exact(qil):
+    A = np.arange(1, 1 + 130 * 67, dtype=np.float64).reshape(130, 67) % 17 - 8
+    B = (np.arange(1, 1 + 67 * 129, dtype=np.float64).reshape(67, 129) % 13) - 6
+    assert np.array_equal(qil.gemm(A, B), A @ B)
