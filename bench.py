@@ -120,10 +120,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # QIL_BENCH_FORCE_DIST=1 exercises the RCCL code path (barrier, all_reduce, gather) even at N=1
+    if world > 1 or os.environ.get("QIL_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -224,6 +226,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(qil, W, psi, cb, db, L)
+        try:                                   # RCCL prints a banner through C stdio: flush it first so
+            import ctypes                      # the JSON line is the last line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

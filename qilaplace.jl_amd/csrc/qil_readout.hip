@@ -175,6 +175,35 @@ __global__ void to_vector_step(const T* __restrict__ Tin, const T* __restrict__ 
     }
 }
 
+// batched path: Vn[q, beta] = T[q, bit_q + 2*beta]  (T = V * A_i viewed as chi_l x (2 chi_r))
+template <class T>
+__global__ void select_slice(const T* __restrict__ Tm, long long nb, int cr, const uint8_t* __restrict__ bits,
+                             int n, int site, T* __restrict__ Vn) {
+    const long long total = nb * cr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long q = t % nb;
+        const long long beta = t / nb;
+        Vn[t] = Tm[q + nb * (bits[q * n + site] + 2 * beta)];
+    }
+}
+
+template <class T>
+__global__ void fill_ones(T* __restrict__ v, long long n) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x)
+        v[t] = one_t(T{});
+}
+
+template <class T>
+__global__ void finish_coeff(const T* __restrict__ v, long long nb, double amplitude, c64* __restrict__ out) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nb;
+         t += (long long)gridDim.x * blockDim.x) {
+        const c64 r = to_c64(v[t]);
+        out[t] = c64{r.re * amplitude, r.im * amplitude};
+    }
+}
+
 __global__ void scale_real(double* p, long long n, double s) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
          t += (long long)gridDim.x * blockDim.x)
@@ -214,6 +243,45 @@ extern "C" int qil_coefficient_batch(const qil_mps* psi, int64_t nb, const uint8
     uint8_t* dbits = nullptr;
     QIL_TRY(upload_bits(ctx, nb, n, bits, &dbits));
     const size_t esz = qil_elem_size(psi->dtype);
+    if (maxchi >= 512 && nb >= 4) {
+        // Large bonds: all queries advance together, one f64-MFMA GEMM per site.  The site tensor is
+        // read ONCE for the whole batch: T (nb x 2 chi_r) = V (nb x chi_l) * A_i (chi_l x 2 chi_r),
+        // then each query keeps the column block of its own bit.
+        void *V = nullptr, *Vn = nullptr, *Tm = nullptr, *dout2 = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nb * maxchi) * esz, &V));
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nb * maxchi) * esz, &Vn));
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * nb * maxchi) * esz, &Tm));
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout2));
+        const bool cx = psi->dtype == QIL_C64;
+        const unsigned g1 = (unsigned)std::min<long long>((nb + 255) / 256, 4096);
+        if (cx) hipLaunchKernelGGL(fill_ones<c64>, dim3(g1), dim3(256), 0, ctx->stream, (c64*)V, (long long)nb);
+        else hipLaunchKernelGGL(fill_ones<double>, dim3(g1), dim3(256), 0, ctx->stream, (double*)V, (long long)nb);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+            QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 0, 0, nb, 2 * cr, cl, V, nb, psi->site[(size_t)i], cl, Tm, nb));
+            const unsigned g = (unsigned)std::min<long long>((nb * cr + 255) / 256, 65536);
+            if (cx)
+                hipLaunchKernelGGL(select_slice<c64>, dim3(g), dim3(256), 0, ctx->stream, (const c64*)Tm,
+                                   (long long)nb, (int)cr, dbits, (int)n, (int)i, (c64*)Vn);
+            else
+                hipLaunchKernelGGL(select_slice<double>, dim3(g), dim3(256), 0, ctx->stream, (const double*)Tm,
+                                   (long long)nb, (int)cr, dbits, (int)n, (int)i, (double*)Vn);
+            std::swap(V, Vn);
+        }
+        if (cx) hipLaunchKernelGGL(finish_coeff<c64>, dim3(g1), dim3(256), 0, ctx->stream, (const c64*)V,
+                                   (long long)nb, psi->amplitude, (c64*)dout2);
+        else hipLaunchKernelGGL(finish_coeff<double>, dim3(g1), dim3(256), 0, ctx->stream, (const double*)V,
+                                (long long)nb, psi->amplitude, (c64*)dout2);
+        QIL_HIP(hipGetLastError());
+        QIL_HIP(hipMemcpyAsync(out, dout2, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream));
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        qil_ctx_free(ctx, V);
+        qil_ctx_free(ctx, Vn);
+        qil_ctx_free(ctx, Tm);
+        qil_ctx_free(ctx, dout2);
+        qil_ctx_free(ctx, dbits);
+        return QIL_OK;
+    }
     void *scratch = nullptr, *dout = nullptr, *pin = nullptr, *dtab = nullptr;
     int slot = 0;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * nb * maxchi) * esz, &scratch));

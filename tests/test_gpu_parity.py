@@ -457,3 +457,79 @@ def test_gemm_mfma_integer_exact(qil):
     A = np.arange(1, 1 + 130 * 67, dtype=np.float64).reshape(130, 67) % 17 - 8
     B = (np.arange(1, 1 + 67 * 129, dtype=np.float64).reshape(67, 129) % 13) - 6
     assert np.array_equal(qil.gemm(A, B), A @ B)
+
+
+# ---------------------------------------------------------------- BASELINE.json full-size configurations
+def _embed_and_gauge(Wdata, cap_profile, rng):
+    """Zero-embed every MPO bond to the nominal cap and conjugate it with a seeded random orthogonal
+    gauge (G on one side, G^T on the other): the operator is exactly unchanged, the tensors are dense
+    (SURVEY.md 8a row P2)."""
+    L = len(Wdata)
+    out = [w.astype(np.complex128) for w in Wdata]
+    for i in range(L - 1):
+        d, D = out[i].shape[3], cap_profile[i]
+        assert D >= d
+        G, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        left = np.zeros(out[i].shape[:3] + (D,), dtype=np.complex128)
+        left[..., :d] = out[i]
+        right = np.zeros((D,) + out[i + 1].shape[1:], dtype=np.complex128)
+        right[:d] = out[i + 1]
+        out[i] = left @ G                                          # (..., D) G
+        out[i + 1] = np.tensordot(G.T, right, axes=([1], [0]))     # G^T (D, ...)
+    return out
+
+
+def test_config2_n20_chi32_D64_qft_vs_fft(qil):
+    """configs[1]: n=20, chi_s=32, chi_c=64 QFT MPO apply, coefficients vs dense FFT (1e-9 relative).
+    The genuine QFT MPO is built at cutoff 1e-24 (so its own truncation error sits at ~1e-11) and
+    then embedded/gauged to the nominal dense chi_c=64 profile."""
+    n = 20
+    N = 2 ** n
+    rng = np.random.default_rng(20240032)
+    a = random_mps_data(saturated_profile(n, 32), rng)
+    Wq = O.build_qft_mpo(n, cutoff=1e-24)
+    w = _embed_and_gauge(Wq.data, saturated_profile(n, 64, base=4), rng)
+    psi = qil.SignalMPS(a)
+    out = qil.SingleSiteMPO(w) * psi
+    assert out.bond_dims == [c * d for c, d in zip(saturated_profile(n, 32), saturated_profile(n, 64, base=4))]
+    x = qil.mps_to_vector(psi)                                     # dense 2^20 input signal
+    F = np.fft.fft(x) / np.sqrt(N)
+    k = rng.integers(0, N, size=4096)
+    bits = ((k[:, None] >> np.arange(n)[None, :]) & 1).astype(np.uint8)      # lsb first = site 1 first
+    got = qil.coefficient_batch(out, bits)
+    assert np.abs(got - F[k]).max() < 1e-9 * np.abs(F).max()
+    lazy = qil.apply_coefficient_batch(qil.SingleSiteMPO(w), psi, bits[:512])
+    assert np.abs(lazy - F[k[:512]]).max() < 1e-9 * np.abs(F).max()
+    full = qil.mps_to_vector(out, reverse=True)                    # all 2^20 coefficients
+    assert np.abs(full - F).max() < 1e-9 * np.abs(F).max()
+
+
+def test_config3_n24_chi64_D128_full_size_vs_cpu_oracle(qil):
+    """configs[2] at full size (48 sites, 80 GB result): sampled coefficients of the materialised
+    HIP result vs the CPU oracle's lazy restatement on the same (W, psi); and homogeneity
+    apply(W, c psi) = c apply(W, psi) through the amplitude."""
+    L = 48
+    cb, db = saturated_profile(L, 64), saturated_profile(L, 128, base=4)
+    psi = qil.ZTMPS.alloc(cb, dtype=np.float64, amplitude=1.5).fill_random(20240064)
+    W = qil.PairedSiteMPO.alloc(db, dtype=np.complex128).fill_random(777)
+    out = W * psi
+    assert out.amplitude == 1.5 and out.bond_dims == [c * d for c, d in zip(cb, db)]
+    bits = np.random.default_rng(5).integers(0, 2, size=(16, L))
+    got = qil.coefficient_batch(out, bits)
+    ref = O.lazy_coefficient_batch(O.SingleSiteMPO(W.to_host()),
+                                   O.SignalMPS(psi.to_host(), amplitude=1.5), bits)
+    assert rel(got, ref) < 1e-9
+    assert rel(qil.apply_coefficient_batch(W, psi, bits), ref) < 1e-9
+    del out
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+def test_coefficient_batched_gemm_path(qil, dt):
+    """Bonds >= 512 route coefficient_batch through the per-site MFMA GEMM (all queries together)."""
+    rng = np.random.default_rng(41)
+    a = random_mps_data([2, 4, 8, 600, 513, 8, 4, 2], rng, dt)
+    psi = qil.SignalMPS(a, amplitude=0.9)
+    bits = rng.integers(0, 2, size=(37, 9))
+    ref = O.coefficient_batch(O.SignalMPS(a, amplitude=0.9), bits)
+    assert rel(qil.coefficient_batch(psi, bits), ref) < 1e-12
+    assert rel(qil.coefficient_batch(psi, bits[:3]), ref[:3]) < 1e-12        # nb < 4: chain kernel
