@@ -1,0 +1,282 @@
+"""Host-side producers of the transform MPOs (the operand ``W`` of the hot path).
+
+In the reference the builders are CPU code as well (tiny latency-bound QR/SVD chains on tensors with
+D <= 8 / 18 / 92): src/transforms/qft_transformer.jl:121-165, dt_transformer.jl:312-412,
+zt_transformer.jl:41-112, with the gate blocks of src/circuits/{qft,dt,zt}_gates.jl.  They stay on the
+host here too (SURVEY.md section 8b "who calls it"; a batched device port is 8f-1) and hand the finished
+tensors to the GPU once.  ``build_*_mpo`` return device handles (SingleSiteMPO / PairedSiteMPO);
+``*_tensors`` return the numpy site tensors W[a, s_in, s_out, b].
+
+Implementation notes: every sweep is written once, for the left-to-right direction; the right-to-left
+("up") variants of the reference run the same routine on the mirrored chain.  Truncation is the
+ITensors rule (keep largest; drop the tail while the discarded squared weight <= cutoff * total; cap
+maxdim).
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from .containers import SingleSiteMPO, PairedSiteMPO
+
+_I = np.eye(2)
+_H = np.array([[1.0, 1.0], [1.0, -1.0]]) / np.sqrt(2.0)
+
+
+def _P(theta):                                       # qft_gates.jl:24-30
+    return np.diag([1.0, np.exp(-1j * theta)])
+
+
+def _R(w):                                           # dt_gates.jl:19-25
+    return np.diag([1.0, np.exp(-w)])
+
+
+def _Hd(w):                                          # dt_gates.jl:11-17
+    return np.array([[1.0, 1.0], [1.0, np.exp(-w / 2.0)]]) / np.sqrt(2.0)
+
+
+def _proj(i):
+    M = np.zeros((2, 2))
+    M[i, i] = 1.0
+    return M
+
+
+def _site(entries, Dl, Dr, dtype):
+    """entries: {(a, b): 2x2 gate[s_in, s_out]}."""
+    W = np.zeros((Dl, 2, 2, Dr), dtype=dtype)
+    for (a, b), g in entries.items():
+        W[a, :, :, b] += g
+    return W
+
+
+# ------------------------------------------------------------------ gate blocks
+def _qft_block(k):
+    """control_Hphase_mpo (qft_gates.jl:43-97): H then project the output of site 1; P(2pi/2^l) on site l."""
+    c = np.complex128
+    if k == 1:
+        return [_site({(0, 0): _H}, 1, 1, c)]
+    out = [_site({(0, 0): _H @ _proj(0), (0, 1): _H @ _proj(1)}, 1, 2, c)]
+    for l in range(2, k):
+        out.append(_site({(0, 0): _I, (1, 1): _P(2 * np.pi / 2.0 ** l)}, 2, 2, c))
+    out.append(_site({(0, 0): _I, (1, 0): _P(2 * np.pi / 2.0 ** k)}, 2, 1, c))
+    return out
+
+
+def _dt_main_block(k, w):
+    """control_damping_mpo (dt_gates.jl:30-130): control = input bit of main_k."""
+    f = np.float64
+    if k == 1:
+        return [_site({(0, 0): _Hd(w)}, 1, 1, f), _site({(0, 0): _I}, 1, 1, f)]
+    out = []
+    for l in range(1, k):
+        Rf = _R(w * 2.0 ** (l - k - 1))
+        out.append(_site({(0, 0): _I, (0 if l == 1 else 1, 1): Rf}, 1 if l == 1 else 2, 2, f))
+        out.append(_site({(0, 0): _I, (1, 1): _I}, 2, 2, f))
+    out.append(_site({(0, 0): _proj(0) @ _Hd(w), (1, 1): _proj(1) @ _Hd(w)}, 2, 2, f))
+    out.append(_site({(0, 0): _I, (1, 0): _I}, 2, 1, f))
+    return out
+
+
+def _dt_copy_block(n, k, w):
+    """control_damping_copy_mpo (dt_gates.jl:133-229): control = projector on copy_k; pairs k..n."""
+    f = np.float64
+    L = n - k + 1
+    if L == 1:
+        return [_site({(0, 0): _I}, 1, 1, f), _site({(0, 0): _I}, 1, 1, f)]
+    out = [_site({(0, 0): _I}, 1, 2, f), _site({(0, 0): _proj(0), (0, 1): _proj(1)}, 2, 2, f)]
+    for j in range(2, L + 1):
+        out.append(_site({(0, 0): _I, (1, 1): _R(w * 2.0 ** (j - 2))}, 2, 2, f))
+        last = j == L
+        out.append(_site({(0, 0): _I, (1, 0 if last else 1): _I}, 2, 1 if last else 2, f))
+    return out
+
+
+def _zt_block(k):
+    """control_Hphase_ztmps_mpo (zt_gates.jl:12-114): control = input bit of copy_k (project, then H)."""
+    c = np.complex128
+    if k == 1:
+        return [_site({(0, 0): _I}, 1, 1, c), _site({(0, 0): _H}, 1, 1, c)]
+    out = [_site({(0, 0): _I, (0, 1): _I}, 1, 2, c),
+           _site({(0, 0): _I, (1, 1): _P(2 * np.pi / 2.0 ** k)}, 2, 2, c)]
+    for j in range(2, k):
+        out.append(_site({(0, 0): _I, (1, 1): _I}, 2, 2, c))
+        out.append(_site({(0, 0): _I, (1, 1): _P(2 * np.pi / 2.0 ** (k - j + 1))}, 2, 2, c))
+    out.append(_site({(0, 0): _I, (1, 1): _I}, 2, 2, c))
+    out.append(_site({(0, 0): _proj(0) @ _H, (1, 0): _proj(1) @ _H}, 2, 1, c))
+    return out
+
+
+# ------------------------------------------------------------------ chain algebra
+def _mirror(chain):
+    """Reverse the site order and swap the two bond axes of every tensor."""
+    return [np.ascontiguousarray(t.transpose(3, 1, 2, 0)) for t in reversed(chain)]
+
+
+def _keep(S, cutoff, maxdim):
+    P = S * S
+    n = len(P)
+    if n <= 1 or P[0] <= 0:
+        return 1
+    err = 0.0
+    if maxdim is not None:
+        while n > maxdim:
+            err += P[n - 1]
+            n -= 1
+    if cutoff is not None:
+        tot = P.sum() or 1.0
+        while n > 1 and err + P[n - 1] <= cutoff * tot:
+            err += P[n - 1]
+            n -= 1
+    return max(n, 1)
+
+
+def _svd(M, cutoff, maxdim):
+    try:
+        U, S, Vh = np.linalg.svd(M, full_matrices=False)
+    except np.linalg.LinAlgError:                     # pragma: no cover
+        import scipy.linalg
+        U, S, Vh = scipy.linalg.svd(M, full_matrices=False, lapack_driver="gesvd")
+    r = _keep(S, cutoff, maxdim)
+    return U[:, :r], S[:r], Vh[:r]
+
+
+def _compose(first, second):
+    """Site tensor of (second o first): first's output leg feeds second's input leg; the bond of
+    `first` is the fast index of the fused bonds (apply.jl:163-171)."""
+    t = np.einsum("aimb,cmod->caiodb", first, second)
+    return t.reshape(first.shape[0] * second.shape[0], 2, 2, first.shape[3] * second.shape[3])
+
+
+def _zip_lr(M, B):
+    """Left-aligned zip of block B (acting after M) into chain M with a QR remainder carried to the
+    right (zip_to_combine_mpos "down", dt_transformer.jl:38-95).  len(B) <= len(M)."""
+    out = list(M)
+    T = np.ones((1, 1, 1), dtype=np.result_type(M[0], B[0]))            # (new, bondM, bondB)
+    for k, Bk in enumerate(B):
+        core = np.einsum("rac,aimb,cmod->riobd", T, M[k], Bk)
+        r, b1, b2 = core.shape[0], core.shape[3], core.shape[4]
+        Q, Rm = np.linalg.qr(core.reshape(r * 4, b1 * b2))
+        out[k] = Q.reshape(r, 2, 2, Q.shape[1])
+        T = Rm.reshape(Q.shape[1], b1, b2)
+    T = T[:, :, 0]                                                        # B has ended: its bond is 1
+    if len(M) > len(B):
+        out[len(B)] = np.tensordot(T, out[len(B)], axes=([1], [0]))
+    else:
+        out[-1] = np.tensordot(out[-1], T, axes=([3], [0]))
+    return out
+
+
+def _compress_lr(M, cutoff, maxdim):
+    """QR gauge sweep left -> right, then truncating two-site SVD sweep right -> left
+    (zip_to_compress_mpo "down", dt_transformer.jl:185-230)."""
+    out = list(M)
+    L = len(out)
+    for i in range(L - 1):
+        a, _, _, b = out[i].shape
+        Q, Rm = np.linalg.qr(out[i].reshape(a * 4, b))
+        out[i] = Q.reshape(a, 2, 2, Q.shape[1])
+        out[i + 1] = np.tensordot(Rm, out[i + 1], axes=([1], [0]))
+    for i in range(L - 1, 0, -1):
+        a0, b1 = out[i - 1].shape[0], out[i].shape[3]
+        core = np.tensordot(out[i - 1], out[i], axes=([3], [0])).reshape(a0 * 4, 4 * b1)
+        U, S, Vh = _svd(core, cutoff, maxdim)
+        out[i] = Vh.reshape(len(S), 2, 2, b1)
+        out[i - 1] = (U * S).reshape(a0, 2, 2, len(S))
+    return out
+
+
+def _zip_rl(M, B):
+    return _mirror(_zip_lr(_mirror(M), _mirror(B)))                      # "up", dt_transformer.jl:97-153
+
+
+def _compress_rl(M, cutoff, maxdim):
+    return _mirror(_compress_lr(_mirror(M), cutoff, maxdim))             # "up", dt_transformer.jl:233-276
+
+
+def _pad_pair(M, dtype):
+    eye = np.eye(2, dtype=dtype).reshape(1, 2, 2, 1)
+    return list(M) + [eye.copy(), eye.copy()]
+
+
+# ------------------------------------------------------------------ builders (host tensors)
+def qft_mpo_tensors(n, cutoff=1e-14, maxdim=1000):
+    """build_qft_mpo (qft_transformer.jl:121-160): n-1 rounds of zip-up (QR, no truncation) on the
+    trailing sites followed by a truncating zip-down SVD sweep."""
+    if n < 1:
+        raise ValueError(f"build_qft_mpo: Number of qubits 'n' must be at least 1. Found n={n}")
+    M = _qft_block(n)
+    for it in range(1, n):
+        B = _qft_block(n - it)
+        # zip-up == right-aligned zip with QR-type factorisation (no cutoff => QR), remainder to the left
+        M = _zip_rl(M, B)
+        for k in range(it - 1, n - 1):                                   # zip-down (:69-101)
+            a, _, _, b = M[k].shape
+            U, S, Vh = _svd(M[k].reshape(a * 4, b), cutoff, maxdim)
+            M[k] = U.reshape(a, 2, 2, len(S))
+            M[k + 1] = np.tensordot(S[:, None] * Vh, M[k + 1], axes=([1], [0]))
+    return M
+
+
+def dt_mpo_tensors(n, wr, cutoff=1e-14, maxdim=1000):
+    """build_dt_mpo (dt_transformer.jl:312-407): part 1 main-control blocks k = 1..n zipped "down",
+    part 2 copy-control blocks k = 1..n-1 zipped "up", whole-chain compression after each."""
+    if n < 1:
+        raise ValueError(f"build_dt_mpo: n must be >= 1. Found n={n}")
+    M = _dt_main_block(1, wr)
+    for k in range(2, n + 1):
+        M = _compress_lr(_zip_lr(_pad_pair(M, np.float64), _dt_main_block(k, wr)), cutoff, maxdim)
+    for k in range(1, n):
+        M = _compress_rl(_zip_rl(M, _dt_copy_block(n, k, wr)), cutoff, maxdim)
+    return M
+
+
+def zt_mpo_tensors(n, wr, cutoff=1e-14, maxdim=1000):
+    """build_zt_mpo (zt_transformer.jl:41-106): DT first, then the paired QFT chain, fused by one
+    MPO x MPO product and one compression."""
+    if n < 1:
+        raise ValueError(f"build_zt_mpo: n must be >= 1. Found n={n}")
+    Wdt = dt_mpo_tensors(n, wr, cutoff, maxdim)
+    Q = _zt_block(1)
+    for k in range(2, n + 1):
+        Q = _compress_lr(_zip_lr(_pad_pair(Q, np.complex128), _zt_block(k)), cutoff, maxdim)
+    W = [_compose(a, b) for a, b in zip(Wdt, Q)]
+    return W if n == 1 else _compress_lr(W, cutoff, maxdim)
+
+
+# ------------------------------------------------------------------ device handles (reference signatures)
+def _n_of(x):
+    return len(x) if hasattr(x, "handle") else int(x)
+
+
+def build_qft_mpo(n_or_psi, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
+    """build_qft_mpo(n, sites; cutoff, maxdim) / build_qft_mpo(psi::SignalMPS; ...)."""
+    psi = n_or_psi if hasattr(n_or_psi, "handle") else None
+    n = _n_of(n_or_psi)
+    if sites is not None and len(sites) != n:
+        raise ValueError(f"build_qft_mpo: Number of sites must be equal to n. Found length(sites)={len(sites)}, n={n}")
+    if psi is not None and sites is None:
+        sites, ctx = psi.site_ids, ctx or psi.ctx
+    return SingleSiteMPO(qft_mpo_tensors(n, cutoff, maxdim), sites=sites, ctx=ctx)
+
+
+def build_dt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None):
+    """build_dt_mpo(n, wr, ...; cutoff, maxdim) / build_dt_mpo(psi::ZTMPS, wr; ...)."""
+    psi = n_or_psi if hasattr(n_or_psi, "handle") else None
+    sites = psi.site_ids if psi is not None else None
+    return PairedSiteMPO(dt_mpo_tensors(_n_of(n_or_psi), wr, cutoff, maxdim), sites=sites,
+                         ctx=ctx or (psi.ctx if psi is not None else None))
+
+
+def build_zt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None):
+    """build_zt_mpo(n, wr, ...; cutoff, maxdim) / build_zt_mpo(psi::ZTMPS, wr; ...)."""
+    psi = n_or_psi if hasattr(n_or_psi, "handle") else None
+    sites = psi.site_ids if psi is not None else None
+    return PairedSiteMPO(zt_mpo_tensors(_n_of(n_or_psi), wr, cutoff, maxdim), sites=sites,
+                         ctx=ctx or (psi.ctx if psi is not None else None))
+
+
+def dt_mpo_tensors_many(n, wrs, cutoff=1e-14, maxdim=1000, workers=8):
+    """Independent builds for a sweep of damping values, spread over host threads (LAPACK releases the GIL)."""
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        return list(ex.map(lambda w: dt_mpo_tensors(n, w, cutoff, maxdim), list(wrs)))

@@ -64,11 +64,16 @@ __device__ __forceinline__ void put_planes(double (*S)[GK][GLD], int kk, int i, 
     S[1][kk][i] = v.im;
 }
 
+// gridDim.z > 1 = split-K: slice z handles K range [z*kchunk, (z+1)*kchunk) and writes its partial tile to
+// C + z*cstride (a workspace); splitk_reduce then sums the slices in a fixed order (deterministic).
 template <class T, int OPA, int OPB>
-__global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, long long k,
+__global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, long long k_total,
                                                    const T* __restrict__ A, long long lda,
                                                    const T* __restrict__ B, long long ldb, T* __restrict__ C,
-                                                   long long ldc) {
+                                                   long long ldc, long long kchunk, long long cstride) {
+    const long long kbeg = (long long)blockIdx.z * kchunk;
+    const long long k = min(k_total, kbeg + kchunk);
+    C += (long long)blockIdx.z * cstride;
     constexpr bool CX = sizeof(T) == 16;
     constexpr int NP = CX ? 2 : 1;
     __shared__ double As[NP][GK][GLD];
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, lon
             ii[a][b] = d4{0, 0, 0, 0};
             ri[a][b] = d4{0, 0, 0, 0};
         }
-    for (long long k0 = 0; k0 < k; k0 += GK) {
+    for (long long k0 = kbeg; k0 < k; k0 += GK) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int i, kk;
@@ -160,15 +165,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, lon
 }
 
 template <class T>
+__global__ void splitk_reduce(const T* __restrict__ W, long long cstride, int splits, long long m, long long n,
+                              T* __restrict__ C, long long ldc) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < m * n;
+         t += (long long)gridDim.x * blockDim.x) {
+        T acc = W[t];
+        for (int z = 1; z < splits; ++z) acc = add_t(acc, W[t + z * cstride]);
+        C[(t % m) + ldc * (t / m)] = acc;
+    }
+}
+
+template <class T>
 int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, long long k, const T* A,
                   long long lda, const T* B, long long ldb, T* C, long long ldc) {
     if (m == 0 || n == 0) return QIL_OK;
-    const dim3 grid((unsigned)((m + GT - 1) / GT), (unsigned)((n + GT - 1) / GT)), block(256);
+    const long long tiles = ((m + GT - 1) / GT) * ((n + GT - 1) / GT);
+    // few output tiles + long K (projections Q^H P, sketches of skinny panels): split K over the chip
+    int splits = 1;
+    if (tiles < 128 && k >= 1024) splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / tiles), 64);
+    if (splits < 2) splits = 1;
+    long long kchunk = k, cstride = 0;
+    T* Cout = C;
+    long long ldo = ldc;
+    void* wsp = nullptr;
+    if (splits > 1) {
+        kchunk = (((k + splits - 1) / splits) + GK - 1) / GK * GK;
+        splits = (int)((k + kchunk - 1) / kchunk);
+        cstride = m * n;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cstride * splits) * sizeof(T), &wsp));
+        Cout = static_cast<T*>(wsp);
+        ldo = m;
+    }
+    const dim3 grid((unsigned)((m + GT - 1) / GT), (unsigned)((n + GT - 1) / GT), (unsigned)splits), block(256);
 #define QIL_GEMM_CASE(OA, OB)                                                                           \
     if (opA == OA && opB == OB) {                                                                       \
-        hipLaunchKernelGGL((gemm_kernel<T, OA, OB>), grid, block, 0, ctx->stream, m, n, k, A, lda, B, ldb, C, \
-                           ldc);                                                                        \
+        hipLaunchKernelGGL((gemm_kernel<T, OA, OB>), grid, block, 0, ctx->stream, m, n, k, A, lda, B, ldb,    \
+                           Cout, ldo, kchunk, cstride);                                                 \
         QIL_HIP(hipGetLastError());                                                                     \
+        if (splits > 1) {                                                                               \
+            hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 2048)), \
+                               dim3(256), 0, ctx->stream, (const T*)Cout, cstride, splits, m, n, C, ldc);  \
+            QIL_HIP(hipGetLastError());                                                                 \
+            qil_ctx_free(ctx, wsp);                                                                     \
+        }                                                                                               \
         return QIL_OK;                                                                                  \
     }
     QIL_GEMM_CASE(0, 0)
@@ -192,10 +231,35 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
 }
 
 // ------------------------------------------------------------------ block reductions
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// Cross-lane sums on the DPP path (no LDS crossbar): quad_perm butterflies inside each quad, then
+// row_half_mirror / row_mirror fold the 8- and 16-lane halves; every lane of a 16-lane row ends with the
+// row total.  A ds_bpermute-based __shfl_xor costs ~50+ cycles per step; a DPP move costs a VALU slot.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
     return v;
+}
+__device__ __forceinline__ double read_lane_d(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v = row16_sum(v);
+    return (read_lane_d(v, 0) + read_lane_d(v, 16)) + (read_lane_d(v, 32) + read_lane_d(v, 48));
+}
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    return G == 16 ? row16_sum(v) : wave_sum(v);
 }
 
 // sums `NV` doubles per thread across a 256-thread workgroup; result valid in all threads
@@ -295,6 +359,130 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
     }
 }
 
+
+// Whole one-sided Jacobi SVD iteration in ONE launch of ONE 1024-thread workgroup: V = I, sweeps of the
+// round-robin tournament until no pair rotates, then the column norms.  Each wave owns whole column
+// pairs (lanes stride over rows, shuffle reductions), pairs of a round are disjoint, rounds are
+// separated by a workgroup barrier.  Used when the rotated side is small (<= 128 columns): there the
+// multi-launch form is bounded by ~(n-1) x sweeps kernel boundaries, not by work.  When A and V fit
+// the CU's 160 KiB LDS (LDS = true) they are staged there for the whole iteration, so every round
+// trip of the rotation is an LDS access instead of an L2 one.
+template <class T, int G>
+__device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ldv, int n, double tol,
+                                              int max_sweeps, int* s_rot) {
+    // a column pair is owned by a group of G lanes (16 = one DPP row, or the whole wave)
+    const int tid = threadIdx.x, lane = tid & (G - 1), wave = tid / G;
+    constexpr int NW = 1024 / G;
+    const int npad = n + (n & 1);
+    for (int sweep = 0; sweep < max_sweeps && n > 1; ++sweep) {
+        if (tid == 0) *s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < npad - 1; ++round) {
+            for (int i = wave; i < npad / 2; i += NW) {
+                int p, q;
+                if (i == 0) {
+                    p = npad - 1;
+                    q = round;
+                } else {
+                    p = (round + i) % (npad - 1);
+                    q = (round + npad - 1 - i) % (npad - 1);
+                }
+                if (p >= n || q >= n) continue;
+                if (p > q) {
+                    const int t = p;
+                    p = q;
+                    q = t;
+                }
+                T* ap = A + lda * p;
+                T* aq = A + lda * q;
+                double al = 0, be = 0, gr = 0, gi = 0;
+                for (int r = lane; r < m; r += G) {
+                    const T x = ap[r], y = aq[r];
+                    al += abs2_t(x);
+                    be += abs2_t(y);
+                    dot_parts(x, y, gr, gi);
+                }
+                al = group_sum<G>(al);
+                be = group_sum<G>(be);
+                gr = group_sum<G>(gr);
+                if (sizeof(T) == 16) gi = group_sum<G>(gi);
+                const double g = sqrt(gr * gr + gi * gi);
+                if (!(g > tol * sqrt(al * be)) || g == 0.0) continue;
+                if (lane == 0) *s_rot = 1;
+                const double zeta = (be - al) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                const double pr = gr / g, pi = gi / g;
+                for (int r = lane; r < m; r += G) {
+                    T x = ap[r], y = aq[r];
+                    rotate_pair(x, y, c, sn, pr, pi);
+                    ap[r] = x;
+                    aq[r] = y;
+                }
+                T* vp = V + ldv * p;
+                T* vq = V + ldv * q;
+                for (int r = lane; r < n; r += G) {
+                    T x = vp[r], y = vq[r];
+                    rotate_pair(x, y, c, sn, pr, pi);
+                    vp[r] = x;
+                    vq[r] = y;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        const int any = *s_rot;
+        __syncthreads();
+        if (!any) break;
+    }
+}
+
+template <class T, bool LDS>
+__global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long long lda, int m,
+                                                     T* __restrict__ V, long long ldv, int n, double tol,
+                                                     int max_sweeps, double* __restrict__ norms) {
+    extern __shared__ __attribute__((aligned(16))) char jf_smem[];
+    __shared__ int s_rot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = 16;
+    T* Aw = A;
+    T* Vw = V;
+    int la = (int)lda, lv = (int)ldv;
+    if (LDS) {
+        // odd leading dimension (in doubles): column pairs start on different banks
+        la = m | 1;
+        lv = n | 1;
+        Aw = reinterpret_cast<T*>(jf_smem);
+        Vw = Aw + (size_t)la * n;
+        for (int t = tid; t < m * n; t += 1024) Aw[(t % m) + la * (t / m)] = A[(t % m) + lda * (t / m)];
+    }
+    for (int t = tid; t < n * n; t += 1024) {
+        const int r = t % n, c = t / n;
+        T v{};
+        if (r == c) reinterpret_cast<double*>(&v)[0] = 1.0;
+        Vw[r + lv * c] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // DPP lane-group exec masks must be uniform per group: the `continue`s above are per pair = per group
+    if (m <= 128)
+        jacobi_sweeps<T, 16>(Aw, la, m, Vw, lv, n, tol, max_sweeps, &s_rot);
+    else
+        jacobi_sweeps<T, 64>(Aw, la, m, Vw, lv, n, tol, max_sweeps, &s_rot);
+    for (int j = wave; j < n; j += NW) {
+        const T* a = Aw + la * j;
+        double v = 0;
+        for (int r = lane; r < m; r += 64) v += abs2_t(a[r]);
+        v = wave_sum(v);
+        if (lane == 0) norms[j] = sqrt(v);
+    }
+    if (LDS) {
+        __syncthreads();
+        for (int t = tid; t < m * n; t += 1024) A[(t % m) + lda * (t / m)] = Aw[(t % m) + la * (t / m)];
+        for (int t = tid; t < n * n; t += 1024) V[(t % n) + ldv * (t / n)] = Vw[(t % n) + lv * (t / n)];
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void col_norms(const T* __restrict__ A, long long lda, long long m,
                                                  double* __restrict__ out) {
@@ -348,12 +536,109 @@ __global__ void conj_transpose(const T* __restrict__ A, long long lda, long long
     }
 }
 
+// Whole CGS2 QR in ONE launch of ONE 1024-thread workgroup (small/medium panels).  Per column, two
+// project/subtract passes then normalisation.  The projections c[i] = q_i^H y for ALL previous columns
+// are accumulated together: every thread owns rows (tid, tid+1024, ...) and keeps up to 16 partial dot
+// products in registers, so each pass is one sweep over the rows with 1024 loads in flight, followed by
+// one DPP/LDS reduction -- not one latency-bound loop per previous column.
+template <class T>
+__global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long lda, int m, int n,
+                                                 T* __restrict__ R, long long ldr) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* c = reinterpret_cast<T*>(smem_raw);                 // n entries
+    __shared__ double red[16][34];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = 16, CH = 16;
+    constexpr int NC = sizeof(T) == 16 ? 2 : 1;
+    if (R)
+        for (int t = tid; t < n * n; t += 1024) R[(t % n) + ldr * (t / n)] = T{};
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        T* y = A + lda * j;
+        for (int pass = 0; pass < 2 && j > 0; ++pass) {
+            for (int i0 = 0; i0 < j; i0 += CH) {
+                const int nc = min(CH, j - i0);
+                double acc[CH][2];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) acc[i][0] = acc[i][1] = 0.0;
+                for (int r = tid; r < m; r += 1024) {
+                    const T yv = y[r];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        if (i < nc) dot_parts(A[r + lda * (i0 + i)], yv, acc[i][0], acc[i][1]);
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    if (i < nc) {
+                        const double s0 = wave_sum(acc[i][0]);
+                        if (lane == 0) red[wave][2 * i] = s0;
+                        if (NC == 2) {
+                            const double s1 = wave_sum(acc[i][1]);
+                            if (lane == 0) red[wave][2 * i + 1] = s1;
+                        }
+                    }
+                __syncthreads();
+                if (tid < nc) {
+                    double sr = 0, si = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        sr += red[w][2 * tid];
+                        if (NC == 2) si += red[w][2 * tid + 1];
+                    }
+                    T out{};
+                    reinterpret_cast<double*>(&out)[0] = sr;
+                    if (NC == 2) reinterpret_cast<double*>(&out)[1] = si;
+                    c[i0 + tid] = out;
+                }
+                __syncthreads();
+            }
+            for (int r = tid; r < m; r += 1024) {
+                T acc = y[r];
+                for (int i = 0; i < j; ++i) acc = sub_t(acc, fma_t(A[r + lda * i], c[i], T{}));
+                y[r] = acc;
+            }
+            if (R)
+                for (int i = tid; i < j; i += 1024) R[i + ldr * j] = add_t(R[i + ldr * j], c[i]);
+            __threadfence_block();
+            __syncthreads();
+        }
+        double v = 0;
+        for (int r = tid; r < m; r += 1024) v += abs2_t(y[r]);
+        v = wave_sum(v);
+        if (lane == 0) red[wave][32] = v;
+        __syncthreads();
+        double tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[w][32];
+        const double nrm = sqrt(tot);
+        const double inv = nrm > 0 ? 1.0 / nrm : 0.0;
+        for (int r = tid; r < m; r += 1024) y[r] = scale_t(y[r], inv);
+        if (R && tid == 0) {
+            T out{};
+            reinterpret_cast<double*>(&out)[0] = nrm;
+            R[j + ldr * j] = out;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+template <class T>
+int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr);
+template <class T>
+int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, long long k, const T* A,
+                  long long lda, const T* B, long long ldb, T* C, long long ldc);
+
+// Thin SVD A = U diag(S) Vh by one-sided Jacobi on the SHORT side.
+//   1. orientation: the work matrix has rows >= cols (A^H if m < n);
+//   2. tall-skinny (rows >= 8 cols): QR first, Jacobi on the cols x cols factor R, U = Q U_R;
+//   3. cols <= 128: the whole iteration is one launch (jacobi_fused); otherwise one launch per
+//      tournament round with one workgroup per column pair (jacobi_round).
 template <class T>
 int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* U, long long ldu,
              double* S_host, T* Vh, long long ldvh) {
     const long long r0 = std::min(m, n);
     if (r0 == 0) return QIL_OK;
-    // Work on the orientation with the fewer columns: one-sided Jacobi rotates columns.
     const bool flip = m < n;
     T* Wk = A;           // work matrix (rows x cols), columns get orthogonalised
     long long ldw = lda, rows = m, cols = n;
@@ -367,6 +652,20 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)),
                            dim3(256), 0, ctx->stream, A, lda, m, n, Wk, ldw);
     }
+    // tall-skinny: Wk = Q R, rotate R instead
+    T* Q = nullptr;
+    long long ldq = 0, qrows = 0;
+    void* rbuf = nullptr;
+    if (rows >= 8 * cols && rows >= 512) {
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rbuf));
+        QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols));
+        Q = Wk;
+        ldq = ldw;
+        qrows = rows;
+        Wk = static_cast<T*>(rbuf);
+        ldw = cols;
+        rows = cols;
+    }
     void *vbuf = nullptr, *flag = nullptr, *nrm = nullptr, *permd = nullptr, *scd = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &vbuf));
     QIL_TRY(qil_ctx_alloc(ctx, 256, &flag));
@@ -374,13 +673,28 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)cols * sizeof(int), &permd));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)cols * sizeof(double), &scd));
     T* V = static_cast<T*>(vbuf);
-    hipLaunchKernelGGL(set_identity<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
-                       dim3(256), 0, ctx->stream, V, cols, (int)cols);
     const int ncol = (int)cols;
     const int npad = ncol + (ncol & 1);
-    if (ncol > 1) {
-        const double tol = 1e-15;
-        for (int sweep = 0; sweep < 40; ++sweep) {
+    const double tol = 1e-15;
+    if (ncol <= 96 && rows * cols <= (1LL << 19)) {
+        const size_t lds_need = ((size_t)((rows | 1) * cols) + (size_t)((cols | 1) * cols)) * sizeof(T);
+        if (lds_need <= 150 * 1024) {
+            static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+            if (!attr_set) {
+                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_fused<T, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((jacobi_fused<T, true>), dim3(1), dim3(1024), lds_need, ctx->stream, Wk, ldw,
+                               (int)rows, V, cols, ncol, tol, 40, (double*)nrm);
+        } else {
+            hipLaunchKernelGGL((jacobi_fused<T, false>), dim3(1), dim3(1024), 0, ctx->stream, Wk, ldw, (int)rows,
+                               V, cols, ncol, tol, 40, (double*)nrm);
+        }
+    } else {
+        hipLaunchKernelGGL(set_identity<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
+                           dim3(256), 0, ctx->stream, V, cols, (int)cols);
+        for (int sweep = 0; sweep < 40 && ncol > 1; ++sweep) {
             QIL_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
             for (int round = 0; round < npad - 1; ++round)
                 hipLaunchKernelGGL(jacobi_round<T>, dim3(npad / 2), dim3(256), 0, ctx->stream, Wk, ldw, rows, V,
@@ -390,8 +704,9 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
             QIL_HIP(hipStreamSynchronize(ctx->stream));
             if (!h) break;
         }
+        hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)cols), dim3(256), 0, ctx->stream, Wk, ldw, rows,
+                           (double*)nrm);
     }
-    hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)cols), dim3(256), 0, ctx->stream, Wk, ldw, rows, (double*)nrm);
     std::vector<double> sig((size_t)cols);
     QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)cols * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QIL_HIP(hipStreamSynchronize(ctx->stream));
@@ -408,23 +723,46 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     QIL_HIP(hipMemcpyAsync(scd, inv.data(), (size_t)cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const unsigned gb = (unsigned)std::min<long long>((rows * cols + 255) / 256, 65536);
     const unsigned gv = (unsigned)std::min<long long>((cols * cols + 255) / 256, 65536);
+    // left factor of the work matrix: Wk[:, perm] D^-1 (rows x cols); with QR preprocessing it is Q * that
+    void* lbuf = nullptr;
+    T* Lw = nullptr;      // where the (orthonormal) left factor of the ORIENTED problem goes
+    long long ldl = 0, lrows = Q ? qrows : rows;
+    T* left_dst = flip ? nullptr : U;   // not flipped: left factor is U itself
+    if (Q) {
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &lbuf));
+        hipLaunchKernelGGL(gather_cols<T>, dim3(gv), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
+                           (const int*)permd, (const double*)scd, static_cast<T*>(lbuf), cols, (int)cols, 0);
+    }
     if (!flip) {
-        // A = (Wk D^-1) D V^H
-        hipLaunchKernelGGL(gather_cols<T>, dim3(gb), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
-                           (const int*)permd, (const double*)scd, U, ldu, (int)cols, 0);
+        // A = L D V^H : U = L, Vh = V[:, perm]^H
+        if (Q) {
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, lrows, cols, cols, Q, ldq, static_cast<T*>(lbuf), cols, U, ldu));
+        } else {
+            hipLaunchKernelGGL(gather_cols<T>, dim3(gb), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
+                               (const int*)permd, (const double*)scd, U, ldu, (int)cols, 0);
+        }
         hipLaunchKernelGGL(gather_cols<T>, dim3(gv), dim3(256), 0, ctx->stream, (const T*)V, cols, cols,
                            (const int*)permd, (const double*)nullptr, Vh, ldvh, (int)cols, 1);
     } else {
-        // A^H = (Wk D^-1) D V^H  =>  A = V D (Wk D^-1)^H
+        // A^H = L D V^H  =>  A = V D L^H : U = V[:, perm], Vh = L^H
         hipLaunchKernelGGL(gather_cols<T>, dim3(gv), dim3(256), 0, ctx->stream, (const T*)V, cols, cols,
                            (const int*)permd, (const double*)nullptr, U, ldu, (int)cols, 0);
-        hipLaunchKernelGGL(gather_cols<T>, dim3(gb), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
-                           (const int*)permd, (const double*)scd, Vh, ldvh, (int)cols, 1);
+        if (Q) {
+            // Vh (cols x lrows) = (Q * Lsmall)^H = Lsmall^H * Q^H
+            QIL_TRY(gemm_dispatch<T>(ctx, sizeof(T) == 16 ? 2 : 1, sizeof(T) == 16 ? 2 : 1, cols, lrows, cols,
+                                     static_cast<T*>(lbuf), cols, Q, ldq, Vh, ldvh));
+        } else {
+            hipLaunchKernelGGL(gather_cols<T>, dim3(gb), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
+                               (const int*)permd, (const double*)scd, Vh, ldvh, (int)cols, 1);
+        }
     }
+    (void)Lw; (void)ldl; (void)left_dst;
     QIL_HIP(hipGetLastError());
     // perm/inv are host vectors read by async copies: finish before they go out of scope
     QIL_HIP(hipStreamSynchronize(ctx->stream));
     if (tbuf) qil_ctx_free(ctx, tbuf);
+    if (rbuf) qil_ctx_free(ctx, rbuf);
+    if (lbuf) qil_ctx_free(ctx, lbuf);
     qil_ctx_free(ctx, vbuf);
     qil_ctx_free(ctx, flag);
     qil_ctx_free(ctx, nrm);
@@ -485,27 +823,73 @@ __global__ __launch_bounds__(256) void gs_normalize(T* __restrict__ y, long long
     }
 }
 
+// R[0:k, j0:j0+b] += C (k x b)
+template <class T>
+__global__ void add_block(T* __restrict__ R, long long ldr, const T* __restrict__ C, long long ldc, int k,
+                          int b) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < k * b; t += gridDim.x * blockDim.x) {
+        const int i = t % k, j = t / k;
+        R[i + ldr * j] = add_t(R[i + ldr * j], C[i + ldc * j]);
+    }
+}
+// P -= D  (m x b)
+template <class T>
+__global__ void sub_block(T* __restrict__ P, long long ldp, const T* __restrict__ D, long long ldd, long long m,
+                          int b) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < m * b;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long i = t % m, j = t / m;
+        P[i + ldp * j] = sub_t(P[i + ldp * j], D[i + ldd * j]);
+    }
+}
+
+// Thin QR with non-negative diagonal (qr(...; positive=true), rsvd.jl:83,90,94).
+//   * small panels: ONE launch (gs_fused);
+//   * otherwise blocked CGS2: panels of 16 columns are projected against all previous columns with two
+//     MFMA GEMMs per pass (C = Q^H P, P -= Q C) and orthonormalised internally by gs_fused -- the work is
+//     spread over the chip by the GEMMs and the launch count drops from ~5 n to ~7 n / 16.
 template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
-    void* cbuf = nullptr;
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)std::max<long long>(n, 1) * sizeof(T), &cbuf));
-    T* c = static_cast<T*>(cbuf);
+    if (n <= 16 || m * n <= (1LL << 15)) {
+        if (m > (1LL << 22)) return qil_fail(QIL_EINVAL_ARG, "qr: panel too tall (%lld rows)", m);
+        hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)n * sizeof(T), ctx->stream, A, lda, (int)m,
+                           (int)n, R, ldr);
+        QIL_HIP(hipGetLastError());
+        return QIL_OK;
+    }
+    constexpr int PB = 16;
     if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
-    const unsigned rb = (unsigned)((m + 255) / 256);
-    for (int j = 0; j < (int)n; ++j) {
-        T* y = A + lda * j;
-        if (j > 0)
-            for (int pass = 0; pass < 2; ++pass) {
-                hipLaunchKernelGGL(gs_project<T>, dim3(j), dim3(256), 0, ctx->stream, (const T*)A, lda, m,
-                                   (const T*)y, c);
-                hipLaunchKernelGGL(gs_subtract<T>, dim3(rb), dim3(256), 0, ctx->stream, (const T*)A, lda, m, j, y,
-                                   (const T*)c, R ? R + ldr * j : (T*)nullptr);
-            }
-        hipLaunchKernelGGL(gs_normalize<T>, dim3(1), dim3(256), 0, ctx->stream, y, m,
-                           R ? R + j + ldr * j : (T*)nullptr);
+    void *cbuf = nullptr, *dbuf = nullptr, *rpan = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * PB) * sizeof(T), &cbuf));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * PB) * sizeof(T), &dbuf));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(PB * PB) * sizeof(T), &rpan));
+    T* C = static_cast<T*>(cbuf);
+    T* D = static_cast<T*>(dbuf);
+    T* Rp = static_cast<T*>(rpan);
+    const int opH = sizeof(T) == 16 ? 2 : 1;
+    for (long long j0 = 0; j0 < n; j0 += PB) {
+        const int b = (int)std::min<long long>(PB, n - j0);
+        T* P = A + lda * j0;
+        for (int pass = 0; pass < 2 && j0 > 0; ++pass) {
+            QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, j0, b, m, A, lda, P, lda, C, n));      // C = Q^H P
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, b, j0, A, lda, C, n, D, m));          // D = Q C
+            hipLaunchKernelGGL(sub_block<T>, dim3((unsigned)std::min<long long>((m * b + 255) / 256, 4096)),
+                               dim3(256), 0, ctx->stream, P, lda, (const T*)D, m, m, b);
+            if (R)
+                hipLaunchKernelGGL(add_block<T>, dim3(8), dim3(256), 0, ctx->stream, R + ldr * j0, ldr, (const T*)C,
+                                   n, (int)j0, b);
+        }
+        // intra-panel CGS2 (one launch); its b x b triangular factor goes to R[j0:, j0:]
+        hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)b * sizeof(T), ctx->stream, P, lda, (int)m, b,
+                           R ? Rp : (T*)nullptr, (long long)PB);
+        if (R)
+            QIL_HIP(hipMemcpy2DAsync(R + j0 + ldr * j0, (size_t)ldr * sizeof(T), Rp, (size_t)PB * sizeof(T),
+                                     (size_t)b * sizeof(T), (size_t)b, hipMemcpyDeviceToDevice, ctx->stream));
     }
     QIL_HIP(hipGetLastError());
     qil_ctx_free(ctx, cbuf);
+    qil_ctx_free(ctx, dbuf);
+    qil_ctx_free(ctx, rpan);
     return QIL_OK;
 }
 

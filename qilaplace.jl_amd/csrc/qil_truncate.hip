@@ -167,6 +167,24 @@ __global__ void fuse_delta(const T* __restrict__ A, int cl, int cr, T* __restric
 
 inline unsigned nblk(long long total) { return (unsigned)std::min<long long>((total + 255) / 256, 65536); }
 
+// per-workgroup partial sums of squares (fixed grid => the host-side final sum has a fixed order)
+__global__ __launch_bounds__(256) void sumsq_partial(const double* __restrict__ x, long long n,
+                                                     double* __restrict__ part) {
+    __shared__ double red[4];
+    double v = 0;
+    for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n; t += (long long)gridDim.x * 256) v += x[t] * x[t];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void scale_inplace(double* __restrict__ x, long long n, double s) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x)
+        x[t] *= s;
+}
+
 // ---------------------------------------------------------------- rsvd on a device operand
 // `Z` holds M^T (plain transpose) column-major: Z is (n x m) for the m x n operand M ("M stored
 // row-major").  Produces, with k = kept rank,
@@ -318,18 +336,34 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
     const int64_t N = 1LL << n;
     QIL_REQUIRE(len <= N, QIL_EINVAL_LENGTH,
                 "_array_to_tensor: Length of signal vector must be a power of 2 (got %lld)", (long long)len);
+    // upload the raw samples, zero-fill the tail, then norm + scale ON THE DEVICE (the host never makes
+    // a pass over the 2^n samples)
     const int ncomp = dtype == QIL_C64 ? 2 : 1;
-    std::vector<double> xh((size_t)(N * ncomp), 0.0);
-    const double* xs = static_cast<const double*>(x);
-    double ss = 0;
-    for (int64_t i = 0; i < len * ncomp; ++i) ss += xs[i] * xs[i];
-    const double amp = std::sqrt(ss);
-    for (int64_t i = 0; i < len * ncomp; ++i) xh[(size_t)i] = xs[i] / amp;
     const size_t e = qil_elem_size(dtype);
     void* X = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)N * e, &X));
-    QIL_HIP(hipMemcpyAsync(X, xh.data(), (size_t)N * e, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(X, x, (size_t)len * e, hipMemcpyHostToDevice, ctx->stream));
+    if (len < N)
+        QIL_HIP(hipMemsetAsync(static_cast<char*>(X) + (size_t)len * e, 0, (size_t)(N - len) * e, ctx->stream));
+    void* part = nullptr;
+    constexpr int kPartBlocks = 1024;
+    QIL_TRY(qil_ctx_alloc(ctx, kPartBlocks * sizeof(double), &part));
+    hipLaunchKernelGGL(sumsq_partial, dim3(kPartBlocks), dim3(256), 0, ctx->stream, (const double*)X,
+                       (long long)(N * ncomp), (double*)part);
+    std::vector<double> ph(kPartBlocks);
+    QIL_HIP(hipMemcpyAsync(ph.data(), part, kPartBlocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));   // also completes the upload of caller memory `x`
+    qil_ctx_free(ctx, part);
+    double ss = 0;
+    for (double v : ph) ss += v;                  // fixed order: deterministic
+    const double amp = std::sqrt(ss);
+    if (!(amp > 0 && std::isfinite(amp))) {
+        qil_ctx_free(ctx, X);
+        return qil_fail(QIL_EINVAL_ARG, "signal_mps: signal has zero or non-finite norm");
+    }
+    hipLaunchKernelGGL(scale_inplace, dim3(nblk(N * ncomp)), dim3(256), 0, ctx->stream, (double*)X,
+                       (long long)(N * ncomp), 1.0 / amp);
+    QIL_HIP(hipGetLastError());
     std::vector<void*> sites((size_t)n, nullptr);
     std::vector<int64_t> dims((size_t)n + 1, 1);
     int s;

@@ -1,0 +1,55 @@
+"""Host-side MPO builders of the product package (qilaplace.jl_amd/builders.py) against the oracle's
+dense operators, the closed forms, and the reference's committed bond-dimension series."""
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import dense_mpo
+
+
+@pytest.fixture(scope="module")
+def qil():
+    import qilaplace_jl_amd as q
+    return q
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5])
+def test_qft_tensors_are_the_bit_reversed_dft(qil, n):
+    M = dense_mpo(qil.qft_mpo_tensors(n))
+    assert np.abs(M - O.qn_matrix(n).T).max() < 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("wr", [0.0, 0.75, 5.0])
+def test_dt_zt_tensors_equal_oracle_operators(qil, n, wr):
+    for mine, ref in ((qil.dt_mpo_tensors(n, wr), O.build_dt_mpo(n, wr).data),
+                      (qil.zt_mpo_tensors(n, wr), O.build_zt_mpo(n, wr).data)):
+        assert [t.shape[3] for t in mine] == [t.shape[3] for t in ref]
+        assert np.abs(dense_mpo(mine) - dense_mpo(ref)).max() < 2e-7
+
+
+def test_bond_series_match_reference_artifact(qil, pins):
+    want = pins["mpo_maxbond_n2_30"]
+    mb = lambda ts: max(t.shape[3] for t in ts)
+    for i, n in enumerate(range(2, 9)):
+        assert mb(qil.qft_mpo_tensors(n, cutoff=1e-15, maxdim=None)) == want["qft"][i]
+        assert mb(qil.dt_mpo_tensors(n, 2 * np.pi, cutoff=1e-15, maxdim=None)) == want["dt"][i]
+        assert mb(qil.zt_mpo_tensors(n, 2 * np.pi, cutoff=1e-15, maxdim=None)) == want["zt"][i]
+    assert mb(qil.qft_mpo_tensors(14, cutoff=1e-15)) == want["qft"][12]
+    assert mb(qil.dt_mpo_tensors(10, 2 * np.pi, cutoff=1e-15)) == want["dt"][8]
+
+
+def test_tutorial_bond_pins(qil, pins):
+    assert [t.shape[3] for t in qil.qft_mpo_tensors(4, cutoff=1e-14, maxdim=100)][:-1] == pins["dft_tutorial"]["qft_mpo_bonds_n4"]
+    assert [t.shape[3] for t in qil.zt_mpo_tensors(2, 2 * np.pi, cutoff=1e-14, maxdim=64)][:-1] == pins["zt_tutorial"]["zt_mpo_chain_bonds"]
+    many = qil.dt_mpo_tensors_many(3, [0.5, 1.2], workers=2)
+    assert np.abs(dense_mpo(many[1]) - dense_mpo(O.build_dt_mpo(3, 1.2).data)).max() < 1e-12
+
+
+def test_builder_argument_errors(qil):
+    with pytest.raises(ValueError):
+        qil.qft_mpo_tensors(0)
+    with pytest.raises(ValueError):
+        qil.dt_mpo_tensors(0, 1.0)
+    with pytest.raises(ValueError):
+        qil.zt_mpo_tensors(0, 1.0)
