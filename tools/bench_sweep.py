@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--n", type=int, default=24)
     ap.add_argument("--sigmas", type=int, default=64)
     ap.add_argument("--samples", type=int, default=1024)
-    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--workers", type=int, default=32)
     args = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     dist = None
