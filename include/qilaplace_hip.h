@@ -200,6 +200,10 @@ int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n, int dty
 int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
              const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc);
 
+/* Diagnostic: device-resident time of the same GEMM (operands generated in HBM, HIP events). */
+int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+                         int reps, double* ms_per_call);
+
 #ifdef __cplusplus
 }
 #endif

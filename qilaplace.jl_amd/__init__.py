@@ -16,7 +16,7 @@ from .containers import (Context, default_context, set_default_context, device_c
                          SignalMPS, ZTMPS, SingleSiteMPO, PairedSiteMPO)
 from .ops import (apply, coefficient, coefficient_batch, apply_coefficient_batch,  # noqa: F401
                   mps_to_vector, norm, canonicalize, compress, signal_mps, signal_ztmps, rsvd,
-                  svd_trunc, gemm)
+                  svd_trunc, gemm, gemm_device_time)
 from .builders import (build_qft_mpo, build_dt_mpo, build_zt_mpo, qft_mpo_tensors,  # noqa: F401
                        dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many)
 from .sweep import shard_items, sweep, damping_sweep, gather_results  # noqa: F401

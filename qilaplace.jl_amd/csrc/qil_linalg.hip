@@ -39,100 +39,168 @@ __device__ __forceinline__ double add_t(double a, double b) { return a + b; }
 __device__ __forceinline__ c64 add_t(c64 a, c64 b) { return c64{a.re + b.re, a.im + b.im}; }
 
 // ------------------------------------------------------------------ GEMM on the f64 matrix cores
-// C (m x n) = opA(A) * opB(B), f64 or c64, through v_mfma_f64_16x16x4_f64.
-//   * 64 x 64 output tile per 256-thread workgroup; wave w owns a 32 x 32 quadrant = 2 x 2 MFMA tiles
-//   * K tiles of 16 staged in LDS as split re/im planes, rows padded to 80 doubles: row stride
-//     640 B == 128 (mod 256) so the two 16-lane halves of a 32-lane ds_read_b64 group hit disjoint banks
+// C (m x n) = opA(A) * opB(B), f64 or c64, through v_mfma_f64_16x16x4_f64 (64-cycle issue per SIMD).
+//   * BM x BN output tile per 256-thread workgroup, 4 waves in a (BM/WM) x (BN/WN) arrangement, each
+//     wave WM/16 x WN/16 MFMA tiles (up to 4 x 4 = 64 accumulator doubles per lane);
+//   * K tiles of 16; PIPE = true: software pipelined -- the next tile's global loads are issued into
+//     registers right after the barrier and land while the current tile's MFMAs run, LDS double buffered,
+//     ONE barrier per K tile (f64: fewer registers, 2 waves/SIMD still fit); PIPE = false: single buffer,
+//     smaller footprint => 3 waves/SIMD, which the complex kernel (3 accumulator sets) needs to keep the
+//     matrix pipe fed.  Measured issue ceiling of this MFMA on MI355X: 47 TFLOP/s with >= 2 waves/SIMD,
+//     35 TFLOP/s with one (tools/micro/mfma_f64_peak.hip);
+//   * LDS holds split re/im planes, rows padded by 2 doubles (keeps both the k-major staging writes and
+//     the fragment reads at <= 2-way bank conflicts);
 //   * the MFMA is issued as (B^T tile) x (A^T tile) = (AB)^T tile: the D fragment then has the C ROW
-//     index on lane&15, so every 16 lanes store 128 B (f64) / 256 B (c64) contiguous in column-major C
-//   * complex product = 4 real MFMAs into 3 accumulators (rr, ii, ri): C = (rr - ii) + i ri
-constexpr int GT = 64, GK = 16, GLD = 80;
+//     index on lane&15, so every 16 lanes store 128 B (f64) / 256 B (c64) contiguous in column-major C;
+//   * complex product = 4 real MFMAs into 3 accumulators (rr, ii, ri): C = (rr - ii) + i ri;
+//   * operands are addressed through (row stride, k stride, conj) so N/T/H/conj need no extra kernels;
+//     the global->register mapping follows whichever index is contiguous (coalesced either way);
+//   * gridDim.z > 1 = split-K into a workspace + fixed-order reduction (deterministic).
+constexpr int GK = 16;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <class T, int OP>
-__device__ __forceinline__ T load_op(const T* __restrict__ M, long long ld, long long r, long long c) {
-    // element (r, c) of op(M); OP: 0 = N, 1 = T, 2 = H, 3 = conj (no transpose)
-    if (OP == 0) return M[r + ld * c];
-    if (OP == 3) return conj_t(M[r + ld * c]);
-    T v = M[c + ld * r];
-    return OP == 2 ? conj_t(v) : v;
+__device__ __forceinline__ void put_plane(double* S0, double* S1, int off, double v) {
+    S0[off] = v;
+    (void)S1;
 }
-
-__device__ __forceinline__ void put_planes(double (*S)[GK][GLD], int kk, int i, double v) { S[0][kk][i] = v; }
-__device__ __forceinline__ void put_planes(double (*S)[GK][GLD], int kk, int i, c64 v) {
-    S[0][kk][i] = v.re;
-    S[1][kk][i] = v.im;
+__device__ __forceinline__ void put_plane(double* S0, double* S1, int off, c64 v) {
+    S0[off] = v.re;
+    S1[off] = v.im;
 }
+__device__ __forceinline__ double maybe_conj(double v, int) { return v; }
+__device__ __forceinline__ c64 maybe_conj(c64 v, int cj) { return cj ? c64{v.re, -v.im} : v; }
 
-// gridDim.z > 1 = split-K: slice z handles K range [z*kchunk, (z+1)*kchunk) and writes its partial tile to
-// C + z*cstride (a workspace); splitk_reduce then sums the slices in a fixed order (deterministic).
-template <class T, int OPA, int OPB>
-__global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, long long k_total,
-                                                   const T* __restrict__ A, long long lda,
-                                                   const T* __restrict__ B, long long ldb, T* __restrict__ C,
-                                                   long long ldc, long long kchunk, long long cstride) {
-    const long long kbeg = (long long)blockIdx.z * kchunk;
-    const long long k = min(k_total, kbeg + kchunk);
-    C += (long long)blockIdx.z * cstride;
+template <class T, int BM, int BN, int WM, int WN, bool PIPE>
+__global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long long k_total,
+                                                 const T* __restrict__ A, long long a_rs, long long a_ks, int conjA,
+                                                 const T* __restrict__ B, long long b_ks, long long b_cs, int conjB,
+                                                 T* __restrict__ C, long long ldc, long long kchunk,
+                                                 long long cstride, int tiles_m, int tiles_n, int col_fastest) {
     constexpr bool CX = sizeof(T) == 16;
     constexpr int NP = CX ? 2 : 1;
-    __shared__ double As[NP][GK][GLD];
-    __shared__ double Bs[NP][GK][GLD];
+    constexpr int LA = BM + 2, LB = BN + 2;   // +2 doubles: <= 2-way LDS conflicts for both the k-major
+                                              // staging writes and the fragment reads
+    constexpr int NBUF = PIPE ? 2 : 1;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int EA = BM * GK / 256, EB = BN * GK / 256;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
+    double* As = reinterpret_cast<double*>(gemm_smem);            // [NBUF][NP][GK][LA]
+    double* Bs = As + NBUF * NP * GK * LA;                         // [NBUF][NP][GK][LB]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+    const int wr = (wave % (BM / WM)) * WM, wc = (wave / (BM / WM)) * WN;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const long long row0 = (long long)blockIdx.x * GT, col0 = (long long)blockIdx.y * GT;
-    d4 rr[2][2], ii[2][2], ri[2][2];
+    int tm, tn;
+    if (col_fastest) {
+        tn = blockIdx.x % tiles_n;
+        tm = blockIdx.x / tiles_n;
+    } else {
+        tm = blockIdx.x % tiles_m;
+        tn = blockIdx.x / tiles_m;
+    }
+    const long long row0 = (long long)tm * BM, col0 = (long long)tn * BN;
+    const long long kbeg = (long long)blockIdx.z * kchunk;
+    const long long kend = min(k_total, kbeg + kchunk);
+    C += (long long)blockIdx.z * cstride;
+
+    d4 rr[TM][TN], ii[CX ? TM : 1][CX ? TN : 1], ri[CX ? TM : 1][CX ? TN : 1];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < TN; ++b) {
             rr[a][b] = d4{0, 0, 0, 0};
-            ii[a][b] = d4{0, 0, 0, 0};
-            ri[a][b] = d4{0, 0, 0, 0};
+            if (CX) {
+                ii[a][b] = d4{0, 0, 0, 0};
+                ri[a][b] = d4{0, 0, 0, 0};
+            }
         }
-    for (long long k0 = kbeg; k0 < k; k0 += GK) {
+    // global -> register mapping: fastest along the contiguous index of each operand
+    const bool a_rows_contig = a_rs == 1, b_k_contig = b_ks == 1;
+    T ra[EA], rb[EB];
+    auto load_tile = [&](long long k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int i, kk;
-            if (OPA == 0 || OPA == 3) {
-                i = tid & 63;
-                kk = (tid >> 6) + 4 * r;
-            } else {
-                kk = tid & 15;
-                i = (tid >> 4) + 16 * r;
-            }
+        for (int e = 0; e < EA; ++e) {
+            const int idx = tid + 256 * e;
+            const int i = a_rows_contig ? idx % BM : idx / GK;
+            const int kk = a_rows_contig ? idx / BM : idx % GK;
             const long long gr = row0 + i, gk = k0 + kk;
-            put_planes(As, kk, i, (gr < m && gk < k) ? load_op<T, OPA>(A, lda, gr, gk) : T{});
-            int j, kb;
-            if (OPB == 0 || OPB == 3) {
-                kb = tid & 15;
-                j = (tid >> 4) + 16 * r;
+            // branch-free edge handling: load from a clamped (always valid) address, then zero the
+            // out-of-range lanes -- a conditional load would put every load in its own exec branch with
+            // its own vmcnt(0) wait, serialising the tile's loads
+            // (for 8-byte elements hipcc already predicates the plain conditional load, and that form is faster)
+            if constexpr (CX) {
+                T v = A[min(gr, m - 1) * a_rs + min(gk, kend - 1) * a_ks];
+                v = maybe_conj(v, conjA);
+                if (!(gr < m && gk < kend)) v = T{};
+                ra[e] = v;
             } else {
-                j = tid & 63;
-                kb = (tid >> 6) + 4 * r;
+                ra[e] = (gr < m && gk < kend) ? A[gr * a_rs + gk * a_ks] : T{};
             }
-            const long long gc = col0 + j, gk2 = k0 + kb;
-            put_planes(Bs, kb, j, (gc < n && gk2 < k) ? load_op<T, OPB>(B, ldb, gk2, gc) : T{});
         }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int idx = tid + 256 * e;
+            const int kk = b_k_contig ? idx % GK : idx / BN;
+            const int j = b_k_contig ? idx / GK : idx % BN;
+            const long long gc = col0 + j, gk = k0 + kk;
+            if constexpr (CX) {
+                T v = B[min(gk, kend - 1) * b_ks + min(gc, n - 1) * b_cs];
+                v = maybe_conj(v, conjB);
+                if (!(gc < n && gk < kend)) v = T{};
+                rb[e] = v;
+            } else {
+                rb[e] = (gc < n && gk < kend) ? B[gk * b_ks + gc * b_cs] : T{};
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        double* a0 = As + (buf * NP) * GK * LA;
+        double* b0 = Bs + (buf * NP) * GK * LB;
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            const int idx = tid + 256 * e;
+            const int i = a_rows_contig ? idx % BM : idx / GK;
+            const int kk = a_rows_contig ? idx / BM : idx % GK;
+            put_plane(a0, a0 + GK * LA, kk * LA + i, ra[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int idx = tid + 256 * e;
+            const int kk = b_k_contig ? idx % GK : idx / BN;
+            const int j = b_k_contig ? idx / GK : idx % BN;
+            put_plane(b0, b0 + GK * LB, kk * LB + j, rb[e]);
+        }
+    };
+    int buf = 0;
+    if (PIPE && kbeg < kend) load_tile(kbeg);
+    for (long long k0 = kbeg; k0 < kend; k0 += GK) {
+        if (!PIPE) {
+            if (k0 > kbeg) __syncthreads();         // everyone is done reading the single buffer
+            load_tile(k0);
+        }
+        store_tile(buf);
         __syncthreads();
+        if (PIPE && k0 + GK < kend) load_tile(k0 + GK);     // in flight during the MFMAs below
+        const double* a0 = As + (buf * NP) * GK * LA;
+        const double* b0 = Bs + (buf * NP) * GK * LB;
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
-            double are[2], aim[2], bre[2], bim[2];
+            double are[TM], aim[TM], bre[TN], bim[TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                are[t] = As[0][kk + l4][wr + 16 * t + l15];
-                bre[t] = Bs[0][kk + l4][wc + 16 * t + l15];
-                if (CX) {
-                    aim[t] = As[NP - 1][kk + l4][wr + 16 * t + l15];
-                    bim[t] = Bs[NP - 1][kk + l4][wc + 16 * t + l15];
-                }
+            for (int t = 0; t < TM; ++t) {
+                are[t] = a0[(kk + l4) * LA + wr + 16 * t + l15];
+                if (CX) aim[t] = a0[GK * LA + (kk + l4) * LA + wr + 16 * t + l15];
             }
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+            for (int t = 0; t < TN; ++t) {
+                bre[t] = b0[(kk + l4) * LB + wc + 16 * t + l15];
+                if (CX) bim[t] = b0[GK * LB + (kk + l4) * LB + wc + 16 * t + l15];
+            }
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj) {
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TN; ++tj) {
                     rr[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], are[ti], rr[ti][tj], 0, 0, 0);
                     if (CX) {
                         ii[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bim[tj], aim[ti], ii[ti][tj], 0, 0, 0);
@@ -141,13 +209,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(long long m, long long n, lon
                     }
                 }
         }
-        __syncthreads();
+        if (PIPE) buf ^= 1;
     }
     // D fragment of (AB)^T: D'[j][i], i = lane & 15, j = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+        for (int tj = 0; tj < TN; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long gr = row0 + wr + 16 * ti + l15;
@@ -175,11 +243,20 @@ __global__ void splitk_reduce(const T* __restrict__ W, long long cstride, int sp
     }
 }
 
-template <class T>
-int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, long long k, const T* A,
-                  long long lda, const T* B, long long ldb, T* C, long long ldc) {
-    if (m == 0 || n == 0) return QIL_OK;
-    const long long tiles = ((m + GT - 1) / GT) * ((n + GT - 1) / GT);
+template <class T, int BM, int BN, int WM, int WN, bool PIPE>
+int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T* A, long long a_rs,
+                long long a_ks, int conjA, const T* B, long long b_ks, long long b_cs, int conjB, T* C,
+                long long ldc) {
+    constexpr int NP = sizeof(T) == 16 ? 2 : 1;
+    constexpr size_t lds = (size_t)(PIPE ? 2 : 1) * NP * GK * ((BM + 2) + (BN + 2)) * sizeof(double);
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma<T, BM, BN, WM, WN, PIPE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
+    const long long tiles = tiles_m * tiles_n;
     // few output tiles + long K (projections Q^H P, sketches of skinny panels): split K over the chip
     int splits = 1;
     if (tiles < 128 && k >= 1024) splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / tiles), 64);
@@ -196,38 +273,46 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
         Cout = static_cast<T*>(wsp);
         ldo = m;
     }
-    const dim3 grid((unsigned)((m + GT - 1) / GT), (unsigned)((n + GT - 1) / GT), (unsigned)splits), block(256);
-#define QIL_GEMM_CASE(OA, OB)                                                                           \
-    if (opA == OA && opB == OB) {                                                                       \
-        hipLaunchKernelGGL((gemm_kernel<T, OA, OB>), grid, block, 0, ctx->stream, m, n, k, A, lda, B, ldb,    \
-                           Cout, ldo, kchunk, cstride);                                                 \
-        QIL_HIP(hipGetLastError());                                                                     \
-        if (splits > 1) {                                                                               \
-            hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 2048)), \
-                               dim3(256), 0, ctx->stream, (const T*)Cout, cstride, splits, m, n, C, ldc);  \
-            QIL_HIP(hipGetLastError());                                                                 \
-            qil_ctx_free(ctx, wsp);                                                                     \
-        }                                                                                               \
-        return QIL_OK;                                                                                  \
+    // narrow outputs: neighbouring workgroups share the same rows of A (served from L2 / Infinity Cache)
+    const int col_fastest = tiles_n <= 8 ? 1 : 0;
+    hipLaunchKernelGGL((gemm_mfma<T, BM, BN, WM, WN, PIPE>), dim3((unsigned)tiles, 1, (unsigned)splits), dim3(256), lds,
+                       ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo, kchunk, cstride,
+                       (int)tiles_m, (int)tiles_n, col_fastest);
+    QIL_HIP(hipGetLastError());
+    if (splits > 1) {
+        hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 2048)), dim3(256),
+                           0, ctx->stream, (const T*)Cout, cstride, splits, m, n, C, ldc);
+        QIL_HIP(hipGetLastError());
+        qil_ctx_free(ctx, wsp);
     }
-    QIL_GEMM_CASE(0, 0)
-    QIL_GEMM_CASE(0, 1)
-    QIL_GEMM_CASE(0, 2)
-    QIL_GEMM_CASE(1, 0)
-    QIL_GEMM_CASE(2, 0)
-    QIL_GEMM_CASE(1, 1)
-    QIL_GEMM_CASE(2, 2)
-    QIL_GEMM_CASE(1, 2)
-    QIL_GEMM_CASE(2, 1)
-    QIL_GEMM_CASE(3, 0)
-    QIL_GEMM_CASE(0, 3)
-    QIL_GEMM_CASE(3, 3)
-    QIL_GEMM_CASE(3, 1)
-    QIL_GEMM_CASE(3, 2)
-    QIL_GEMM_CASE(1, 3)
-    QIL_GEMM_CASE(2, 3)
-#undef QIL_GEMM_CASE
-    return qil_fail(QIL_EINVAL_ARG, "gemm: bad op codes %d, %d", opA, opB);
+    return QIL_OK;
+}
+
+template <class T>
+int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, long long k, const T* A,
+                  long long lda, const T* B, long long ldb, T* C, long long ldc) {
+    if (m == 0 || n == 0) return QIL_OK;
+    QIL_REQUIRE(opA >= 0 && opA <= 3 && opB >= 0 && opB <= 3, QIL_EINVAL_ARG, "gemm: bad op codes %d, %d", opA, opB);
+    // op(A)[r, kk] = A[r * a_rs + kk * a_ks];  op(B)[kk, c] = B[kk * b_ks + c * b_cs]
+    const bool at = opA == 1 || opA == 2, bt = opB == 1 || opB == 2;
+    const long long a_rs = at ? lda : 1, a_ks = at ? 1 : lda;
+    const long long b_ks = bt ? ldb : 1, b_cs = bt ? 1 : ldb;
+    const int cA = (opA == 2 || opA == 3) ? 1 : 0, cB = (opB == 2 || opB == 3) ? 1 : 0;
+    constexpr bool CX = sizeof(T) == 16;
+#define QIL_GEMM_GO(BM, BN, WM, WN, PIPE) \
+    return gemm_launch<T, BM, BN, WM, WN, PIPE>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc)
+    static const int force = getenv("QIL_GEMM_CFG") ? atoi(getenv("QIL_GEMM_CFG")) : -1;   // tuning aid
+    if constexpr (CX) {
+        if (force == 1) QIL_GEMM_GO(64, 64, 32, 32, true);
+        QIL_GEMM_GO(64, 64, 32, 32, false);
+    } else {
+        if (force == 0) QIL_GEMM_GO(64, 64, 32, 32, true);
+        if (force == 1) QIL_GEMM_GO(64, 64, 32, 32, false);
+        if (force == 3) QIL_GEMM_GO(128, 128, 64, 64, true);
+        if (m >= 256) QIL_GEMM_GO(128, 64, 64, 32, true);
+        QIL_GEMM_GO(64, 64, 32, 32, true);
+    }
+#undef QIL_GEMM_GO
 }
 
 // ------------------------------------------------------------------ block reductions
@@ -957,6 +1042,39 @@ extern "C" int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m
     QIL_TRY(qil_dev_gemm(ctx, dtype, opA, opB, m, n, k, dA, lda, dB, ldb, dC, ldc));
     QIL_HIP(hipMemcpyAsync(C, dC, (size_t)(ldc * n) * e, hipMemcpyDeviceToHost, ctx->stream));
     QIL_HIP(hipStreamSynchronize(ctx->stream));
+    qil_ctx_free(ctx, dA);
+    qil_ctx_free(ctx, dB);
+    qil_ctx_free(ctx, dC);
+    return QIL_OK;
+}
+
+// Device-resident timing of the GEMM (operands generated on the device, HIP events): ms per call.
+extern "C" int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+                                    int reps, double* ms_per_call) {
+    QIL_REQUIRE(ctx && ms_per_call && reps >= 1, QIL_EINVAL_ARG, "gemm_device_time: bad argument");
+    QIL_TRY(qil_ctx_activate(ctx));
+    const size_t e = qil_elem_size(dtype);
+    const int64_t a_rows = (opA == 0 || opA == 3) ? m : k, a_cols = (opA == 0 || opA == 3) ? k : m;
+    const int64_t b_rows = (opB == 0 || opB == 3) ? k : n, b_cols = (opB == 0 || opB == 3) ? n : k;
+    void *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(a_rows * a_cols) * e, &dA));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(b_rows * b_cols) * e, &dB));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dC));
+    QIL_TRY(qil_dev_fill_normal(ctx, dtype, dA, a_rows * a_cols, 11, 1.0));
+    QIL_TRY(qil_dev_fill_normal(ctx, dtype, dB, b_rows * b_cols, 12, 1.0));
+    QIL_TRY(qil_dev_gemm(ctx, dtype, opA, opB, m, n, k, dA, a_rows, dB, b_rows, dC, m));   // warm-up
+    hipEvent_t e0, e1;
+    QIL_HIP(hipEventCreate(&e0));
+    QIL_HIP(hipEventCreate(&e1));
+    QIL_HIP(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; ++r) QIL_TRY(qil_dev_gemm(ctx, dtype, opA, opB, m, n, k, dA, a_rows, dB, b_rows, dC, m));
+    QIL_HIP(hipEventRecord(e1, ctx->stream));
+    QIL_HIP(hipEventSynchronize(e1));
+    float f = 0;
+    QIL_HIP(hipEventElapsedTime(&f, e0, e1));
+    *ms_per_call = (double)f / reps;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
     qil_ctx_free(ctx, dA);
     qil_ctx_free(ctx, dB);
     qil_ctx_free(ctx, dC);

@@ -263,3 +263,13 @@ def gemm(A, B, opA="N", opB="N", ctx=None):
                            Af.shape[0], Bf.ctypes.data_as(C.c_void_p), Bf.shape[0],
                            Cm.ctypes.data_as(C.c_void_p), m))
     return Cm
+
+
+def gemm_device_time(m, n, k, dtype=np.float64, opA="N", opB="N", reps=10, ctx=None):
+    """ms per call of the device-resident MFMA GEMM (diagnostic)."""
+    ctx = ctx or default_context()
+    code = L.QIL_C64 if np.dtype(dtype) == np.complex128 else L.QIL_F64
+    ms = C.c_double()
+    L.check(L.lib.qil_gemm_device_time(ctx.handle, code, _OPS[opA], _OPS[opB], int(m), int(n), int(k),
+                                       int(reps), C.byref(ms)))
+    return ms.value

@@ -66,18 +66,18 @@ def main():
         apply_case("apply_qft_n20_chi1024_D8", 20, 1024, 8, False, 0.628, "apply(W_qft, psi) :random n=20")
         apply_case("apply_qft_n20_chi32_D64_cfg2", 20, 32, 64, False, None, "BASELINE.json configs[1]")
     if "gemm" in which:
-        rng = np.random.default_rng(0)
-        for (m, n, k, dt) in ((4096, 64, 4096, np.float64), (32768, 136, 32768 // 8, np.float64),
-                              (2048, 2048, 2048, np.float64), (2048, 2048, 2048, np.complex128)):
-            A = rng.standard_normal((m, k)).astype(dt)
-            B = rng.standard_normal((k, n)).astype(dt)
-            import ctypes as C
-            L_ = __import__("qilaplace_jl_amd._lib", fromlist=["lib"])
-            # device-resident timing through the MPS norm path is indirect; time the host hook minus copies
-            t0 = time.perf_counter(); qil.gemm(A, B); t1 = time.perf_counter() - t0
+        # device-resident f64-MFMA GEMM rates (peak f64 matrix rate of MI355X: 78.6 TFLOP/s spec)
+        for (m, n, k, dt, oa, ob, note) in (
+                (4096, 4096, 4096, np.float64, "N", "N", "square"),
+                (4096, 4096, 4096, np.complex128, "N", "N", "square complex"),
+                (64, 16384, 8192, np.complex128, "N", "N", "coefficient_batch bulk site at cfg3 (64 queries)"),
+                (4096, 55, 4096, np.float64, "T", "N", "rsvd sketch Y = M Omega, n=24 k=50"),
+                (32768, 133, 32768, np.float64, "T", "N", "rsvd sketch, n=30 k=128"),
+                (32768, 133, 32768, np.float64, "C", "N", "rsvd power iteration M^H Q, n=30")):
+            ms = qil.gemm_device_time(m, n, k, dt, oa, ob, reps=5)
             fl = (8 if dt == np.complex128 else 2) * m * n * k
-            emit(case="gemm_host_hook", m=m, n=n, k=k, dtype=str(np.dtype(dt)), seconds_incl_pcie=t1,
-                 gflops_incl_pcie=fl / t1 / 1e9)
+            emit(case="gemm_device", m=m, n=n, k=k, dtype=str(np.dtype(dt)), opA=oa, opB=ob, note=note, ms=ms,
+                 tflops=fl / ms / 1e9, frac_of_f64_mfma_peak=fl / ms / 1e9 / 78.6)
     if "encode" in which:
         rng = np.random.default_rng(3)
         for n, kk in ((16, 50), (20, 50), (24, 50)):
