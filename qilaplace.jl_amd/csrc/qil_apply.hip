@@ -81,14 +81,18 @@ __device__ __forceinline__ c64 mad2(c64 w0, c64 a0, c64 w1, c64 a1) {
     return c64{re, im};
 }
 
-__device__ __forceinline__ void store_out(double* p, double v) { __builtin_nontemporal_store(v, p); }
+template <bool NT>
+__device__ __forceinline__ void store_out(double* p, double v) {
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NT>
 __device__ __forceinline__ void store_out(c64* p, c64 v) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     d2 t = {v.re, v.im};
-    __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p));
+    if (NT) __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p)); else *reinterpret_cast<d2*>(p) = t;
 }
 
-template <class TW, class TA>
+template <class TW, class TA, bool NT, int NBV>
 __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __restrict__ sites, int nsites) {
     using TO = typename out_type<TW, TA>::type;
     // ---- block -> site (wave-uniform binary search over the prefix table)
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __r
     const int alpha = (int)(r - (long long)a * S.cl);
     const int beta0 = beta_tile * kTB;
     const int nbeta = min(kTB, S.cr - beta0);
-    const int b0 = b_chunk * kNB;
-    const int b1 = min(b0 + kNB, S.Dr);
+    const int b0 = b_chunk * NBV;
+    const int b1 = min(b0 + NBV, S.Dr);
 
     const TA* __restrict__ A = static_cast<const TA*>(S.A);
     const TW* __restrict__ W = static_cast<const TW*>(S.W);
@@ -145,16 +149,16 @@ __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __r
         if (nbeta == kTB) {
 #pragma unroll
             for (int t = 0; t < kTB; ++t) {
-                store_out(bp, mad2(w00, A0[t], w10, A1[t]));
-                store_out(bp + R, mad2(w01, A0[t], w11, A1[t]));
+                store_out<NT>(bp, mad2(w00, A0[t], w10, A1[t]));
+                store_out<NT>(bp + R, mad2(w01, A0[t], w11, A1[t]));
                 bp += 2 * R;
             }
         } else {
 #pragma unroll
             for (int t = 0; t < kTB; ++t) {
                 if (t < nbeta) {
-                    store_out(bp, mad2(w00, A0[t], w10, A1[t]));
-                    store_out(bp + R, mad2(w01, A0[t], w11, A1[t]));
+                    store_out<NT>(bp, mad2(w00, A0[t], w10, A1[t]));
+                    store_out<NT>(bp + R, mad2(w01, A0[t], w11, A1[t]));
                 }
                 bp += 2 * R;
             }
@@ -216,6 +220,10 @@ int check_apply_operands(const qil_mpo* W, const qil_mps* psi) {
 int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
     qil_context* ctx = W->ctx;
     const int64_t n = W->n();
+    // tuning aid: QIL_APPLY_VARIANT = 0 (default: non-temporal stores, 16 b per workgroup), 1 (plain
+    // stores), 2 (NT, 32 b), 3 (NT, 8 b)
+    static const int variant = getenv("QIL_APPLY_VARIANT") ? atoi(getenv("QIL_APPLY_VARIANT")) : 0;
+    const int nbv = variant == 2 ? 32 : variant == 3 ? 8 : kNB;
     std::vector<ApplySite> tab((size_t)n);
     long long blocks = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -230,7 +238,7 @@ int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
         s.R = (long long)s.Dl * s.cl;
         s.row_tiles = (int)((s.R + kRows - 1) / kRows);
         s.beta_tiles = (s.cr + kTB - 1) / kTB;
-        s.b_chunks = (s.Dr + kNB - 1) / kNB;
+        s.b_chunks = (s.Dr + nbv - 1) / nbv;
         s.pad = 0;
         s.block_begin = blocks;
         blocks += (long long)s.row_tiles * s.beta_tiles * s.b_chunks;
@@ -246,14 +254,22 @@ int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
     const ApplySite* dtab = static_cast<const ApplySite*>(dev);
     const dim3 grid((unsigned)blocks), block(kRows);
     const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;
-    if (wc && ac)
-        hipLaunchKernelGGL((site_apply_grouped<c64, c64>), grid, block, 0, ctx->stream, dtab, (int)n);
-    else if (wc)
-        hipLaunchKernelGGL((site_apply_grouped<c64, double>), grid, block, 0, ctx->stream, dtab, (int)n);
-    else if (ac)
-        hipLaunchKernelGGL((site_apply_grouped<double, c64>), grid, block, 0, ctx->stream, dtab, (int)n);
-    else
-        hipLaunchKernelGGL((site_apply_grouped<double, double>), grid, block, 0, ctx->stream, dtab, (int)n);
+#define QIL_APPLY_LAUNCH(TW, TA)                                                                              \
+    do {                                                                                                      \
+        if (variant == 1)                                                                                     \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, false, 16>), grid, block, 0, ctx->stream, dtab, (int)n); \
+        else if (variant == 2)                                                                                \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 32>), grid, block, 0, ctx->stream, dtab, (int)n);  \
+        else if (variant == 3)                                                                                \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 8>), grid, block, 0, ctx->stream, dtab, (int)n);   \
+        else                                                                                                  \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16>), grid, block, 0, ctx->stream, dtab, (int)n);  \
+    } while (0)
+    if (wc && ac) QIL_APPLY_LAUNCH(c64, c64);
+    else if (wc) QIL_APPLY_LAUNCH(c64, double);
+    else if (ac) QIL_APPLY_LAUNCH(double, c64);
+    else QIL_APPLY_LAUNCH(double, double);
+#undef QIL_APPLY_LAUNCH
     QIL_HIP(hipGetLastError());
     QIL_TRY(qil_ctx_prof_end(ctx));
     return qil_ctx_desc_commit(ctx, slot);
