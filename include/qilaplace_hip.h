@@ -157,6 +157,11 @@ int qil_apply_mpo_mpo(const qil_mpo* W1, const qil_mpo* W2, qil_mpo** out);
  * out: host, nb complex doubles (re, im) = amplitude * prod_i A_i[:, bit_i, :].
  * Errors: QIL_EINVAL_CONFIG for a bit outside [0,1] (mps.jl:612).                  */
 int qil_coefficient_batch(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out);
+/* Same with bit value 2 allowed = "sum over this site's physical index" (marginal / partial trace with
+ * the all-ones vector).  Serves the coefficient-grid and Laplace-value scans of the tutorials
+ * (docs/src/tutorials/dt.jl:187-197 sums N coefficient calls per value; zt.jl:283-309 scans 256 x 256
+ * grids) with one chain per value instead of N. */
+int qil_coefficient_marginal_batch(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out);
 /* <bits| W psi> without materialising W*psi (same numbers as
  * qil_coefficient_batch(qil_apply(W, psi))).                                      */
 int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi, int64_t nb,

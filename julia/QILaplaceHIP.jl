@@ -134,6 +134,15 @@ function coefficient(psi::DeviceMPS, bits::AbstractMatrix{<:Integer})          #
                 psi.h, nb, b, out))
     return out
 end
+# marginals: an entry of 2 sums that site's physical index (one chain instead of 2^m coefficient calls)
+function marginal(psi::DeviceMPS, bits::AbstractMatrix{<:Integer})
+    nb, n = size(bits)
+    b = Matrix{UInt8}(permutedims(bits))
+    out = Vector{ComplexF64}(undef, nb)
+    check(ccall((:qil_coefficient_marginal_batch, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cdouble}),
+                psi.h, nb, b, out))
+    return out
+end
 coefficient(psi::DeviceMPS, cfg::AbstractVector{<:Integer}) = coefficient(psi, reshape(collect(cfg), 1, :))[1]
 coefficient(psi::DeviceMPS, cfg::Tuple{Vararg{Integer}}) = coefficient(psi, collect(cfg))
 coefficient(psi::DeviceMPS, cfg::Vararg{Integer}) = coefficient(psi, collect(cfg))

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "qil_apply_into": [_vp, _vp, _vp],
     "qil_apply_mpo_mpo": [_vp, _vp, _pvp],
     "qil_coefficient_batch": [_vp, _i64, _pu8, _pdbl],
+    "qil_coefficient_marginal_batch": [_vp, _i64, _pu8, _pdbl],
     "qil_apply_coefficient_batch": [_vp, _vp, _i64, _pu8, _pdbl],
     "qil_mps_to_vector": [_vp, _int, _vp],
     "qil_norm": [_vp, _pdbl],

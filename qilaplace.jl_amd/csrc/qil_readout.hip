@@ -72,7 +72,9 @@ __global__ __launch_bounds__(kThreads) void coefficient_chain(const ChainSite* _
     for (int i = 0; i < n; ++i) {
         const ChainSite S = sites[i];
         const int bit = bits[q * n + i];
-        const T* __restrict__ M = static_cast<const T*>(S.A) + (long long)S.cl * bit;
+        // bit == 2: the site's physical index is summed (marginal): v' = v (A[:,0,:] + A[:,1,:])
+        const bool both = bit == 2;
+        const T* __restrict__ M = static_cast<const T*>(S.A) + (long long)S.cl * (both ? 0 : bit);
         int G = 64;  // lanes per dot product: smallest power of two >= cl (cap 64)
         while (G > 1 && (G >> 1) >= S.cl) G >>= 1;
         const int per_wave = 64 / G;
@@ -80,7 +82,10 @@ __global__ __launch_bounds__(kThreads) void coefficient_chain(const ChainSite* _
         for (int beta = wave * per_wave + grp; beta < S.cr; beta += nwaves * per_wave) {
             const T* col = M + 2LL * S.cl * beta;
             T acc{};
-            for (int al = gl; al < S.cl; al += G) acc = cmul_add(acc, v_in[al], col[al]);
+            if (both)
+                for (int al = gl; al < S.cl; al += G) acc = cmul_add(acc, v_in[al], add_t(col[al], col[al + S.cl]));
+            else
+                for (int al = gl; al < S.cl; al += G) acc = cmul_add(acc, v_in[al], col[al]);
             for (int m = G >> 1; m >= 1; m >>= 1) acc = add_t(acc, shfl_xor_t(acc, m));
             if (gl == 0) v_out[beta] = acc;
         }
@@ -184,7 +189,9 @@ __global__ void select_slice(const T* __restrict__ Tm, long long nb, int cr, con
          t += (long long)gridDim.x * blockDim.x) {
         const long long q = t % nb;
         const long long beta = t / nb;
-        Vn[t] = Tm[q + nb * (bits[q * n + site] + 2 * beta)];
+        const int bit = bits[q * n + site];
+        Vn[t] = bit == 2 ? add_t(Tm[q + nb * (2 * beta)], Tm[q + nb * (1 + 2 * beta)])
+                         : Tm[q + nb * (bit + 2 * beta)];
     }
 }
 
@@ -210,9 +217,10 @@ __global__ void scale_real(double* p, long long n, double s) {
         p[t] *= s;
 }
 
-int upload_bits(qil_context* ctx, int64_t nb, int64_t n, const uint8_t* bits, uint8_t** dbits) {
+int upload_bits(qil_context* ctx, int64_t nb, int64_t n, const uint8_t* bits, uint8_t** dbits, int max_bit = 1) {
     for (int64_t t = 0; t < nb * n; ++t)
-        QIL_REQUIRE(bits[t] <= 1, QIL_EINVAL_CONFIG, "coefficient: bit value %d outside [0,1]", (int)bits[t]);
+        QIL_REQUIRE(bits[t] <= max_bit, QIL_EINVAL_CONFIG, "coefficient: bit value %d outside [0,%d]", (int)bits[t],
+                    max_bit);
     void* p = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nb * n), &p));
     hipError_t e = hipMemcpyAsync(p, bits, (size_t)(nb * n), hipMemcpyHostToDevice, ctx->stream);
@@ -227,7 +235,20 @@ int upload_bits(qil_context* ctx, int64_t nb, int64_t n, const uint8_t* bits, ui
 
 }  // namespace
 
+static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out, int max_bit);
+
 extern "C" int qil_coefficient_batch(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out) {
+    return coefficient_impl(psi, nb, bits, out, 1);
+}
+
+// Marginals: bit value 2 sums the site's physical index (a partial trace with the all-ones vector), so
+// e.g. a Laplace value L(s_k) = dt sqrt(N) sum_j <k, j | psi>  (docs/src/tutorials/dt.jl:187-197: N
+// coefficient calls per value) is ONE chain with every copy-site bit set to 2.
+extern "C" int qil_coefficient_marginal_batch(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out) {
+    return coefficient_impl(psi, nb, bits, out, 2);
+}
+
+static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out, int max_bit) {
     QIL_REQUIRE(psi && (nb == 0 || (bits && out)), QIL_EINVAL_ARG, "coefficient: null argument");
     if (nb == 0) return QIL_OK;
     qil_context* ctx = psi->ctx;
@@ -241,7 +262,7 @@ extern "C" int qil_coefficient_batch(const qil_mps* psi, int64_t nb, const uint8
         maxchi = std::max<long long>(maxchi, psi->dims[(size_t)i + 1]);
     }
     uint8_t* dbits = nullptr;
-    QIL_TRY(upload_bits(ctx, nb, n, bits, &dbits));
+    QIL_TRY(upload_bits(ctx, nb, n, bits, &dbits, max_bit));
     const size_t esz = qil_elem_size(psi->dtype);
     if (maxchi >= 512 && nb >= 4) {
         // Large bonds: all queries advance together, one f64-MFMA GEMM per site.  The site tensor is

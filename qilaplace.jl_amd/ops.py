@@ -86,15 +86,15 @@ def _ntensors(psi):
     return psi.ntensors if isinstance(psi, (ZTMPS, PairedSiteMPO)) else len(psi)
 
 
-def _bits_array(psi, bits):
+def _bits_array(psi, bits, max_bit=1):
     n = _ntensors(psi)
     b = np.asarray(bits)
     if b.ndim != 2 or b.shape[1] != n:
         got = b.shape[1] if b.ndim == 2 else b.shape
         raise ValueError(f"coefficient: expected {n} entries, got {got}")
-    if b.size and (b.min() < 0 or b.max() > 1):
-        bad = int(b[(b < 0) | (b > 1)][0])
-        raise ValueError(f"coefficient: bit value {bad} outside [0,1]")
+    if b.size and (b.min() < 0 or b.max() > max_bit):
+        bad = int(b[(b < 0) | (b > max_bit)][0])
+        raise ValueError(f"coefficient: bit value {bad} outside [0,{max_bit}]")
     return np.ascontiguousarray(b, dtype=np.uint8)
 
 
@@ -107,6 +107,55 @@ def coefficient_batch(psi, bits):
     L.check(L.lib.qil_coefficient_batch(psi.handle, nb, b.ctypes.data_as(C.POINTER(C.c_uint8)),
                                         out.ctypes.data_as(C.POINTER(C.c_double))))
     return out if psi.dtype == np.complex128 else out.real.copy()
+
+
+def marginal_batch(psi, bits):
+    """Like coefficient_batch, but a bit value of 2 SUMS that site's physical index (marginal).  One
+    chain then replaces 2^m coefficient calls when m sites are summed."""
+    b = _bits_array(psi, bits, max_bit=2)
+    nb = b.shape[0]
+    out = np.zeros(nb, dtype=np.complex128)
+    L.check(L.lib.qil_coefficient_marginal_batch(psi.handle, nb, b.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                 out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out if psi.dtype == np.complex128 else out.real.copy()
+
+
+def _lsb_bits(vals, n):
+    v = np.asarray(vals, dtype=np.int64)
+    return ((v[:, None] >> np.arange(n)[None, :]) & 1).astype(np.uint8)
+
+
+def _msb_bits(vals, n):
+    v = np.asarray(vals, dtype=np.int64)
+    return ((v[:, None] >> np.arange(n - 1, -1, -1)[None, :]) & 1).astype(np.uint8)
+
+
+def coefficient_grid(psi, ks, ls, chunk=1 << 16):
+    """chi[k, l] = coefficient(psi, interleave(lsb(k), lsb(l))) for a transformed ZTMPS (the (k, l) scans
+    of docs/src/tutorials/zt.jl:152-157, 283-309) -- all pairs in batched launches."""
+    n = len(psi)
+    ks, ls = np.asarray(ks, dtype=np.int64), np.asarray(ls, dtype=np.int64)
+    kb, lb = _lsb_bits(ks, n), _lsb_bits(ls, n)
+    out = np.empty((len(ks), len(ls)), dtype=np.complex128)
+    rows = max(1, chunk // max(len(ls), 1))
+    for r0 in range(0, len(ks), rows):
+        kk = kb[r0:r0 + rows]
+        bits = np.empty((len(kk), len(ls), 2 * n), dtype=np.uint8)
+        bits[:, :, 0::2] = kk[:, None, :]
+        bits[:, :, 1::2] = lb[None, :, :]
+        out[r0:r0 + rows] = np.asarray(coefficient_batch(psi, bits.reshape(-1, 2 * n))).reshape(len(kk), len(ls))
+    return out
+
+
+def laplace_values(psi_out, ks, dt):
+    """L(s_k) = dt sqrt(N) sum_j coefficient(psi_out, interleave(lsb(k), msb(j))) for a damping-transformed
+    ZTMPS (docs/src/tutorials/dt.jl:172-197).  The sum over the copy register is a marginal: one chain per
+    k instead of N coefficient calls."""
+    n = len(psi_out)
+    kb = _lsb_bits(ks, n)
+    bits = np.full((len(kb), 2 * n), 2, dtype=np.uint8)
+    bits[:, 0::2] = kb
+    return dt * np.sqrt(2.0 ** n) * marginal_batch(psi_out, bits)
 
 
 def coefficient(psi, config):

@@ -533,3 +533,49 @@ def test_coefficient_batched_gemm_path(qil, dt):
     ref = O.coefficient_batch(O.SignalMPS(a, amplitude=0.9), bits)
     assert rel(qil.coefficient_batch(psi, bits), ref) < 1e-12
     assert rel(qil.coefficient_batch(psi, bits[:3]), ref[:3]) < 1e-12        # nb < 4: chain kernel
+
+
+# ---------------------------------------------------------------- marginals / scans
+@pytest.mark.parametrize("big", [False, True])
+def test_marginal_batch_and_scans(qil, big):
+    rng = np.random.default_rng(51)
+    bonds = [2, 4, 600, 520, 4, 2] if big else [2, 4, 8, 8, 4, 2]
+    a = random_mps_data(bonds + ([2] if len(bonds) % 2 == 0 else []), rng, np.complex128)
+    L = len(a)
+    psi = qil.SignalMPS(a, amplitude=1.1)
+    bits = rng.integers(0, 3, size=(40, L))
+    got = qil.marginal_batch(psi, bits)
+    ones = np.array([1.0, 1.0])
+    ref = []
+    for row in bits:
+        v = np.ones((1,), dtype=np.complex128)
+        for i, b in enumerate(row):
+            M = a[i][:, 0, :] + a[i][:, 1, :] if b == 2 else a[i][:, b, :]
+            v = v @ M
+        ref.append(1.1 * v[0])
+    assert rel(got, np.array(ref)) < 1e-12
+    with pytest.raises(ValueError, match="outside"):
+        qil.marginal_batch(psi, np.full((1, L), 3))
+    with pytest.raises(ValueError, match="outside"):
+        qil.coefficient_batch(psi, np.full((1, L), 2))
+    del ones
+
+
+def test_laplace_values_and_grid_match_tutorial(qil, pins):
+    p = pins["dt_tutorial"]
+    n, dt, wr = p["n"], p["dt"], p["wr"]
+    N = 2 ** n
+    x = np.exp(-p["a"] * dt * np.arange(N))
+    psiz = qil.signal_ztmps(x, cutoff=1e-14, maxdim=64)
+    out = qil.build_dt_mpo(psiz, wr, cutoff=1e-14, maxdim=64) * psiz
+    Lv = qil.laplace_values(out, np.arange(N), dt)
+    assert abs(Lv[0] - p["L_s0"]) < 1e-13
+    assert np.abs(np.round(Lv.real, 5) - np.array(p["L_rounded5"])).max() < 1e-12
+    p = pins["zt_tutorial"]
+    n = p["n"]
+    N = 2 ** n
+    x = np.array([p["a"] ** j * np.cos(np.pi * p["w0_over_pi"] * j) for j in range(N)])
+    psiz = qil.signal_ztmps(x, cutoff=1e-14, maxdim=64)
+    chi = qil.coefficient_grid(qil.build_zt_mpo(psiz, 2 * np.pi, cutoff=1e-14, maxdim=64) * psiz, np.arange(N), np.arange(N))
+    assert np.abs(np.round(chi.real, 4) - np.array(p["chi_rounded4_re"])).max() < 1e-12
+    assert np.abs(np.round(chi.imag, 4) - np.array(p["chi_rounded4_im"])).max() < 1e-12
