@@ -199,6 +199,14 @@ int qil_rsvd(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, i
 int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, double cutoff,
                   int64_t maxdim, int64_t mindim, int64_t* rank, void* U, double* S, void* Vh);
 
+/* ------------------------------------------------------------------ transform producers (P2) */
+/* build_dt_mpo(n, wr; cutoff=1e-14, maxdim=1000) src/transforms/dt_transformer.jl:312-407 for a BATCH of
+ * damping values wr[0..nb): all chains are built together on the device (one workgroup per damping value
+ * per step).  out[nb] receives PairedSiteMPO handles (f64, 2n tensors, site ids 1..2n); the batch shares one
+ * bond profile (each MPO is zero-padded to the batch maximum -- same operator).  maxdim <= 0: no cap.      */
+int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff,
+                           int64_t maxdim, qil_mpo** out);
+
 /* C (m x n) = opA(A) * opB(B) on host operands, column-major; op: 0 = N, 1 = T, 2 = H, 3 = conj.
  * The f64-MFMA GEMM every contraction of the truncation/encode path goes through (the `*` of
  * mps.jl:930,947; rsvd.jl:79,89,93,98,114); exported as a utility and test hook.                */

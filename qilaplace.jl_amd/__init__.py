@@ -19,7 +19,7 @@ from .ops import (apply, coefficient, coefficient_batch, apply_coefficient_batch
                   mps_to_vector, norm, canonicalize, compress, signal_mps, signal_ztmps, rsvd,
                   svd_trunc, gemm, gemm_device_time)
 from .builders import (build_qft_mpo, build_dt_mpo, build_zt_mpo, qft_mpo_tensors,  # noqa: F401
-                       dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many)
+                       dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many, build_dt_mpo_batch)
 from .sweep import shard_items, sweep, damping_sweep, gather_results  # noqa: F401
 
 __all__ = [
@@ -28,7 +28,7 @@ __all__ = [
     "apply", "coefficient", "coefficient_batch", "apply_coefficient_batch", "marginal_batch", "coefficient_grid", "laplace_values", "mps_to_vector", "norm",
     "canonicalize", "compress", "signal_mps", "signal_ztmps", "rsvd", "svd_trunc", "gemm",
     "build_qft_mpo", "build_dt_mpo", "build_zt_mpo", "qft_mpo_tensors", "dt_mpo_tensors", "zt_mpo_tensors",
-    "dt_mpo_tensors_many",
+    "dt_mpo_tensors_many", "build_dt_mpo_batch",
     "shard_items", "sweep", "damping_sweep", "gather_results",
     "QilError", "QilDomainError",
 ]

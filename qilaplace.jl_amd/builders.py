@@ -310,3 +310,20 @@ def dt_mpo_tensors_many(n, wrs, cutoff=1e-14, maxdim=1000, workers=8):
     from concurrent.futures import ProcessPoolExecutor
     with ProcessPoolExecutor(max_workers=min(workers, len(jobs)), mp_context=mp.get_context("spawn")) as ex:
         return list(ex.map(_dt_worker, jobs))
+
+
+def build_dt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None):
+    """All damping values of a sweep built TOGETHER on the GPU (qil_build_dt_mpo_batch): one launch per
+    step with one workgroup per damping value, instead of one host chain per value.  Returns a list of
+    PairedSiteMPO handles sharing one (zero-padded) bond profile."""
+    import ctypes as C
+    from . import _lib as L
+    from .containers import default_context
+    psi = n_or_psi if hasattr(n_or_psi, "handle") else None
+    ctx = ctx or (psi.ctx if psi is not None else default_context())
+    n = _n_of(n_or_psi)
+    w = np.ascontiguousarray(np.asarray(list(wrs), dtype=np.float64))
+    outs = (C.c_void_p * len(w))()
+    L.check(L.lib.qil_build_dt_mpo_batch(ctx.handle, int(n), len(w), w.ctypes.data_as(C.POINTER(C.c_double)),
+                                         float(cutoff), -1 if maxdim is None else int(maxdim), outs))
+    return [PairedSiteMPO(ctx=ctx, _handle=C.c_void_p(h)) for h in outs]

@@ -12,31 +12,11 @@
 #include <numeric>
 
 #include "qil_internal.h"
+#include "qil_device_utils.h"
 
 namespace {
 
-struct c64 {
-    double re, im;
-};
-
-__device__ __forceinline__ double conj_t(double v) { return v; }
-__device__ __forceinline__ c64 conj_t(c64 v) { return c64{v.re, -v.im}; }
-__device__ __forceinline__ double fma_t(double a, double b, double acc) { return fma(a, b, acc); }
-__device__ __forceinline__ c64 fma_t(c64 a, c64 b, c64 acc) {
-    acc.re = fma(a.re, b.re, acc.re);
-    acc.re = fma(-a.im, b.im, acc.re);
-    acc.im = fma(a.re, b.im, acc.im);
-    acc.im = fma(a.im, b.re, acc.im);
-    return acc;
-}
-__device__ __forceinline__ double abs2_t(double v) { return v * v; }
-__device__ __forceinline__ double abs2_t(c64 v) { return v.re * v.re + v.im * v.im; }
-__device__ __forceinline__ double scale_t(double v, double s) { return v * s; }
-__device__ __forceinline__ c64 scale_t(c64 v, double s) { return c64{v.re * s, v.im * s}; }
-__device__ __forceinline__ double sub_t(double a, double b) { return a - b; }
-__device__ __forceinline__ c64 sub_t(c64 a, c64 b) { return c64{a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ double add_t(double a, double b) { return a + b; }
-__device__ __forceinline__ c64 add_t(c64 a, c64 b) { return c64{a.re + b.re, a.im + b.im}; }
+using namespace qil_dev;
 
 // ------------------------------------------------------------------ GEMM on the f64 matrix cores
 // C (m x n) = opA(A) * opB(B), f64 or c64, through v_mfma_f64_16x16x4_f64 (64-cycle issue per SIMD).
@@ -315,81 +295,7 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
 #undef QIL_GEMM_GO
 }
 
-// ------------------------------------------------------------------ block reductions
-// Cross-lane sums on the DPP path (no LDS crossbar): quad_perm butterflies inside each quad, then
-// row_half_mirror / row_mirror fold the 8- and 16-lane halves; every lane of a 16-lane row ends with the
-// row total.  A ds_bpermute-based __shfl_xor costs ~50+ cycles per step; a DPP move costs a VALU slot.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double v) {
-    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);  // row_half_mirror
-    v += dpp_mov<0x140>(v);  // row_mirror
-    return v;
-}
-__device__ __forceinline__ double read_lane_d(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    v = row16_sum(v);
-    return (read_lane_d(v, 0) + read_lane_d(v, 16)) + (read_lane_d(v, 32) + read_lane_d(v, 48));
-}
-template <int G>
-__device__ __forceinline__ double group_sum(double v) {
-    return G == 16 ? row16_sum(v) : wave_sum(v);
-}
-
-// sums `NV` doubles per thread across a 256-thread workgroup; result valid in all threads
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* NV * 4 */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
-    __syncthreads();
-    if (lane == 0)
-#pragma unroll
-        for (int i = 0; i < NV; ++i) lds[i * 4 + wave] = v[i];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = lds[i * 4 + 0] + lds[i * 4 + 1] + lds[i * 4 + 2] + lds[i * 4 + 3];
-}
-
 // ------------------------------------------------------------------ one-sided Jacobi SVD
-// One round of the round-robin tournament: workgroup i orthogonalises columns (p, q) of A
-// (m x n) and applies the same rotation to V (n x n).
-__device__ __forceinline__ void rotate_pair(double& x, double& y, double c, double s, double pr, double) {
-    // pr = sign(x.y): the rotation angle is computed for |gamma|
-    const double xn = c * x - s * pr * y, yn = s * pr * x + c * y;
-    x = xn;
-    y = yn;
-}
-__device__ __forceinline__ void rotate_pair(c64& x, c64& y, double c, double s, double pr, double pi) {
-    // x' = c x - s e^{-i phi} y ;  y' = s e^{i phi} x + c y,  e^{i phi} = pr + i pi
-    const c64 ey{pr * y.re + pi * y.im, pr * y.im - pi * y.re};  // e^{-i phi} y
-    const c64 ex{pr * x.re - pi * x.im, pr * x.im + pi * x.re};  // e^{ i phi} x
-    const c64 xn{c * x.re - s * ey.re, c * x.im - s * ey.im};
-    const c64 yn{s * ex.re + c * y.re, s * ex.im + c * y.im};
-    x = xn;
-    y = yn;
-}
-__device__ __forceinline__ void dot_parts(double x, double y, double& gr, double& gi) {
-    gr += x * y;
-    (void)gi;
-}
-__device__ __forceinline__ void dot_parts(c64 x, c64 y, double& gr, double& gi) {
-    // conj(x) * y
-    gr += x.re * y.re + x.im * y.im;
-    gi += x.re * y.im - x.im * y.re;
-}
-
 template <class T>
 __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long lda, long long m,
                                                     T* __restrict__ V, long long ldv, int n, int npad,
@@ -444,83 +350,6 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
     }
 }
 
-
-// Whole one-sided Jacobi SVD iteration in ONE launch of ONE 1024-thread workgroup: V = I, sweeps of the
-// round-robin tournament until no pair rotates, then the column norms.  Each wave owns whole column
-// pairs (lanes stride over rows, shuffle reductions), pairs of a round are disjoint, rounds are
-// separated by a workgroup barrier.  Used when the rotated side is small (<= 128 columns): there the
-// multi-launch form is bounded by ~(n-1) x sweeps kernel boundaries, not by work.  When A and V fit
-// the CU's 160 KiB LDS (LDS = true) they are staged there for the whole iteration, so every round
-// trip of the rotation is an LDS access instead of an L2 one.
-template <class T, int G>
-__device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ldv, int n, double tol,
-                                              int max_sweeps, int* s_rot) {
-    // a column pair is owned by a group of G lanes (16 = one DPP row, or the whole wave)
-    const int tid = threadIdx.x, lane = tid & (G - 1), wave = tid / G;
-    constexpr int NW = 1024 / G;
-    const int npad = n + (n & 1);
-    for (int sweep = 0; sweep < max_sweeps && n > 1; ++sweep) {
-        if (tid == 0) *s_rot = 0;
-        __syncthreads();
-        for (int round = 0; round < npad - 1; ++round) {
-            for (int i = wave; i < npad / 2; i += NW) {
-                int p, q;
-                if (i == 0) {
-                    p = npad - 1;
-                    q = round;
-                } else {
-                    p = (round + i) % (npad - 1);
-                    q = (round + npad - 1 - i) % (npad - 1);
-                }
-                if (p >= n || q >= n) continue;
-                if (p > q) {
-                    const int t = p;
-                    p = q;
-                    q = t;
-                }
-                T* ap = A + lda * p;
-                T* aq = A + lda * q;
-                double al = 0, be = 0, gr = 0, gi = 0;
-                for (int r = lane; r < m; r += G) {
-                    const T x = ap[r], y = aq[r];
-                    al += abs2_t(x);
-                    be += abs2_t(y);
-                    dot_parts(x, y, gr, gi);
-                }
-                al = group_sum<G>(al);
-                be = group_sum<G>(be);
-                gr = group_sum<G>(gr);
-                if (sizeof(T) == 16) gi = group_sum<G>(gi);
-                const double g = sqrt(gr * gr + gi * gi);
-                if (!(g > tol * sqrt(al * be)) || g == 0.0) continue;
-                if (lane == 0) *s_rot = 1;
-                const double zeta = (be - al) / (2.0 * g);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                const double pr = gr / g, pi = gi / g;
-                for (int r = lane; r < m; r += G) {
-                    T x = ap[r], y = aq[r];
-                    rotate_pair(x, y, c, sn, pr, pi);
-                    ap[r] = x;
-                    aq[r] = y;
-                }
-                T* vp = V + ldv * p;
-                T* vq = V + ldv * q;
-                for (int r = lane; r < n; r += G) {
-                    T x = vp[r], y = vq[r];
-                    rotate_pair(x, y, c, sn, pr, pi);
-                    vp[r] = x;
-                    vq[r] = y;
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-        const int any = *s_rot;
-        __syncthreads();
-        if (!any) break;
-    }
-}
 
 template <class T, bool LDS>
 __global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long long lda, int m,

@@ -579,3 +579,39 @@ def test_laplace_values_and_grid_match_tutorial(qil, pins):
     chi = qil.coefficient_grid(qil.build_zt_mpo(psiz, 2 * np.pi, cutoff=1e-14, maxdim=64) * psiz, np.arange(N), np.arange(N))
     assert np.abs(np.round(chi.real, 4) - np.array(p["chi_rounded4_re"])).max() < 1e-12
     assert np.abs(np.round(chi.imag, 4) - np.array(p["chi_rounded4_im"])).max() < 1e-12
+
+
+# ---------------------------------------------------------------- batched device DT builder
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5])
+def test_device_dt_builder_matches_host_operator(qil, n):
+    from helpers import dense_mpo
+    wrs = [0.0, 0.75, 1.0, 2.0, 5.0, 2 * np.pi]
+    Ws = qil.build_dt_mpo_batch(n, wrs)
+    assert len(Ws) == len(wrs)
+    for W, w in zip(Ws, wrs):
+        assert W.ntensors == 2 * n and W.paired and W.dtype == np.float64
+        ref = dense_mpo(O.build_dt_mpo(n, w).data)
+        assert np.abs(dense_mpo(W.to_host()) - ref).max() < 2e-7
+
+
+def test_device_dt_builder_bonds_and_transform(qil, pins):
+    want = pins["mpo_maxbond_n2_30"]["dt"]
+    for n in (6, 8, 10):
+        W = qil.build_dt_mpo_batch(n, [2 * np.pi], cutoff=1e-15, maxdim=None)[0]
+        assert max(W.bond_dims) == want[n - 2]
+    # batch padding keeps the operator: coefficients of W(sigma) psi against the closed form
+    n = 8
+    N = 2 ** n
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    psi = qil.signal_ztmps(x, cutoff=1e-14)
+    sig = np.linspace(0.25, 16.0, 9)
+    Ws = qil.build_dt_mpo_batch(psi, sig)
+    xh = x / np.linalg.norm(x)
+    ks = np.array([0, 1, 5, 77, 200])
+    for W, s_ in zip(Ws, sig):
+        out = qil.PairedSiteMPO(W.to_host(), sites=psi.site_ids) * psi
+        for k in ks:
+            bits = np.array([interleave(int_to_bits(int(k), n, "lsb"), int_to_bits(j, n)) for j in range(N)])
+            ref = psi.amplitude * xh * np.exp(-s_ * k * np.arange(N) / N) / np.sqrt(N)
+            # MPO cutoff 1e-14 => ~1e-7 per truncation (the reference's own DT bound is 1e-7 * max(1, ||.||))
+            assert np.abs(qil.coefficient_batch(out, bits) - ref).max() < 5e-7 * max(1.0, np.abs(ref).max())

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--sigmas", type=int, default=64)
     ap.add_argument("--samples", type=int, default=1024)
     ap.add_argument("--workers", type=int, default=32)
+    ap.add_argument("--host-build", action="store_true", help="build the MPOs with the host process pool instead of "
+                    "the batched device builder")
     args = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     dist = None
@@ -49,20 +51,25 @@ def main():
     sig = np.linspace(0.25, 16.0, args.sigmas)
     bits = np.random.default_rng(7).integers(0, 2, size=(args.samples, 2 * n)).astype(np.uint8)
     mine = qil.shard_items(len(sig), world, rank)
+    import torch  # noqa: F401  (kept out of the timed region)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    tensors = qil.dt_mpo_tensors_many(n, [sig[i] for i in mine], workers=args.workers)   # host, threaded
+    if args.host_build:
+        tensors = qil.dt_mpo_tensors_many(n, [sig[i] for i in mine], workers=args.workers)   # host process pool
+        mpos = [qil.PairedSiteMPO(W, sites=psi.site_ids, ctx=ctx) for W in tensors]
+    else:
+        mpos = qil.build_dt_mpo_batch(psi, [sig[i] for i in mine], ctx=ctx)                  # one device batch
+    ctx.synchronize()
     t_build = time.perf_counter() - t0
     t1 = time.perf_counter()
     local_res = {}
-    for i, W in zip(mine, tensors):
-        out = qil.PairedSiteMPO(W, sites=psi.site_ids, ctx=ctx) * psi
+    for i, W in zip(mine, mpos):
+        out = W * psi
         local_res[i] = qil.coefficient_batch(out, bits)
         del out
     ctx.synchronize()
     t_apply = time.perf_counter() - t1
-    import torch
     res = qil.gather_results(local_res, len(sig), args.samples, dist, f"cuda:{local}" if dist is not None else None)
     total = time.perf_counter() - t0
     if dist is not None:
@@ -81,7 +88,7 @@ def main():
             err = max(err, float(np.abs(res[r] - ref).max() / max(np.abs(x).max() / np.sqrt(N), 1e-300)))
         print(json.dumps({
             "case": "dt_sigma_sweep", "n": n, "sigmas": len(sig), "samples": args.samples, "n_gpus": world,
-            "mps_bonds_max": max(psi.bond_dims), "seconds_total": total, "seconds_build_host": t_build,
+            "mps_bonds_max": max(psi.bond_dims), "seconds_total": total, "seconds_build": t_build, "builder": "host-pool" if args.host_build else "device-batch",
             "seconds_apply_and_sample": t_apply, "seconds_encode": t_encode,
             "site_contractions_per_s": len(sig) * 2 * n / total,
             "site_contractions_per_s_apply_only": len(sig) * 2 * n / t_apply,
