@@ -415,28 +415,16 @@ extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps
     qil_context* ctx = psi->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
     const int dt = psi->dtype;
-    const size_t e = qil_elem_size(dt);
     const double cutoff = tol * tol / ((double)(N - 1) * sweeps);               // mps.jl:920
     QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, 1e-12, kNoCap));            // mps.jl:923
+    // The reference truncates the two-site tensor psi[j] psi[j+1] (mps.jl:929, :946).  In canonical gauge --
+    // which every step of the sweep maintains -- that tensor has the same singular values and the same kept
+    // subspace as the single site next to the orthogonality centre (its neighbour is an isometry), so each
+    // sweep is run as a truncating gauge sweep on one-site matrices: (2 chi_l x chi) instead of
+    // (2 chi_l x 2 chi_r), no theta product, and the Jacobi SVD rotates half as many columns.
     for (int sw = 0; sw < sweeps; ++sw) {
-        for (int pass = 0; pass < 2; ++pass) {
-            // pass 0: L -> R keeping U | S V (mps.jl:927-942); pass 1: R -> L keeping U S | V (:944-959)
-            for (int64_t t = 0; t < N - 1; ++t) {
-                const int64_t j = pass == 0 ? t : N - 2 - t;
-                const int64_t cl = psi->dims[(size_t)j], c = psi->dims[(size_t)j + 1], cr = psi->dims[(size_t)j + 2];
-                void* theta = nullptr;
-                QIL_TRY(qil_ctx_alloc(ctx, (size_t)(4 * cl * cr) * e, &theta));
-                QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, 2 * cl, 2 * cr, c, psi->site[(size_t)j], 2 * cl,
-                                     psi->site[(size_t)j + 1], c, theta, 2 * cl));
-                int64_t r = 0;
-                void *U = nullptr, *Vh = nullptr;
-                QIL_TRY(svd_trunc_dev(ctx, dt, 2 * cl, 2 * cr, theta, 2 * cl, cutoff, true, maxdim, 1,
-                                      pass == 0 ? 2 : 1, &r, &U, &Vh, nullptr));
-                qil_ctx_free(ctx, theta);
-                QIL_TRY(qil_chain_set_site(psi, j, U, cl, r));
-                QIL_TRY(qil_chain_set_site(psi, j + 1, Vh, r, cr));
-            }
-        }
+        QIL_TRY(canonicalize_impl(psi, QIL_DIR_RIGHT, 0, cutoff, maxdim));      // L -> R: U | S V   (mps.jl:927-942)
+        QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, cutoff, maxdim));       // R -> L: U S | V   (mps.jl:944-959)
     }
     QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, 1e-12, kNoCap));            // mps.jl:963
     double nrm = 0;
