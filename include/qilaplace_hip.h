@@ -178,6 +178,14 @@ int qil_canonicalize(qil_mps* psi, int direction, int64_t center, double cutoff,
 /* compress!(psi; maxdim, tol=1e-12, sweeps=1) src/mps.jl:913-999.  In place.        */
 int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps);
 
+/* Fused apply-and-truncate: the result of compress!(apply(W, psi); maxdim, tol, sweeps)
+ * (apply.jl:75-122 followed by mps.jl:913-973) without materialising the (D chi)^2 product: a zip-up sweep
+ * with intermediate bond cap zip_maxdim (<= 0: 2 maxdim) followed by the exact-gauge compress!.  Same error
+ * codes as qil_apply / qil_compress.  Not a reference entry point (the reference's apply ignores its
+ * cutoff/maxdim kwargs); qil_apply keeps that behaviour.                                                  */
+int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
+                       int64_t zip_maxdim, qil_mps** out);
+
 /* ------------------------------------------------------------------ encode (E1-E4) */
 /* signal_mps(x; method, cutoff, maxdim, k, p, q, random_seed, mindim)
  * src/signals/SignalConverters.jl:228-233.  x: host, len values of `dtype`.        */

@@ -395,6 +395,76 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
     return QIL_OK;
 }
 
+
+// ---------------------------------------------------------------- fused apply-and-truncate (zip-up) kernels
+__device__ __forceinline__ c64 zmul(c64 a, c64 b) { return c64{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ c64 zmul(c64 a, double b) { return c64{a.re * b, a.im * b}; }
+__device__ __forceinline__ double zmul(double a, double b) { return a * b; }
+__device__ __forceinline__ c64 zadd(c64 a, c64 b) { return c64{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ double zadd(double a, double b) { return a + b; }
+
+// X[r, a, s', beta] = sum_alpha Rm[r, alpha, a] * A[alpha, s', beta]      (Rm index: r + R*(alpha + cl*a))
+template <class TO, class TA>
+__global__ void zip_stage1(const TO* __restrict__ Rm, const TA* __restrict__ A, TO* __restrict__ X, int R, int Dl,
+                           int cl, int cr) {
+    const long long total = (long long)R * Dl * 2 * cr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        long long u = t;
+        const int r = (int)(u % R);
+        u /= R;
+        const int a = (int)(u % Dl);
+        u /= Dl;
+        const int sp = (int)(u & 1);
+        const int beta = (int)(u >> 1);
+        const TO* rp = Rm + r + (long long)R * cl * a;
+        const TA* ap = A + (long long)cl * (sp + 2LL * beta);
+        TO acc{};
+        for (int al = 0; al < cl; ++al) acc = zadd(acc, zmul(rp[(long long)R * al], ap[al]));
+        X[t] = acc;
+    }
+}
+
+// theta[(r, s), (beta, b)] = sum_{a, s'} X[r, a, s', beta] * W[a, s', s, b]
+template <class TO, class TW>
+__global__ void zip_stage2(const TO* __restrict__ X, const TW* __restrict__ W, TO* __restrict__ theta, int R, int Dl,
+                           int Dr, int cr) {
+    const long long total = (long long)R * 2 * cr * Dr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        long long u = t;
+        const int r = (int)(u % R);
+        u /= R;
+        const int s_ = (int)(u & 1);
+        u >>= 1;
+        const int beta = (int)(u % cr);
+        const int b = (int)(u / cr);
+        TO acc{};
+        for (int sp = 0; sp < 2; ++sp) {
+            const TO* xp = X + r + (long long)R * Dl * (sp + 2LL * beta);            // + R * a
+            const TW* wp = W + (long long)Dl * (sp + 2 * (s_ + 2LL * b));            // + a
+            for (int a = 0; a < Dl; ++a) acc = zadd(acc, zmul(xp[(long long)R * a], wp[a]));
+        }
+        theta[t] = acc;
+    }
+}
+
+template <class TO, class TW, class TA>
+int zip_theta(qil_context* ctx, const void* Rm, const void* W, const void* A, int R, int Dl, int Dr, int cl, int cr,
+              void** theta_out) {
+    void *X = nullptr, *th = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)R * Dl * 2 * cr * sizeof(TO), &X));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)R * 2 * cr * Dr * sizeof(TO), &th));
+    hipLaunchKernelGGL((zip_stage1<TO, TA>), dim3(nblk((long long)R * Dl * 2 * cr)), dim3(256), 0, ctx->stream,
+                       (const TO*)Rm, (const TA*)A, (TO*)X, R, Dl, cl, cr);
+    hipLaunchKernelGGL((zip_stage2<TO, TW>), dim3(nblk((long long)R * 2 * cr * Dr)), dim3(256), 0, ctx->stream,
+                       (const TO*)X, (const TW*)W, (TO*)th, R, Dl, Dr, cr);
+    QIL_HIP(hipGetLastError());
+    qil_ctx_free(ctx, X);
+    *theta_out = th;
+    return QIL_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- exported
@@ -405,6 +475,101 @@ extern "C" int qil_canonicalize(qil_mps* psi, int direction, int64_t center, dou
     QIL_TRY(qil_ctx_activate(psi->ctx));
     // the ZTMPS method forwards `center` unchanged to the 2n-site chain (mps.jl:880-881)
     return canonicalize_impl(psi, direction, center, cutoff, maxdim);
+}
+
+extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps);
+
+// Fused apply-and-truncate ("zip-up"): compress!(apply(W, psi); maxdim, tol, sweeps) WITHOUT
+// ever writing the (D chi)^2 product tensors.  psi is brought to right-canonical gauge (a copy), then one
+// left-to-right sweep carries a remainder R[r, alpha, a] and per site forms only
+//     theta[(r, s), (beta, b)] = sum R[r, alpha, a] W[a, s', s, b] A[alpha, s', beta]      (2 r x D chi)
+// whose truncated SVD gives the output site (U) and the next remainder (S V^h).  The intermediate bond cap
+// zip_maxdim (default 2 maxdim) and a 100x tighter cutoff leave head-room for the final, exact-gauge
+// compress! (src/mps.jl:913-973) that fixes the reference's post-conditions (bonds <= maxdim, unit norm in
+// the tensors, norm moved into `amplitude`).  Cost O(n r D chi (D + chi)) instead of O(n (D chi)^2 ...).
+extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
+                                  int64_t zip_maxdim, qil_mps** out) {
+    QIL_REQUIRE(W && psi && out, QIL_EINVAL_ARG, "apply_compress: null argument");
+    QIL_REQUIRE(W->ctx == psi->ctx, QIL_EINVAL_ARG, "apply: MPO and MPS belong to different contexts");
+    QIL_REQUIRE(W->paired == psi->paired, QIL_EINVAL_ARG, "apply: cannot mix paired and single-register operands");
+    QIL_REQUIRE(W->n() == psi->n(), QIL_EINVAL_LENGTH,
+                "apply: MPO and MPS must have the same number of sites. Found length(W)=%lld, length(psi)=%lld",
+                (long long)W->n(), (long long)psi->n());
+    QIL_REQUIRE(W->site_ids == psi->site_ids, QIL_EINVAL_SITES, "apply: MPO and MPS must have the same site indices.");
+    const int64_t N = psi->n();
+    QIL_REQUIRE(N >= 2, QIL_EDOMAIN, "SignalMPS must have at least 2 sites.");
+    QIL_REQUIRE(sweeps >= 1, QIL_EINVAL_ARG, "compress!: sweeps must be >= 1");
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    if (maxdim <= 0) maxdim = kNoCap;
+    if (zip_maxdim <= 0) zip_maxdim = maxdim > kNoCap / 2 ? kNoCap : 2 * maxdim;
+    const double cutoff = tol * tol / ((double)(N - 1) * sweeps);
+    const double zip_cutoff = cutoff * 1e-2;
+    const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;
+    const int odt = (wc || ac) ? QIL_C64 : QIL_F64;
+    const size_t e = qil_elem_size(odt);
+    // right-canonical copy of psi: the zip's truncations then see (nearly) orthonormal environments
+    qil_mps* phi = nullptr;
+    QIL_TRY(qil_mps_clone(psi, &phi));
+    int st = canonicalize_impl(phi, QIL_DIR_LEFT, 0, 1e-14, kNoCap);
+    if (st != QIL_OK) {
+        qil_mps_destroy(phi);
+        return st;
+    }
+    qil_mps* res = new qil_mps();
+    res->ctx = ctx;
+    res->dtype = odt;
+    res->paired = psi->paired;
+    res->phys_rank = 1;
+    res->dims.assign((size_t)N + 1, 1);
+    res->site.assign((size_t)N, nullptr);
+    res->site_ids = psi->site_ids;
+    res->amplitude = psi->amplitude;
+    void* Rm = nullptr;
+    st = qil_ctx_alloc(ctx, e, &Rm);
+    const double one[2] = {1.0, 0.0};
+    if (st == QIL_OK && hipMemcpyAsync(Rm, one, e, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        st = qil_fail(QIL_EHIP, "apply_compress: upload failed");
+    if (st == QIL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = qil_fail(QIL_EHIP, "sync failed");
+    int R = 1;
+    for (int64_t i = 0; i < N && st == QIL_OK; ++i) {
+        const int Dl = (int)W->dims[(size_t)i], Dr = (int)W->dims[(size_t)i + 1];
+        const int cl = (int)phi->dims[(size_t)i], cr = (int)phi->dims[(size_t)i + 1];
+        void* theta = nullptr;
+        const void *Wp = W->site[(size_t)i], *Ap = phi->site[(size_t)i];
+        if (odt == QIL_F64) st = zip_theta<double, double, double>(ctx, Rm, Wp, Ap, R, Dl, Dr, cl, cr, &theta);
+        else if (wc && ac) st = zip_theta<c64, c64, c64>(ctx, Rm, Wp, Ap, R, Dl, Dr, cl, cr, &theta);
+        else if (wc) st = zip_theta<c64, c64, double>(ctx, Rm, Wp, Ap, R, Dl, Dr, cl, cr, &theta);
+        else st = zip_theta<c64, double, c64>(ctx, Rm, Wp, Ap, R, Dl, Dr, cl, cr, &theta);
+        if (st != QIL_OK) break;
+        qil_ctx_free(ctx, Rm);
+        Rm = nullptr;
+        if (i + 1 == N) {                       // last site: theta is (R, 2, 1)
+            res->site[(size_t)i] = theta;
+            res->dims[(size_t)i] = R;
+            break;
+        }
+        int64_t r = 0;
+        void *U = nullptr, *SV = nullptr;
+        st = svd_trunc_dev(ctx, odt, 2LL * R, (int64_t)cr * Dr, theta, 2LL * R, zip_cutoff, true, zip_maxdim, 1, 2, &r, &U,
+                           &SV, nullptr);
+        qil_ctx_free(ctx, theta);
+        if (st != QIL_OK) break;
+        res->site[(size_t)i] = U;               // [R, s, r]
+        res->dims[(size_t)i] = R;
+        res->dims[(size_t)i + 1] = r;
+        Rm = SV;                                // [r, (beta, b)] == R[r, alpha, a] of the next site
+        R = (int)r;
+    }
+    if (Rm) qil_ctx_free(ctx, Rm);
+    qil_mps_destroy(phi);
+    if (st == QIL_OK) st = qil_compress(res, maxdim, tol, sweeps);
+    if (st != QIL_OK) {
+        qil_mps_destroy(res);
+        return st;
+    }
+    *out = res;
+    return QIL_OK;
 }
 
 extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps) {

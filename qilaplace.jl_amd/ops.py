@@ -216,6 +216,18 @@ def compress(psi, maxdim=None, tol=1e-12, sweeps=1):
     return psi
 
 
+def apply_compress(W, psi, maxdim=None, tol=1e-12, sweeps=1, zip_maxdim=None):
+    """compress(apply(W, psi), maxdim, tol, sweeps) fused: a zip-up sweep that never writes the (D chi)^2
+    product tensors, then the exact-gauge compress.  (The reference's `apply` ignores cutoff/maxdim, and so
+    does `apply` here; this is the explicit truncating variant.)"""
+    if W.paired != psi.paired:
+        raise TypeError("apply: PairedSiteMPO acts on ZTMPS, SingleSiteMPO on SignalMPS")
+    h = C.c_void_p()
+    L.check(L.lib.qil_apply_compress(W.handle, psi.handle, _maxdim(maxdim), float(tol), int(sweeps),
+                                     0 if zip_maxdim is None else int(zip_maxdim), C.byref(h)))
+    return _wrap_like(psi, h)
+
+
 # ---------------------------------------------------------------- encode
 def _encode(fn, cls, x, method, cutoff, maxdim, k, p, q, random_seed, mindim, ctx):
     if method not in ("svd", "rsvd"):

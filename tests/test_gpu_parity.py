@@ -615,3 +615,37 @@ def test_device_dt_builder_bonds_and_transform(qil, pins):
             ref = psi.amplitude * xh * np.exp(-s_ * k * np.arange(N) / N) / np.sqrt(N)
             # MPO cutoff 1e-14 => ~1e-7 per truncation (the reference's own DT bound is 1e-7 * max(1, ||.||))
             assert np.abs(qil.coefficient_batch(out, bits) - ref).max() < 5e-7 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------- fused apply-and-truncate
+@pytest.mark.parametrize("wdt,adt", [(np.float64, np.float64), (np.complex128, np.float64), (np.complex128, np.complex128)])
+def test_apply_compress_lossless_equals_apply(qil, wdt, adt):
+    rng = np.random.default_rng(61)
+    L = 8
+    a = random_mps_data(saturated_profile(L, 4), rng, adt)
+    w = random_mpo_data(saturated_profile(L, 6, base=4), rng, wdt)
+    W, psi = qil.SingleSiteMPO(w), qil.SignalMPS(a, amplitude=1.3)
+    ref = qil.mps_to_vector(W * psi)
+    got = qil.apply_compress(W, psi, tol=1e-13)                  # no cap: nothing to lose (2^8 space)
+    assert rel(qil.mps_to_vector(got), ref) < 1e-10
+    assert abs(qil.norm(got) - 1.0) < 1e-10                       # compress! post-condition
+    with pytest.raises(ValueError, match="same number of sites"):
+        qil.apply_compress(qil.SingleSiteMPO.identity(3), psi)
+
+
+def test_apply_compress_matches_apply_then_compress(qil):
+    """A genuine transform at sizes where the product is large: QFT of a structured signal, n = 14."""
+    n = 14
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    psi = qil.signal_mps(x, cutoff=1e-12)
+    W = qil.build_qft_mpo(psi)
+    full = W * psi
+    ref_vec = qil.mps_to_vector(full)
+    slow = full.copy()
+    qil.compress(slow, maxdim=32, tol=1e-6)
+    fast = qil.apply_compress(W, psi, maxdim=32, tol=1e-6)
+    assert max(fast.bond_dims) <= 32
+    e_slow = np.linalg.norm(qil.mps_to_vector(slow) - ref_vec) / np.linalg.norm(ref_vec)
+    e_fast = np.linalg.norm(qil.mps_to_vector(fast) - ref_vec) / np.linalg.norm(ref_vec)
+    assert e_fast < 2e-6 and e_fast < 10 * max(e_slow, 1e-9)
+    assert abs(fast.amplitude - slow.amplitude) < 1e-6 * slow.amplitude
