@@ -686,57 +686,6 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
 }
 
 // ------------------------------------------------------------------ Gram-Schmidt QR (CGS2), positive diagonal
-// c[i] = Q[:, i]^H y   for i < j          (one workgroup per previous column)
-template <class T>
-__global__ __launch_bounds__(256) void gs_project(const T* __restrict__ Q, long long ldq, long long m,
-                                                  const T* __restrict__ y, T* __restrict__ c) {
-    __shared__ double red[8];
-    const T* qi = Q + ldq * blockIdx.x;
-    double v[2] = {0, 0};
-    for (long long r = threadIdx.x; r < m; r += 256) dot_parts(qi[r], y[r], v[0], v[1]);
-    block_sum<2>(v, red);
-    if (threadIdx.x == 0) {
-        T out{};
-        reinterpret_cast<double*>(&out)[0] = v[0];
-        if (sizeof(T) == 16) reinterpret_cast<double*>(&out)[1] = v[1];
-        c[blockIdx.x] = out;
-    }
-}
-
-// y -= Q[:, :j] c ;  racc[:j] += c     (one thread per row)
-template <class T>
-__global__ void gs_subtract(const T* __restrict__ Q, long long ldq, long long m, int j, T* __restrict__ y,
-                            const T* __restrict__ c, T* __restrict__ racc) {
-    const long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (r < m) {
-        T acc = y[r];
-        for (int i = 0; i < j; ++i) {
-            const T qc = fma_t(Q[r + ldq * i], c[i], T{});
-            acc = sub_t(acc, qc);
-        }
-        y[r] = acc;
-    }
-    if (racc && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < j; i += blockDim.x) racc[i] = add_t(racc[i], c[i]);
-}
-
-// y /= ||y|| ; rdiag = ||y||
-template <class T>
-__global__ __launch_bounds__(256) void gs_normalize(T* __restrict__ y, long long m, T* __restrict__ rdiag) {
-    __shared__ double red[4];
-    double v[1] = {0};
-    for (long long r = threadIdx.x; r < m; r += 256) v[0] += abs2_t(y[r]);
-    block_sum<1>(v, red);
-    const double nrm = sqrt(v[0]);
-    const double inv = nrm > 0 ? 1.0 / nrm : 0.0;
-    for (long long r = threadIdx.x; r < m; r += 256) y[r] = scale_t(y[r], inv);
-    if (rdiag && threadIdx.x == 0) {
-        T out{};
-        reinterpret_cast<double*>(&out)[0] = nrm;
-        *rdiag = out;
-    }
-}
-
 // R[0:k, j0:j0+b] += C (k x b)
 template <class T>
 __global__ void add_block(T* __restrict__ R, long long ldr, const T* __restrict__ C, long long ldc, int k,

@@ -397,7 +397,7 @@ def test_rsvd_low_rank_fixture(qil):                              # test_rsvd.jl
         qil.rsvd(np.zeros((0, 4)))
 
 
-@pytest.mark.parametrize("shape", [(40, 12), (12, 40), (33, 33)])
+@pytest.mark.parametrize("shape", [(40, 12), (12, 40), (33, 33), (300, 150), (200, 200), (130, 400), (2000, 24), (700, 260)])
 @pytest.mark.parametrize("dt", [np.float64, np.complex128])
 def test_svd_trunc_vs_lapack(qil, shape, dt):
     rng = np.random.default_rng(14)
@@ -405,8 +405,8 @@ def test_svd_trunc_vs_lapack(qil, shape, dt):
     if dt == np.complex128:
         A = A + 1j * rng.standard_normal(shape)
     U, S, Vh = qil.svd_trunc(A)
-    assert np.abs(S - np.linalg.svd(A, compute_uv=False)).max() < 1e-12
-    assert np.abs((U * S) @ Vh - A).max() < 1e-12
+    assert np.abs(S - np.linalg.svd(A, compute_uv=False)).max() < 1e-13 * S.max()
+    assert np.abs((U * S) @ Vh - A).max() < 1e-13 * S.max()
     assert np.abs(U.conj().T @ U - np.eye(len(S))).max() < 1e-12
     s = np.array([1.0, 1e-3, 1e-8, 0.0])
     Q1, _ = np.linalg.qr(rng.standard_normal((6, 4)))
