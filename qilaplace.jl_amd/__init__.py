@@ -20,6 +20,7 @@ from .ops import (apply, apply_compress, coefficient, coefficient_batch, apply_c
                   svd_trunc, gemm, gemm_device_time)
 from .builders import (build_qft_mpo, build_dt_mpo, build_zt_mpo, qft_mpo_tensors,  # noqa: F401
                        dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many, build_dt_mpo_batch)
+from .interchange import save, load  # noqa: F401
 from .sweep import shard_items, sweep, damping_sweep, gather_results  # noqa: F401
 
 __all__ = [
@@ -29,6 +30,7 @@ __all__ = [
     "canonicalize", "compress", "signal_mps", "signal_ztmps", "rsvd", "svd_trunc", "gemm",
     "build_qft_mpo", "build_dt_mpo", "build_zt_mpo", "qft_mpo_tensors", "dt_mpo_tensors", "zt_mpo_tensors",
     "dt_mpo_tensors_many", "build_dt_mpo_batch",
+    "save", "load",
     "shard_items", "sweep", "damping_sweep", "gather_results",
     "QilError", "QilDomainError",
 ]

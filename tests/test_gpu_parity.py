@@ -649,3 +649,19 @@ def test_apply_compress_matches_apply_then_compress(qil):
     e_fast = np.linalg.norm(qil.mps_to_vector(fast) - ref_vec) / np.linalg.norm(ref_vec)
     assert e_fast < 2e-6 and e_fast < 10 * max(e_slow, 1e-9)
     assert abs(fast.amplitude - slow.amplitude) < 1e-6 * slow.amplitude
+
+
+def test_npz_interchange_roundtrip(qil, tmp_path):
+    rng = np.random.default_rng(71)
+    psi = qil.ZTMPS(random_mps_data([2, 3, 2], rng, np.complex128), amplitude=0.4)
+    W = qil.SingleSiteMPO(random_mpo_data([3, 2], rng, np.float64), sites=[5, 6, 7])
+    for obj in (psi, W):
+        f = tmp_path / "obj.npz"
+        qil.save(f, obj)
+        back = qil.load(f)
+        assert type(back) is type(obj) and back.site_ids == obj.site_ids and back.bond_dims == obj.bond_dims
+        for a, b in zip(obj.to_host(), back.to_host()):
+            assert np.array_equal(a, b)
+    assert qil.load(tmp_path / "obj.npz").dtype == np.float64
+    qil.save(tmp_path / "p.npz", psi)
+    assert qil.load(tmp_path / "p.npz").amplitude == 0.4
