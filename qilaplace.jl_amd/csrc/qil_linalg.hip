@@ -289,6 +289,9 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
         if (force == 0) QIL_GEMM_GO(64, 64, 32, 32, true);
         if (force == 1) QIL_GEMM_GO(64, 64, 32, 32, false);
         if (force == 3) QIL_GEMM_GO(128, 128, 64, 64, true);
+        // 97..144 output columns (RSVD sketches with k + p = 133): one 144-wide tile reads A ONCE and pads
+        // 133 -> 144 columns instead of 192
+        if (m >= 256 && n > 96 && n <= 144) QIL_GEMM_GO(128, 144, 32, 144, true);
         if (m >= 256) QIL_GEMM_GO(128, 64, 64, 32, true);
         QIL_GEMM_GO(64, 64, 32, 32, true);
     }
