@@ -12,8 +12,9 @@
 //   * one lane owns one output ROW; for fixed (s, col) the rows are contiguous in memory, so
 //     every wave-level store is 64 x 16 B = 1 KiB contiguous (c64) -- full-line coalesced;
 //   * the lane keeps its A[alpha, :, beta-tile] values in registers for the whole block, and
-//     streams over the MPO bond b, so the only per-b loads are 4 MPO entries (L1/L2 hits,
-//     wave-broadcast when chi_l >= 64);
+//     streams over the MPO bond b; the workgroup's slab of the MPO site W[a_lo..a_hi, :, :, b-chunk]
+//     (<= 16 KiB) is staged in LDS once, so the inner loop reads 4 LDS entries (wave-broadcast when
+//     chi_l >= 64) and issues nothing but stores to global memory;
 //   * ALL sites of one apply are issued as ONE grouped launch (a device-side site table and a
 //     block -> (site, tile) map), so small-chi applies are not launch-bound and large ones
 //     keep > 2000 independent workgroups per site in flight over the 256 CUs.
@@ -92,7 +93,7 @@ __device__ __forceinline__ void store_out(c64* p, c64 v) {
     if (NT) __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p)); else *reinterpret_cast<d2*>(p) = t;
 }
 
-template <class TW, class TA, bool NT, int NBV>
+template <class TW, class TA, bool NT, int NBV, bool WLDS>
 __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __restrict__ sites, int nsites) {
     using TO = typename out_type<TW, TA>::type;
     // ---- block -> site (wave-uniform binary search over the prefix table)
@@ -110,8 +111,10 @@ __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __r
     const int beta_tile = (int)(local % S.beta_tiles);
     const int b_chunk = (int)(local / S.beta_tiles);
 
-    const long long r = (long long)row_tile * kRows + threadIdx.x;
-    if (r >= S.R) return;
+    const long long r_raw = (long long)row_tile * kRows + threadIdx.x;
+    const bool valid = r_raw < S.R;
+    if (!WLDS && !valid) return;
+    const long long r = valid ? r_raw : S.R - 1;   // WLDS: idle lanes stay for the barrier, clamped to a real row
     const int a = (int)(r / S.cl);
     const int alpha = (int)(r - (long long)a * S.cl);
     const int beta0 = beta_tile * kTB;
@@ -139,12 +142,37 @@ __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __r
 
     const long long R = S.R;
     const long long wstride = (long long)S.Dl;  // W[a, si, so, b]: a + Dl*(si + 2*(so + 2*b))
+    // ---- WLDS: stage this workgroup's slab of the MPO site, W[a_lo..a_hi, :, :, b0..b1), in LDS once
+    constexpr int kWCap = 16384 / (int)sizeof(TW);
+    __shared__ TW wtile[WLDS ? kWCap : 1];
+    const int a_lo = (int)(((long long)row_tile * kRows) / S.cl);
+    const int a_hi = (int)(min((long long)row_tile * kRows + kRows - 1, S.R - 1) / S.cl);
+    const int na = a_hi - a_lo + 1;
+    const bool staged = WLDS && na * 4 * (b1 - b0) <= kWCap;
+    if (WLDS) {
+        if (staged)
+            for (int idx = threadIdx.x; idx < na * 4 * (b1 - b0); idx += kRows) {
+                const int al = idx % na, q = (idx / na) & 3, bl = idx / (4 * na);
+                wtile[idx] = W[(a_lo + al) + wstride * (q + 4LL * (b0 + bl))];
+            }
+        __syncthreads();
+        if (!valid) return;
+    }
     for (int b = b0; b < b1; ++b) {
-        const TW* wp = W + a + wstride * (4LL * b);
-        const TW w00 = wp[0];                // s_in=0, s_out=0
-        const TW w10 = wp[wstride];          // s_in=1, s_out=0
-        const TW w01 = wp[2 * wstride];      // s_in=0, s_out=1
-        const TW w11 = wp[3 * wstride];      // s_in=1, s_out=1
+        TW w00, w10, w01, w11;
+        if (staged) {
+            const TW* wl = wtile + (a - a_lo) + na * 4 * (b - b0);
+            w00 = wl[0];
+            w10 = wl[na];
+            w01 = wl[2 * na];
+            w11 = wl[3 * na];
+        } else {
+            const TW* wp = W + a + wstride * (4LL * b);
+            w00 = wp[0];                     // s_in=0, s_out=0
+            w10 = wp[wstride];               // s_in=1, s_out=0
+            w01 = wp[2 * wstride];           // s_in=0, s_out=1
+            w11 = wp[3 * wstride];           // s_in=1, s_out=1
+        }
         TO* bp = B + r + R * (2LL * ((long long)beta0 + (long long)S.cr * b));
         if (nbeta == kTB) {
 #pragma unroll
@@ -220,10 +248,10 @@ int check_apply_operands(const qil_mpo* W, const qil_mps* psi) {
 int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
     qil_context* ctx = W->ctx;
     const int64_t n = W->n();
-    // tuning aid: QIL_APPLY_VARIANT = 0 (default: non-temporal stores, 16 b per workgroup), 1 (plain
-    // stores), 2 (NT, 32 b), 3 (NT, 8 b)
-    static const int variant = getenv("QIL_APPLY_VARIANT") ? atoi(getenv("QIL_APPLY_VARIANT")) : 0;
-    const int nbv = variant == 2 ? 32 : variant == 3 ? 8 : kNB;
+    // tuning aid: QIL_APPLY_VARIANT = 4 (default: MPO slab staged in LDS, non-temporal stores, 16 b per
+    // workgroup), 5 (same, 8 b), 0 (MPO entries straight from L1/L2), 1 (plain stores), 2 (32 b), 3 (8 b)
+    static const int variant = getenv("QIL_APPLY_VARIANT") ? atoi(getenv("QIL_APPLY_VARIANT")) : 4;
+    const int nbv = variant == 2 ? 32 : (variant == 3 || variant == 5) ? 8 : kNB;
     std::vector<ApplySite> tab((size_t)n);
     long long blocks = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -257,13 +285,17 @@ int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
 #define QIL_APPLY_LAUNCH(TW, TA)                                                                              \
     do {                                                                                                      \
         if (variant == 1)                                                                                     \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, false, 16>), grid, block, 0, ctx->stream, dtab, (int)n); \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, false, 16, false>), grid, block, 0, ctx->stream, dtab, (int)n); \
         else if (variant == 2)                                                                                \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 32>), grid, block, 0, ctx->stream, dtab, (int)n);  \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 32, false>), grid, block, 0, ctx->stream, dtab, (int)n);  \
         else if (variant == 3)                                                                                \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 8>), grid, block, 0, ctx->stream, dtab, (int)n);   \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 8, false>), grid, block, 0, ctx->stream, dtab, (int)n);   \
+        else if (variant == 4)                                                                                \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16, true>), grid, block, 0, ctx->stream, dtab, (int)n);   \
+        else if (variant == 5)                                                                                \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 8, true>), grid, block, 0, ctx->stream, dtab, (int)n);    \
         else                                                                                                  \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16>), grid, block, 0, ctx->stream, dtab, (int)n);  \
+            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16, false>), grid, block, 0, ctx->stream, dtab, (int)n);  \
     } while (0)
     if (wc && ac) QIL_APPLY_LAUNCH(c64, c64);
     else if (wc) QIL_APPLY_LAUNCH(c64, double);
