@@ -93,9 +93,25 @@ __device__ __forceinline__ void store_out(c64* p, c64 v) {
     if (NT) __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p)); else *reinterpret_cast<d2*>(p) = t;
 }
 
+// RPL = output rows per lane: 1 for complex results (one 16-B store per element), 2 for real results (two
+// adjacent rows packed into one 16-B store), so every wave-level store is 1 KiB contiguous either way.
+template <class TO>
+struct rows_per_lane {
+    static constexpr int value = sizeof(TO) == 16 ? 1 : 2;
+};
+
+template <bool NT>
+__device__ __forceinline__ void store_pair(double* p, double v0, double v1) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 t = {v0, v1};
+    if (NT) __builtin_nontemporal_store(t, reinterpret_cast<d2*>(p)); else *reinterpret_cast<d2*>(p) = t;
+}
+
 template <class TW, class TA, bool NT, int NBV, bool WLDS>
 __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __restrict__ sites, int nsites) {
     using TO = typename out_type<TW, TA>::type;
+    constexpr int RPL = rows_per_lane<TO>::value;
+    constexpr int kTileRows = kRows * RPL;
     // ---- block -> site (wave-uniform binary search over the prefix table)
     const long long blk = blockIdx.x;
     int lo = 0, hi = nsites - 1;
@@ -111,12 +127,20 @@ __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __r
     const int beta_tile = (int)(local % S.beta_tiles);
     const int b_chunk = (int)(local / S.beta_tiles);
 
-    const long long r_raw = (long long)row_tile * kRows + threadIdx.x;
-    const bool valid = r_raw < S.R;
+    const long long R = S.R;
+    const long long r_first = (long long)row_tile * kTileRows + (long long)threadIdx.x * RPL;
+    const bool valid = r_first < R;
     if (!WLDS && !valid) return;
-    const long long r = valid ? r_raw : S.R - 1;   // WLDS: idle lanes stay for the barrier, clamped to a real row
-    const int a = (int)(r / S.cl);
-    const int alpha = (int)(r - (long long)a * S.cl);
+    long long rr[RPL];
+    int a[RPL], alpha[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        rr[k] = min(r_first + k, R - 1);   // clamped: idle lanes (WLDS) and the odd last row stay on a real row
+        a[k] = (int)(rr[k] / S.cl);
+        alpha[k] = (int)(rr[k] - (long long)a[k] * S.cl);
+    }
+    const bool second = RPL == 2 && r_first + 1 < R;              // this lane's second row exists
+    const bool packed = RPL == 2 && second && (R & 1) == 0;       // 16-B aligned pair for every column
     const int beta0 = beta_tile * kTB;
     const int nbeta = min(kTB, S.cr - beta0);
     const int b0 = b_chunk * NBV;
@@ -127,26 +151,27 @@ __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __r
     TO* __restrict__ B = static_cast<TO*>(S.B);
 
     // ---- this lane's slice of the MPS site: A[alpha, s', beta0 .. beta0+TB)
-    TA A0[kTB], A1[kTB];
+    TA A0[RPL][kTB], A1[RPL][kTB];
 #pragma unroll
-    for (int t = 0; t < kTB; ++t) {
-        if (t < nbeta) {
-            const long long off = alpha + (long long)S.cl * (2LL * (beta0 + t));
-            A0[t] = A[off];
-            A1[t] = A[off + S.cl];
-        } else {
-            A0[t] = TA{};
-            A1[t] = TA{};
+    for (int k = 0; k < RPL; ++k)
+#pragma unroll
+        for (int t = 0; t < kTB; ++t) {
+            if (t < nbeta) {
+                const long long off = alpha[k] + (long long)S.cl * (2LL * (beta0 + t));
+                A0[k][t] = A[off];
+                A1[k][t] = A[off + S.cl];
+            } else {
+                A0[k][t] = TA{};
+                A1[k][t] = TA{};
+            }
         }
-    }
 
-    const long long R = S.R;
     const long long wstride = (long long)S.Dl;  // W[a, si, so, b]: a + Dl*(si + 2*(so + 2*b))
     // ---- WLDS: stage this workgroup's slab of the MPO site, W[a_lo..a_hi, :, :, b0..b1), in LDS once
     constexpr int kWCap = 16384 / (int)sizeof(TW);
     __shared__ TW wtile[WLDS ? kWCap : 1];
-    const int a_lo = (int)(((long long)row_tile * kRows) / S.cl);
-    const int a_hi = (int)(min((long long)row_tile * kRows + kRows - 1, S.R - 1) / S.cl);
+    const int a_lo = (int)(((long long)row_tile * kTileRows) / S.cl);
+    const int a_hi = (int)(min((long long)row_tile * kTileRows + kTileRows - 1, R - 1) / S.cl);
     const int na = a_hi - a_lo + 1;
     const bool staged = WLDS && na * 4 * (b1 - b0) <= kWCap;
     if (WLDS) {
@@ -159,37 +184,49 @@ __global__ __launch_bounds__(kRows) void site_apply_grouped(const ApplySite* __r
         if (!valid) return;
     }
     for (int b = b0; b < b1; ++b) {
-        TW w00, w10, w01, w11;
-        if (staged) {
-            const TW* wl = wtile + (a - a_lo) + na * 4 * (b - b0);
-            w00 = wl[0];
-            w10 = wl[na];
-            w01 = wl[2 * na];
-            w11 = wl[3 * na];
-        } else {
-            const TW* wp = W + a + wstride * (4LL * b);
-            w00 = wp[0];                     // s_in=0, s_out=0
-            w10 = wp[wstride];               // s_in=1, s_out=0
-            w01 = wp[2 * wstride];           // s_in=0, s_out=1
-            w11 = wp[3 * wstride];           // s_in=1, s_out=1
+        TW w00[RPL], w10[RPL], w01[RPL], w11[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            if (staged) {
+                const TW* wl = wtile + (a[k] - a_lo) + na * 4 * (b - b0);
+                w00[k] = wl[0];
+                w10[k] = wl[na];
+                w01[k] = wl[2 * na];
+                w11[k] = wl[3 * na];
+            } else {
+                const TW* wp = W + a[k] + wstride * (4LL * b);
+                w00[k] = wp[0];                     // s_in=0, s_out=0
+                w10[k] = wp[wstride];               // s_in=1, s_out=0
+                w01[k] = wp[2 * wstride];           // s_in=0, s_out=1
+                w11[k] = wp[3 * wstride];           // s_in=1, s_out=1
+            }
         }
-        TO* bp = B + r + R * (2LL * ((long long)beta0 + (long long)S.cr * b));
-        if (nbeta == kTB) {
+        TO* bp = B + r_first + R * (2LL * ((long long)beta0 + (long long)S.cr * b));
 #pragma unroll
-            for (int t = 0; t < kTB; ++t) {
-                store_out<NT>(bp, mad2(w00, A0[t], w10, A1[t]));
-                store_out<NT>(bp + R, mad2(w01, A0[t], w11, A1[t]));
-                bp += 2 * R;
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < kTB; ++t) {
-                if (t < nbeta) {
-                    store_out<NT>(bp, mad2(w00, A0[t], w10, A1[t]));
-                    store_out<NT>(bp + R, mad2(w01, A0[t], w11, A1[t]));
+        for (int t = 0; t < kTB; ++t) {
+            if (nbeta == kTB || t < nbeta) {
+                const TO v0 = mad2(w00[0], A0[0][t], w10[0], A1[0][t]);
+                const TO v1 = mad2(w01[0], A0[0][t], w11[0], A1[0][t]);
+                if constexpr (RPL == 2) {
+                    const TO u0 = mad2(w00[1], A0[1][t], w10[1], A1[1][t]);
+                    const TO u1 = mad2(w01[1], A0[1][t], w11[1], A1[1][t]);
+                    if (packed) {
+                        store_pair<NT>(bp, v0, u0);
+                        store_pair<NT>(bp + R, v1, u1);
+                    } else {
+                        store_out<NT>(bp, v0);
+                        store_out<NT>(bp + R, v1);
+                        if (second) {
+                            store_out<NT>(bp + 1, u0);
+                            store_out<NT>(bp + R + 1, u1);
+                        }
+                    }
+                } else {
+                    store_out<NT>(bp, v0);
+                    store_out<NT>(bp + R, v1);
                 }
-                bp += 2 * R;
             }
+            bp += 2 * R;
         }
     }
 }
@@ -252,6 +289,8 @@ int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
     // workgroup), 5 (same, 8 b), 0 (MPO entries straight from L1/L2), 1 (plain stores), 2 (32 b), 3 (8 b)
     static const int variant = getenv("QIL_APPLY_VARIANT") ? atoi(getenv("QIL_APPLY_VARIANT")) : 4;
     const int nbv = variant == 2 ? 32 : (variant == 3 || variant == 5) ? 8 : kNB;
+    // real x real results pack two rows per lane (16-B stores): 512-row tiles
+    const int tile_rows = (W->dtype == QIL_F64 && psi->dtype == QIL_F64) ? 2 * kRows : kRows;
     std::vector<ApplySite> tab((size_t)n);
     long long blocks = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -264,7 +303,7 @@ int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
         s.cl = (int)psi->dims[(size_t)i];
         s.cr = (int)psi->dims[(size_t)i + 1];
         s.R = (long long)s.Dl * s.cl;
-        s.row_tiles = (int)((s.R + kRows - 1) / kRows);
+        s.row_tiles = (int)((s.R + tile_rows - 1) / tile_rows);
         s.beta_tiles = (s.cr + kTB - 1) / kTB;
         s.b_chunks = (s.Dr + nbv - 1) / nbv;
         s.pad = 0;
