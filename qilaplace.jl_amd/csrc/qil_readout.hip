@@ -264,7 +264,12 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
     uint8_t* dbits = nullptr;
     QIL_TRY(upload_bits(ctx, nb, n, bits, &dbits, max_bit));
     const size_t esz = qil_elem_size(psi->dtype);
-    if (maxchi >= 512 && nb >= 4) {
+    // crossover between one-workgroup-per-query chains and the all-queries-together GEMM path (tuning aid:
+    // QIL_COEFF_GEMM_MINCHI)
+    // Measured on a 256 x 256 grid scan (65,536 queries): bond 504 chains 0.40 s vs GEMM 0.09 s; bond 23
+    // chains 4.9 ms vs GEMM 3.2 ms -- many queries favour the GEMM path at any bond dimension.
+    static const long long min_chi = getenv("QIL_COEFF_GEMM_MINCHI") ? atoll(getenv("QIL_COEFF_GEMM_MINCHI")) : 256;
+    if (nb >= 4 && (maxchi >= min_chi || (nb >= 1024 && maxchi >= 16))) {
         // Large bonds: all queries advance together, one f64-MFMA GEMM per site.  The site tensor is
         // read ONCE for the whole batch: T (nb x 2 chi_r) = V (nb x chi_l) * A_i (chi_l x 2 chi_r),
         // then each query keeps the column block of its own bit.
