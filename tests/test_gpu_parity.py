@@ -665,3 +665,30 @@ def test_npz_interchange_roundtrip(qil, tmp_path):
     assert qil.load(tmp_path / "obj.npz").dtype == np.float64
     qil.save(tmp_path / "p.npz", psi)
     assert qil.load(tmp_path / "p.npz").amplitude == 0.4
+
+
+# ---------------------------------------------------------------- randomized shapes for the apply kernel
+def test_apply_random_shapes_bitwise(qil):
+    """40 seeded random (bond, dtype) configurations, including rows > one tile, chi_l = 1 with large D_l
+    (MPO slab too big for LDS -> direct path), odd row counts (unpacked real stores), chi_r not a multiple
+    of the beta tile and D_r beyond one b chunk: every site tensor equals the oracle's element-wise."""
+    rng = np.random.default_rng(2026)
+    dts = [np.float64, np.complex128]
+    special = [([300, 3], [3, 40]), ([1, 1], [300, 33]), ([7, 129], [37, 2]), ([64, 64, 64], [20, 20, 20]),
+               ([5, 1, 9], [1, 70, 1])]
+    for it in range(40):
+        if it < len(special):
+            cb, db = special[it]
+        else:
+            L = int(rng.integers(1, 6))
+            cb = [int(rng.integers(1, 40)) for _ in range(L - 1)]
+            db = [int(rng.integers(1, 24)) for _ in range(L - 1)]
+        wdt, adt = dts[int(rng.integers(0, 2))], dts[int(rng.integers(0, 2))]
+        a = random_mps_data(cb, rng, adt, normalize=False)
+        w = random_mpo_data(db, rng, wdt)
+        got = qil.apply(qil.SingleSiteMPO(w), qil.SignalMPS(a))
+        ref = O.apply(O.SingleSiteMPO(w), O.SignalMPS(a))
+        for i in range(len(ref)):
+            g = got.site(i)
+            assert g.shape == ref.data[i].shape
+            assert rel(g, ref.data[i]) < 1e-14, (it, i, cb, db, wdt, adt)
