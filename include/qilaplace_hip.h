@@ -221,6 +221,9 @@ int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, const double
 int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
              const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc);
 
+/* Thin QR with non-negative real diagonal (qr(...; positive=true), rsvd.jl:83,90,94) of a host operand
+ * A (m x n, m >= n, column-major): Q (m x n), R (n x n).  Utility / test hook.                       */
+int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R);
 /* Diagnostic: device-resident time of the same GEMM (operands generated in HBM, HIP events). */
 int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
                          int reps, double* ms_per_call);

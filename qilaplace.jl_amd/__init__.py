@@ -17,7 +17,7 @@ from .containers import (Context, default_context, set_default_context, device_c
 from .ops import (apply, apply_compress, coefficient, coefficient_batch, apply_coefficient_batch,  # noqa: F401
                   marginal_batch, coefficient_grid, laplace_values,
                   mps_to_vector, norm, canonicalize, compress, signal_mps, signal_ztmps, rsvd,
-                  svd_trunc, gemm, gemm_device_time)
+                  svd_trunc, gemm, gemm_device_time, qr_positive)
 from .builders import (build_qft_mpo, build_dt_mpo, build_zt_mpo, qft_mpo_tensors,  # noqa: F401
                        dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many, build_dt_mpo_batch)
 from .interchange import save, load  # noqa: F401

@@ -458,12 +458,19 @@ __global__ void conj_transpose(const T* __restrict__ A, long long lda, long long
 // are accumulated together: every thread owns rows (tid, tid+1024, ...) and keeps up to 16 partial dot
 // products in registers, so each pass is one sweep over the rows with 1024 loads in flight, followed by
 // one DPP/LDS reduction -- not one latency-bound loop per previous column.
+// Numerically dependent columns: a column whose residual after the projections is below 1e-13 of its
+// ORIGINAL norm (`ref_norm[j]` if given -- the blocked driver measures it before its GEMM projections --
+// else the norm on entry) carries nothing but rounding noise.  Normalising that noise would produce a unit
+// vector that is NOT orthogonal to the previous ones ("twice is enough" does not hold for pure noise), and
+// every later projection through it would be wrong.  Such a column is dropped as a ZERO column with a zero
+// R diagonal: A = Q R still holds and Q^H Q is the projector on the numerical range.
 template <class T>
 __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long lda, int m, int n,
-                                                 T* __restrict__ R, long long ldr) {
+                                                 T* __restrict__ R, long long ldr,
+                                                 const double* __restrict__ ref_norm) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* c = reinterpret_cast<T*>(smem_raw);                 // n entries
-    __shared__ double red[16][34];
+    __shared__ double red[16][36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = 16, CH = 16;
     constexpr int NC = sizeof(T) == 16 ? 2 : 1;
@@ -472,6 +479,21 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long ld
     __syncthreads();
     for (int j = 0; j < n; ++j) {
         T* y = A + lda * j;
+        double nrm0;
+        if (ref_norm) {
+            nrm0 = ref_norm[j];
+        } else {
+            double v0 = 0;
+            for (int r = tid; r < m; r += 1024) v0 += abs2_t(y[r]);
+            v0 = wave_sum(v0);
+            if (lane == 0) red[wave][33] = v0;
+            __syncthreads();
+            double t0 = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t0 += red[w][33];
+            nrm0 = sqrt(t0);
+            __syncthreads();
+        }
         for (int pass = 0; pass < 2 && j > 0; ++pass) {
             for (int i0 = 0; i0 < j; i0 += CH) {
                 const int nc = min(CH, j - i0);
@@ -528,11 +550,12 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long ld
 #pragma unroll
         for (int w = 0; w < NW; ++w) tot += red[w][32];
         const double nrm = sqrt(tot);
-        const double inv = nrm > 0 ? 1.0 / nrm : 0.0;
+        const bool dep = !(nrm > 1e-13 * nrm0);
+        const double inv = dep ? 0.0 : 1.0 / nrm;
         for (int r = tid; r < m; r += 1024) y[r] = scale_t(y[r], inv);
         if (R && tid == 0) {
             T out{};
-            reinterpret_cast<double*>(&out)[0] = nrm;
+            reinterpret_cast<double*>(&out)[0] = dep ? 0.0 : nrm;
             R[j + ldr * j] = out;
         }
         __threadfence_block();
@@ -719,13 +742,16 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     if (n <= 16 || m * n <= (1LL << 15)) {
         if (m > (1LL << 22)) return qil_fail(QIL_EINVAL_ARG, "qr: panel too tall (%lld rows)", m);
         hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)n * sizeof(T), ctx->stream, A, lda, (int)m,
-                           (int)n, R, ldr);
+                           (int)n, R, ldr, (const double*)nullptr);
         QIL_HIP(hipGetLastError());
         return QIL_OK;
     }
     constexpr int PB = 16;
     if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
-    void *cbuf = nullptr, *dbuf = nullptr, *rpan = nullptr;
+    void *cbuf = nullptr, *dbuf = nullptr, *rpan = nullptr, *nbuf = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nbuf));
+    // original column norms, measured before any projection (reference for the dependence test)
+    hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const T*)A, lda, m, (double*)nbuf);
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * PB) * sizeof(T), &cbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * PB) * sizeof(T), &dbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(PB * PB) * sizeof(T), &rpan));
@@ -747,7 +773,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
         }
         // intra-panel CGS2 (one launch); its b x b triangular factor goes to R[j0:, j0:]
         hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)b * sizeof(T), ctx->stream, P, lda, (int)m, b,
-                           R ? Rp : (T*)nullptr, (long long)PB);
+                           R ? Rp : (T*)nullptr, (long long)PB, (const double*)nbuf + j0);
         if (R)
             QIL_HIP(hipMemcpy2DAsync(R + j0 + ldr * j0, (size_t)ldr * sizeof(T), Rp, (size_t)PB * sizeof(T),
                                      (size_t)b * sizeof(T), (size_t)b, hipMemcpyDeviceToDevice, ctx->stream));
@@ -756,6 +782,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     qil_ctx_free(ctx, cbuf);
     qil_ctx_free(ctx, dbuf);
     qil_ctx_free(ctx, rpan);
+    qil_ctx_free(ctx, nbuf);
     return QIL_OK;
 }
 
@@ -826,6 +853,26 @@ extern "C" int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m
     qil_ctx_free(ctx, dA);
     qil_ctx_free(ctx, dB);
     qil_ctx_free(ctx, dC);
+    return QIL_OK;
+}
+
+// Thin QR with non-negative diagonal on a host operand (m >= n): utility / test hook for the Gram-Schmidt QR
+extern "C" int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R) {
+    QIL_REQUIRE(ctx && A && Q && R, QIL_EINVAL_ARG, "qr: null argument");
+    QIL_REQUIRE(m >= n && n >= 1, QIL_EINVAL_ARG, "qr: needs m >= n >= 1 (got %lld x %lld)", (long long)m, (long long)n);
+    QIL_TRY(qil_ctx_activate(ctx));
+    const size_t e = qil_elem_size(dtype);
+    void *dA = nullptr, *dR = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * e, &dR));
+    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_TRY(qil_dev_qr_positive(ctx, dtype, m, n, dA, m, dR, n));
+    QIL_HIP(hipMemcpyAsync(Q, dA, (size_t)(m * n) * e, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(R, dR, (size_t)(n * n) * e, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    qil_ctx_free(ctx, dA);
+    qil_ctx_free(ctx, dR);
     return QIL_OK;
 }
 

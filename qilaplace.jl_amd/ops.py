@@ -334,3 +334,17 @@ def gemm_device_time(m, n, k, dtype=np.float64, opA="N", opB="N", reps=10, ctx=N
     L.check(L.lib.qil_gemm_device_time(ctx.handle, code, _OPS[opA], _OPS[opB], int(m), int(n), int(k),
                                        int(reps), C.byref(ms)))
     return ms.value
+
+
+def qr_positive(A, ctx=None):
+    """Thin QR with non-negative diagonal of R (the device Gram-Schmidt QR; utility / test hook)."""
+    ctx = ctx or default_context()
+    A = np.asarray(A)
+    code = L.QIL_C64 if np.iscomplexobj(A) else L.QIL_F64
+    Af = np.asfortranarray(A, dtype=_np_dtype(code))
+    m, n = Af.shape
+    Q = np.empty((m, n), dtype=Af.dtype, order="F")
+    R = np.empty((n, n), dtype=Af.dtype, order="F")
+    L.check(L.lib.qil_qr_positive(ctx.handle, code, m, n, Af.ctypes.data_as(C.c_void_p),
+                                  Q.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p)))
+    return Q, R

@@ -692,3 +692,56 @@ def test_apply_random_shapes_bitwise(qil):
             g = got.site(i)
             assert g.shape == ref.data[i].shape
             assert rel(g, ref.data[i]) < 1e-14, (it, i, cb, db, wdt, adt)
+
+
+def test_quickstart_example_runs(qil):
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "quickstart.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("OK")
+
+
+# ---------------------------------------------------------------- QR / RSVD on numerically rank-deficient inputs
+@pytest.mark.parametrize("m,l", [(32, 8), (32, 17), (32, 30), (100, 30), (5000, 30), (300, 64)])
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+def test_qr_rank_deficient_inputs(qil, m, l, dt):
+    """Sketches Y = M Omega of fast-decaying spectra: columns beyond the numerical rank are pure rounding
+    noise.  Q must stay orthonormal on its support (dropped columns are exactly zero) and Q R = Y."""
+    rng = np.random.default_rng(81)
+    G = lambda *s: rng.standard_normal(s) + (1j * rng.standard_normal(s) if dt == np.complex128 else 0)
+    M = G(m, 4) @ np.diag([1, 1e-2, 1e-7, 1e-10]) @ G(4, 32)
+    Y = M @ G(32, l)
+    Q, R = qil.qr_positive(Y)
+    Gm = Q.conj().T @ Q
+    d = np.real(np.diag(Gm))
+    assert np.all((np.abs(d - 1) < 1e-12) | (d == 0))                      # unit or exactly dropped
+    assert np.abs(Gm - np.diag(d)).max() < 1e-10
+    assert np.abs(Q @ R - Y).max() < 1e-12 * np.abs(Y).max()
+    assert np.all(np.real(np.diag(R)) >= 0) and np.abs(np.imag(np.diag(R))).max() == 0
+    assert 3 <= int(d.sum()) <= 6                                          # numerical rank ~4
+
+
+def test_qr_full_rank_matches_lapack_up_to_phase(qil):
+    rng = np.random.default_rng(82)
+    for shape in ((64, 33), (200, 40), (3000, 70)):
+        Y = rng.standard_normal(shape)
+        Q, R = qil.qr_positive(Y)
+        Qn, Rn = np.linalg.qr(Y)
+        sg = np.sign(np.diag(Rn))
+        assert np.abs(Q - Qn * sg).max() < 1e-10 and np.abs(R - Rn * sg[:, None]).max() < 1e-9
+
+
+def test_rsvd_wide_sketch_on_low_rank_signal(qil):
+    """README quick start: a rank-2 structured signal with the default sketch (l = 30 of 32 columns)."""
+    n = 10
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    A = (x / np.linalg.norm(x)).reshape(32, 32)
+    for kw in (dict(k=20, p=10, q=0), dict(k=30, p=2, q=0), dict(k=20, p=10, q=2)):
+        U, S, Vh = qil.rsvd(A, cutoff=1e-9, maxdim=64, **kw)
+        assert np.abs((U * S) @ Vh - A).max() < 1e-6
+        assert np.abs(U.T @ U - np.eye(len(S))).max() < 1e-10
+    psi = qil.signal_mps(x, method="rsvd", cutoff=1e-9, maxdim=64)
+    assert np.abs(qil.mps_to_vector(psi) - x).max() < 1e-4 * np.abs(x).max()
+    assert abs(psi.amplitude - np.linalg.norm(x)) < 1e-10
