@@ -82,6 +82,14 @@ pins = {
                             [0.0, -0.0038, 0.0, 0.0038], [0.0, -0.0008, 0.0, 0.0008]],
         "max_rel_err_published": 2.762e-15,
     },
+    # docs/src/tutorials/zt.md:318-392 -- n=20 complex two-pole signal x_j = a^j cos(w0 j),
+    # a = 1.00015 exp(0.002i), w0 = 0.0061; signal_ztmps(:rsvd, k=50, p=5, q=2, cutoff=1e-12, maxdim=128)
+    "zt_tutorial_big": {
+        "n": 20, "a_abs": 1.00015, "a_arg": 0.002, "w0": 0.0061,
+        "k": 50, "p": 5, "q": 2, "cutoff": 1e-12, "maxdim": 128,
+        "bonds_main": [1, 1, 1] + [2] * 16,
+        "bonds_copy": [1, 1, 1, 2, 3] + [4] * 14 + [2],
+    },
 }
 
 if os.path.isdir(REF):

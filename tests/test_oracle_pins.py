@@ -145,3 +145,13 @@ def test_zt_tutorial(pins):
     assert np.abs(np.round(chi.imag, 4) - np.array(p["chi_rounded4_im"])).max() < 1e-12
     ref = O.analytical_zt(x, wr=2 * np.pi, wi=2 * np.pi)
     assert (np.abs(chi - ref) / np.abs(ref)).max() < 1e-13
+
+
+# ---- zT tutorial, large signal: docs/src/tutorials/zt.md:318-392 (68 orders of magnitude of dynamic range)
+def test_zt_tutorial_big_signal_bond_structure(pins):
+    p = pins["zt_tutorial_big"]
+    N = 2 ** p["n"]
+    j = np.arange(N)
+    x = (p["a_abs"] * np.exp(1j * p["a_arg"])) ** j * np.cos(p["w0"] * j)
+    zt = O.signal_ztmps(x, method="rsvd", k=p["k"], p=p["p"], q=p["q"], cutoff=p["cutoff"], maxdim=p["maxdim"])
+    assert zt.bonds_main == p["bonds_main"] and zt.bonds_copy == p["bonds_copy"]
