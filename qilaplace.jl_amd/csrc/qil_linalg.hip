@@ -464,14 +464,23 @@ __global__ void conj_transpose(const T* __restrict__ A, long long lda, long long
 // vector that is NOT orthogonal to the previous ones ("twice is enough" does not hold for pure noise), and
 // every later projection through it would be wrong.  Such a column is dropped as a ZERO column with a zero
 // R diagonal: A = Q R still holds and Q^H Q is the projector on the numerical range.
+// Chunk mode (chunk_rows > 0, first level of the tall-skinny tree below): workgroup c factors rows
+// [c*chunk_rows, ...) on its own and writes its n x n triangle to rows [c*n, (c+1)*n) of a stacked R.
 template <class T>
-__global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long lda, int m, int n,
+__global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long lda, long long mtot, int n,
                                                  T* __restrict__ R, long long ldr,
-                                                 const double* __restrict__ ref_norm) {
+                                                 const double* __restrict__ ref_norm, long long chunk_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* c = reinterpret_cast<T*>(smem_raw);                 // n entries
     __shared__ double red[16][36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int m = (int)mtot;
+    if (chunk_rows > 0) {
+        const long long r0 = blockIdx.x * chunk_rows;
+        A += r0;
+        m = (int)min(chunk_rows, mtot - r0);
+        if (R) R += (long long)blockIdx.x * n;
+    }
     constexpr int NW = 16, CH = 16;
     constexpr int NC = sizeof(T) == 16 ? 2 : 1;
     if (R)
@@ -732,6 +741,105 @@ __global__ void sub_block(T* __restrict__ P, long long ldp, const T* __restrict_
     }
 }
 
+// Column norms of a tall matrix: partial sums of squares per (chunk, column), then one small reduction.
+template <class T>
+__global__ __launch_bounds__(256) void col_sumsq_chunks(const T* __restrict__ A, long long lda, long long m,
+                                                        long long chunk_rows, double* __restrict__ part) {
+    __shared__ double red[4];
+    const long long r0 = blockIdx.y * chunk_rows, r1 = min(m, r0 + chunk_rows);
+    const T* a = A + lda * blockIdx.x;
+    double v[1] = {0};
+    for (long long r = r0 + threadIdx.x; r < r1; r += 256) v[0] += abs2_t(a[r]);
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) part[blockIdx.y + (long long)gridDim.y * blockIdx.x] = v[0];
+}
+__global__ __launch_bounds__(256) void sqrt_sum_chunks(const double* __restrict__ part, int nch,
+                                                       double* __restrict__ out) {
+    __shared__ double red[4];
+    double v[1] = {0};
+    for (int t = threadIdx.x; t < nch; t += 256) v[0] += part[t + (long long)nch * blockIdx.x];
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrt(v[0]);
+}
+template <class T>
+int col_norms_any(qil_context* ctx, const T* A, long long lda, long long m, long long n, double* out) {
+    if (m < (1LL << 16)) {
+        hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, A, lda, m, out);
+        QIL_HIP(hipGetLastError());
+        return QIL_OK;
+    }
+    const long long chunk = std::max<long long>(4096, (m / 256 + 255) / 256 * 256);
+    const int nch = (int)((m + chunk - 1) / chunk);
+    void* part = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nch * n) * sizeof(double), &part));
+    hipLaunchKernelGGL(col_sumsq_chunks<T>, dim3((unsigned)n, (unsigned)nch), dim3(256), 0, ctx->stream, A, lda, m,
+                       chunk, (double*)part);
+    hipLaunchKernelGGL(sqrt_sum_chunks, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const double*)part, nch, out);
+    QIL_HIP(hipGetLastError());
+    qil_ctx_free(ctx, part);
+    return QIL_OK;
+}
+
+// P[rows of chunk c, :] <- P[rows of chunk c, :] * Q2[c*b : (c+1)*b, :]   (second half of the tree: the
+// chunk-local orthonormal factors times the factor of the stacked triangles)
+template <class T, int B>
+__global__ __launch_bounds__(256) void tsqr_apply_q2(T* __restrict__ P, long long lda, long long m, int b,
+                                                     const T* __restrict__ Q2, long long ldq,
+                                                     long long chunk_rows) {
+    __shared__ T q2[B * B];
+    const long long c = blockIdx.y;
+    for (int t = threadIdx.x; t < B * B; t += 256) {
+        const int i = t % B, j = t / B;
+        q2[t] = (i < b && j < b) ? Q2[c * b + i + ldq * j] : T{};
+    }
+    __syncthreads();
+    const long long r1 = min(m, (c + 1) * chunk_rows);
+    for (long long r = c * chunk_rows + blockIdx.x * 256 + threadIdx.x; r < r1; r += (long long)gridDim.x * 256) {
+        T in[B], out[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) in[i] = i < b ? P[r + lda * i] : T{};
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            T acc{};
+#pragma unroll
+            for (int i = 0; i < B; ++i) acc = fma_t(in[i], q2[i + B * j], acc);
+            out[j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j)
+            if (j < b) P[r + lda * j] = out[j];
+    }
+}
+
+// Tall-skinny QR of an m x b panel (b <= 16): a two-level tree.  ~512 workgroups orthonormalise their own
+// row chunks (CGS2, same dependence rule, measured against the GLOBAL column norms so a chunk never
+// normalises what is noise for the whole column), one workgroup factors the stacked triangles, and the
+// chunk factors are multiplied by their b x b piece of that second factor.  Three launches that stream
+// the panel with the whole chip instead of one CU.
+template <class T>
+int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, long long ldr,
+               const double* ref_norm) {
+    const long long chunk = std::max<long long>(2048, (m / 512 + 255) / 256 * 256);
+    const long long nch = (m + chunk - 1) / chunk;
+    void *rs = nullptr, *r2 = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nch * b * b) * sizeof(T), &rs));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(b * b) * sizeof(T), &r2));
+    T* Rs = static_cast<T*>(rs);
+    hipLaunchKernelGGL(gs_fused<T>, dim3((unsigned)nch), dim3(1024), (size_t)b * sizeof(T), ctx->stream, P, lda, m,
+                       b, Rs, nch * b, ref_norm, chunk);
+    hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)b * sizeof(T), ctx->stream, Rs, nch * b, nch * b,
+                       b, static_cast<T*>(r2), (long long)b, ref_norm, 0LL);
+    hipLaunchKernelGGL((tsqr_apply_q2<T, 16>), dim3((unsigned)std::min<long long>((chunk + 255) / 256, 64), (unsigned)nch),
+                       dim3(256), 0, ctx->stream, P, lda, m, b, (const T*)Rs, nch * b, chunk);
+    QIL_HIP(hipGetLastError());
+    if (R)
+        QIL_HIP(hipMemcpy2DAsync(R, (size_t)ldr * sizeof(T), r2, (size_t)b * sizeof(T), (size_t)b * sizeof(T),
+                                 (size_t)b, hipMemcpyDeviceToDevice, ctx->stream));
+    qil_ctx_free(ctx, rs);
+    qil_ctx_free(ctx, r2);
+    return QIL_OK;
+}
+
 // Thin QR with non-negative diagonal (qr(...; positive=true), rsvd.jl:83,90,94).
 //   * small panels: ONE launch (gs_fused);
 //   * otherwise blocked CGS2: panels of 16 columns are projected against all previous columns with two
@@ -739,10 +847,18 @@ __global__ void sub_block(T* __restrict__ P, long long ldp, const T* __restrict_
 //     spread over the chip by the GEMMs and the launch count drops from ~5 n to ~7 n / 16.
 template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
+    constexpr long long TALL = 8192;
     if (n <= 16 || m * n <= (1LL << 15)) {
-        if (m > (1LL << 22)) return qil_fail(QIL_EINVAL_ARG, "qr: panel too tall (%lld rows)", m);
-        hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)n * sizeof(T), ctx->stream, A, lda, (int)m,
-                           (int)n, R, ldr, (const double*)nullptr);
+        if (m >= TALL && n <= 16) {
+            void* nb0 = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nb0));
+            QIL_TRY(col_norms_any<T>(ctx, A, lda, m, n, (double*)nb0));
+            QIL_TRY(tsqr_panel<T>(ctx, m, (int)n, A, lda, R, ldr, (const double*)nb0));
+            qil_ctx_free(ctx, nb0);
+            return QIL_OK;
+        }
+        hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)n * sizeof(T), ctx->stream, A, lda, m,
+                           (int)n, R, ldr, (const double*)nullptr, 0LL);
         QIL_HIP(hipGetLastError());
         return QIL_OK;
     }
@@ -751,7 +867,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     void *cbuf = nullptr, *dbuf = nullptr, *rpan = nullptr, *nbuf = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nbuf));
     // original column norms, measured before any projection (reference for the dependence test)
-    hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const T*)A, lda, m, (double*)nbuf);
+    QIL_TRY(col_norms_any<T>(ctx, A, lda, m, n, (double*)nbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * PB) * sizeof(T), &cbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * PB) * sizeof(T), &dbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(PB * PB) * sizeof(T), &rpan));
@@ -772,8 +888,11 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
                                    n, (int)j0, b);
         }
         // intra-panel CGS2 (one launch); its b x b triangular factor goes to R[j0:, j0:]
-        hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)b * sizeof(T), ctx->stream, P, lda, (int)m, b,
-                           R ? Rp : (T*)nullptr, (long long)PB, (const double*)nbuf + j0);
+        if (m >= TALL)
+            QIL_TRY(tsqr_panel<T>(ctx, m, b, P, lda, R ? Rp : (T*)nullptr, (long long)PB, (const double*)nbuf + j0));
+        else
+            hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)b * sizeof(T), ctx->stream, P, lda, m, b,
+                               R ? Rp : (T*)nullptr, (long long)PB, (const double*)nbuf + j0, 0LL);
         if (R)
             QIL_HIP(hipMemcpy2DAsync(R + j0 + ldr * j0, (size_t)ldr * sizeof(T), Rp, (size_t)PB * sizeof(T),
                                      (size_t)b * sizeof(T), (size_t)b, hipMemcpyDeviceToDevice, ctx->stream));

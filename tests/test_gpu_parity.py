@@ -772,3 +772,22 @@ def test_zt_tutorial_big_signal_through_hip(qil, pins):
     # the encode's own cutoff (1e-12 per bond on a signal spanning 68 decades) sets the floor: the CPU
     # oracle pipeline shows the same ~1.5e-5 relative deviation from the closed form
     assert np.abs(chi - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("m,n,cplx,rank", [(8192, 3, 0, 0), (100001, 7, 1, 0), (200000, 16, 0, 5), (70000, 33, 0, 9),
+                                           (1 << 22, 2, 0, 0)])
+def test_qr_tall_panels_tree(qil, m, n, cplx, rank):
+    """Tall-skinny panels go through the two-level tree (chunk CGS2 -> stacked triangles -> Q1*Q2); same
+    contract as the single-workgroup path: A = QR, R upper triangular with diagonal >= 0, Q^H Q = projector
+    on the numerical range (dependent columns dropped as zero columns).  rsvd.jl:83,90,94 `qr(...; positive=true)`."""
+    rng = np.random.default_rng(m % 1000 + n)
+    A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n)) if rank else rng.standard_normal((m, n))
+    if cplx:
+        A = A + 1j * rng.standard_normal((m, n))
+    Q, R = qil.qr_positive(A)
+    assert np.abs(Q @ R - A).max() < 1e-13 * np.abs(A).max()
+    G = Q.conj().T @ Q
+    kept = np.real(np.diag(G)) > 0.5
+    assert kept.sum() == (rank or n)
+    assert np.abs(G - np.diag(kept.astype(float))).max() < 1e-13
+    assert np.abs(np.tril(R, -1)).max() == 0 and np.real(np.diag(R)).min() >= 0

@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import qilaplace_jl_amd as qil
 ctx = qil.default_context()
 rng = np.random.default_rng(3)
-for n in (16, 18, 20):
+for n in [int(a) for a in sys.argv[1:]] or (16, 18, 20):
     x = rng.standard_normal(2 ** n)
     t0 = time.perf_counter(); psi = qil.signal_mps(x, method="svd"); ctx.synchronize()
     t = time.perf_counter() - t0
