@@ -8,7 +8,9 @@
 //   `*`   every contraction on the path
 // Only gauge-invariant results are comparable with the reference.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 #include "qil_internal.h"
@@ -55,7 +57,9 @@ __global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long 
                                                  const T* __restrict__ A, long long a_rs, long long a_ks, int conjA,
                                                  const T* __restrict__ B, long long b_ks, long long b_cs, int conjB,
                                                  T* __restrict__ C, long long ldc, long long kchunk,
-                                                 long long cstride, int tiles_m, int tiles_n, int col_fastest) {
+                                                 long long cstride, int tiles_m, int tiles_n, int col_fastest,
+                                                 long long a_bs, long long b_bs, long long c_bs,
+                                                 const int* __restrict__ cmap, int cmap_blk) {
     constexpr bool CX = sizeof(T) == 16;
     constexpr int NP = CX ? 2 : 1;
     constexpr int LA = BM + 2, LB = BN + 2;   // +2 doubles: <= 2-way LDS conflicts for both the k-major
@@ -82,7 +86,12 @@ __global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long 
     const long long row0 = (long long)tm * BM, col0 = (long long)tn * BN;
     const long long kbeg = (long long)blockIdx.z * kchunk;
     const long long kend = min(k_total, kbeg + kchunk);
-    C += (long long)blockIdx.z * cstride;
+    // batch = blockIdx.y: strided operands; with `cmap` the output COLUMN BLOCKS of batch y are scattered
+    // (block g of width cmap_blk goes to column block cmap[y * n / cmap_blk + g] of the un-strided C)
+    A += (long long)blockIdx.y * a_bs;
+    B += (long long)blockIdx.y * b_bs;
+    C += (long long)blockIdx.z * cstride + (long long)blockIdx.y * c_bs;
+    if (cmap) cmap += (long long)blockIdx.y * (n / cmap_blk);
 
     d4 rr[TM][TN], ii[CX ? TM : 1][CX ? TN : 1], ri[CX ? TM : 1][CX ? TN : 1];
 #pragma unroll
@@ -201,7 +210,8 @@ __global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long 
                 const long long gr = row0 + wr + 16 * ti + l15;
                 const long long gc = col0 + wc + 16 * tj + l4 + 4 * r;
                 if (gr < m && gc < n) {
-                    double* cp = reinterpret_cast<double*>(C + gr + ldc * gc);
+                    const long long oc = cmap ? (long long)cmap[gc / cmap_blk] * cmap_blk + gc % cmap_blk : gc;
+                    double* cp = reinterpret_cast<double*>(C + gr + ldc * oc);
                     if (CX) {
                         cp[0] = rr[ti][tj][r] - ii[ti][tj][r];
                         cp[1] = ri[ti][tj][r];
@@ -223,10 +233,18 @@ __global__ void splitk_reduce(const T* __restrict__ W, long long cstride, int sp
     }
 }
 
+// strided batch (gridDim.y); split-K of a batch needs packed outputs (ldc == m, c_bs == m * n, no cmap)
+struct gemm_batch {
+    int count = 1;
+    long long a_bs = 0, b_bs = 0, c_bs = 0;
+    const int* cmap = nullptr;
+    int cmap_blk = 1;
+};
+
 template <class T, int BM, int BN, int WM, int WN, bool PIPE>
 int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T* A, long long a_rs,
                 long long a_ks, int conjA, const T* B, long long b_ks, long long b_cs, int conjB, T* C,
-                long long ldc) {
+                long long ldc, const gemm_batch& bt) {
     constexpr int NP = sizeof(T) == 16 ? 2 : 1;
     constexpr size_t lds = (size_t)(PIPE ? 2 : 1) * NP * GK * ((BM + 2) + (BN + 2)) * sizeof(double);
     static bool attr_set = false;
@@ -237,31 +255,36 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     }
     const long long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
     const long long tiles = tiles_m * tiles_n;
+    const bool can_split = bt.count == 1 || (ldc == m && bt.c_bs == m * n && !bt.cmap);
     // few output tiles + long K (projections Q^H P, sketches of skinny panels): split K over the chip
     int splits = 1;
-    if (tiles < 128 && k >= 1024) splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / tiles), 64);
+    if (can_split && tiles * bt.count < 128 && k >= 1024)
+        splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / (tiles * bt.count)), 64);
     if (splits < 2) splits = 1;
-    long long kchunk = k, cstride = 0;
+    long long kchunk = k, cstride = 0, c_bs = bt.c_bs;
     T* Cout = C;
     long long ldo = ldc;
     void* wsp = nullptr;
     if (splits > 1) {
         kchunk = (((k + splits - 1) / splits) + GK - 1) / GK * GK;
         splits = (int)((k + kchunk - 1) / kchunk);
-        cstride = m * n;
+        cstride = m * n * bt.count;
+        c_bs = m * n;
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cstride * splits) * sizeof(T), &wsp));
         Cout = static_cast<T*>(wsp);
         ldo = m;
     }
     // narrow outputs: neighbouring workgroups share the same rows of A (served from L2 / Infinity Cache)
     const int col_fastest = tiles_n <= 8 ? 1 : 0;
-    hipLaunchKernelGGL((gemm_mfma<T, BM, BN, WM, WN, PIPE>), dim3((unsigned)tiles, 1, (unsigned)splits), dim3(256), lds,
-                       ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo, kchunk, cstride,
-                       (int)tiles_m, (int)tiles_n, col_fastest);
+    hipLaunchKernelGGL((gemm_mfma<T, BM, BN, WM, WN, PIPE>), dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits),
+                       dim3(256), lds, ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo,
+                       kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,
+                       bt.cmap_blk);
     QIL_HIP(hipGetLastError());
     if (splits > 1) {
-        hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 2048)), dim3(256),
-                           0, ctx->stream, (const T*)Cout, cstride, splits, m, n, C, ldc);
+        // a packed batch reduces as one m x (n * count) matrix
+        hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)std::min<long long>((cstride + 255) / 256, 2048)), dim3(256),
+                           0, ctx->stream, (const T*)Cout, cstride, splits, m, n * bt.count, C, ldc);
         QIL_HIP(hipGetLastError());
         qil_ctx_free(ctx, wsp);
     }
@@ -270,7 +293,8 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
 
 template <class T>
 int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, long long k, const T* A,
-                  long long lda, const T* B, long long ldb, T* C, long long ldc) {
+                  long long lda, const T* B, long long ldb, T* C, long long ldc,
+                  const gemm_batch& batch = gemm_batch{}) {
     if (m == 0 || n == 0) return QIL_OK;
     QIL_REQUIRE(opA >= 0 && opA <= 3 && opB >= 0 && opB <= 3, QIL_EINVAL_ARG, "gemm: bad op codes %d, %d", opA, opB);
     // op(A)[r, kk] = A[r * a_rs + kk * a_ks];  op(B)[kk, c] = B[kk * b_ks + c * b_cs]
@@ -280,7 +304,7 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
     const int cA = (opA == 2 || opA == 3) ? 1 : 0, cB = (opB == 2 || opB == 3) ? 1 : 0;
     constexpr bool CX = sizeof(T) == 16;
 #define QIL_GEMM_GO(BM, BN, WM, WN, PIPE) \
-    return gemm_launch<T, BM, BN, WM, WN, PIPE>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc)
+    return gemm_launch<T, BM, BN, WM, WN, PIPE>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch)
     static const int force = getenv("QIL_GEMM_CFG") ? atoi(getenv("QIL_GEMM_CFG")) : -1;   // tuning aid
     if constexpr (CX) {
         if (force == 1) QIL_GEMM_GO(64, 64, 32, 32, true);
@@ -301,8 +325,9 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
 // ------------------------------------------------------------------ one-sided Jacobi SVD
 template <class T>
 __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long lda, long long m,
-                                                    T* __restrict__ V, long long ldv, int n, int npad,
-                                                    int round, double tol, int* __restrict__ rotated) {
+                                                    T* __restrict__ V, long long ldv, int vrows, int n,
+                                                    int npad, int round, double tol,
+                                                    int* __restrict__ rotated) {
     __shared__ double red[16];
     const int i = blockIdx.x;
     int p, q;
@@ -345,7 +370,7 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
     }
     T* vp = V + ldv * p;
     T* vq = V + ldv * q;
-    for (int r = threadIdx.x; r < n; r += 256) {
+    for (int r = threadIdx.x; r < vrows; r += 256) {
         T x = vp[r], y = vq[r];
         rotate_pair(x, y, c, s, pr, pi);
         vp[r] = x;
@@ -576,7 +601,249 @@ template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr);
 template <class T>
 int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, long long k, const T* A,
-                  long long lda, const T* B, long long ldb, T* C, long long ldc);
+                  long long lda, const T* B, long long ldb, T* C, long long ldc, const gemm_batch& batch);
+
+// ------------------------------------------------------------------ block one-sided Jacobi (large column counts)
+// The scalar tournament above moves the whole matrix through L2 once per ROUND (cols - 1 rounds per sweep,
+// one rotation per column pair per round).  For hundreds to thousands of columns the same orthogonalisation
+// is done on BLOCKS of BJ_B columns: a round pairs the blocks, and for every pair
+//     G = P^H P        (P = the pair's 2 BJ_B columns)            batched MFMA GEMM, split over K
+//     G = L L^H,  one-sided Jacobi on L^H  =>  J with J^H G J diagonal   (one workgroup, all in LDS)
+//     [P; V_P] <- [P; V_P] J                                       batched MFMA GEMM
+// so a sweep is (cols / BJ_B - 1) rounds of GEMM-shaped work.  The inner factorisation goes through the
+// Cholesky factor, not G itself, so small singular directions inside a pair are still resolved relative to
+// their own scale.  The update writes each block straight to the slot where the NEXT round's partner is
+// adjacent (column-block scatter of the GEMM), so pairs are always 64 contiguous columns and nothing is
+// ever copied just to re-pair.  The scalar tournament then runs as the convergence check / polish.
+constexpr int BJ_B = 32;
+constexpr int BJ_W = 2 * BJ_B;
+
+template <class T>
+__global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* __restrict__ Jm, double tol,
+                                                    int max_sweeps, int* __restrict__ flag,
+                                                    const int* __restrict__ big_second) {
+    constexpr int N = BJ_W, LD = N + 1;
+    extern __shared__ __attribute__((aligned(16))) char bj_smem[];
+    T* Aw = reinterpret_cast<T*>(bj_smem);
+    T* Vw = Aw + N * LD;
+    __shared__ double d0[N], lam[N];
+    __shared__ int s_rot, s_any, dest[N];
+    const int tid = threadIdx.x;
+    const T* G = Gm + (long long)blockIdx.x * N * N;
+    T* J = Jm + (long long)blockIdx.x * N * N;
+    if (tid == 0) s_any = 0;
+    for (int t = tid; t < N * N; t += 512) Aw[(t % N) + LD * (t / N)] = G[t];
+    __syncthreads();
+    if (tid < N) d0[tid] = reinterpret_cast<const double*>(&Aw[tid + LD * tid])[0];
+    __syncthreads();
+    int any = 0, work = 0;
+    float worst = 0.f;
+    for (int t = tid; t < N * N; t += 512) {
+        const int r = t % N, c = t / N;
+        if (r < c) {
+            const double g2 = abs2_t(Aw[r + LD * c]), dd = d0[r] * d0[c];
+            if (g2 > tol * tol * dd) any = 1;                 // above the convergence threshold
+            if (g2 > 1e-32 * dd) work = 1;                    // worth rotating at all
+            if (dd > 0) worst = fmaxf(worst, (float)sqrt(g2 / dd));
+        }
+    }
+    if (any) atomicOr(flag, 1);
+    if (worst > 0.f) atomicMax(reinterpret_cast<unsigned*>(flag) + 1, __float_as_uint(worst));
+    if (work) s_any = 1;
+    __syncthreads();
+    if (!s_any) {
+        for (int t = tid; t < N * N; t += 512) {
+            T v{};
+            if (t % N == t / N) reinterpret_cast<double*>(&v)[0] = 1.0;
+            J[t] = v;
+        }
+        return;
+    }
+    // Cholesky of the (semi-definite) Gram matrix, lower triangle, right-looking; a pivot at rounding level
+    // of its original diagonal closes that column (dependent / zero / padding columns)
+    for (int j = 0; j < N; ++j) {
+        const double d = reinterpret_cast<const double*>(&Aw[j + LD * j])[0];
+        const bool dead = !(d > 1e-14 * d0[j]);
+        const double piv = dead ? 0.0 : 1.0 / sqrt(d);
+        __syncthreads();
+        if (tid >= j && tid < N) {
+            T v = scale_t(Aw[tid + LD * j], piv);
+            if (tid == j) {
+                v = T{};
+                reinterpret_cast<double*>(&v)[0] = dead ? 0.0 : sqrt(d);
+            }
+            Aw[tid + LD * j] = v;
+        }
+        __syncthreads();
+        const int rem = N - 1 - j;
+        for (int t = tid; t < rem * rem; t += 512) {
+            const int i = j + 1 + t % rem, k = j + 1 + t / rem;
+            if (k <= i) Aw[i + LD * k] = sub_t(Aw[i + LD * k], fma_t(Aw[i + LD * j], conj_t(Aw[k + LD * j]), T{}));
+        }
+        __syncthreads();
+    }
+    // M = L^H (upper triangular): M^H M = G, so the right rotations that orthogonalise M's columns diagonalise G
+    for (int t = tid; t < N * N; t += 512) {
+        const int r = t % N, c = t / N;
+        Vw[r + LD * c] = r <= c ? conj_t(Aw[c + LD * r]) : T{};
+    }
+    __syncthreads();
+    for (int t = tid; t < N * N; t += 512) {
+        const int r = t % N, c = t / N;
+        Aw[r + LD * c] = Vw[r + LD * c];
+    }
+    __syncthreads();
+    for (int t = tid; t < N * N; t += 512) {
+        const int r = t % N, c = t / N;
+        T v{};
+        if (r == c) reinterpret_cast<double*>(&v)[0] = 1.0;
+        Vw[r + LD * c] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    jacobi_sweeps<T, 16, 512>(Aw, LD, N, Vw, LD, N, 1e-15, max_sweeps, &s_rot);
+    __syncthreads();
+    // de Rijk ordering at block level: the rotated columns leave sorted by norm (= eigenvalue of G), the
+    // larger half to the block with the smaller tournament label -- without it the sweeps count doubles
+    if (tid < N) {
+        double v = 0;
+        for (int r = 0; r < N; ++r) v += abs2_t(Aw[r + LD * tid]);
+        lam[tid] = v;
+    }
+    __syncthreads();
+    if (tid < N) {
+        int rank = 0;
+        const double mine = lam[tid];
+        for (int k = 0; k < N; ++k) rank += (lam[k] > mine || (lam[k] == mine && k < tid)) ? 1 : 0;
+        dest[tid] = big_second[blockIdx.x] ? (rank + N / 2) % N : rank;
+    }
+    __syncthreads();
+    // J is a product of a few thousand rotations: one Newton-Schulz step J (3 I - J^H J) / 2 brings it back to
+    // unitary at rounding level, otherwise the deviation accumulates over the hundreds of rounds V goes through
+    for (int t = tid; t < N * N; t += 512) {
+        const int r = t % N, c = t / N;
+        T acc{};
+        for (int k = 0; k < N; ++k) acc = fma_t(conj_t(Vw[k + LD * r]), Vw[k + LD * c], acc);
+        acc = scale_t(acc, -0.5);
+        if (r == c) reinterpret_cast<double*>(&acc)[0] += 1.5;
+        Aw[r + LD * c] = acc;                                  // E = (3 I - J^H J) / 2
+    }
+    __syncthreads();
+    for (int t = tid; t < N * N; t += 512) {
+        const int r = t % N, c = t / N;
+        T acc{};
+        for (int k = 0; k < N; ++k) acc = fma_t(Vw[r + LD * k], Aw[k + LD * c], acc);
+        J[r + N * dest[c]] = acc;
+    }
+}
+
+// Runs block sweeps on [Wk; I] (copied into a padded, double-buffered work area) until no pair's Gram matrix
+// has a relative off-diagonal above `tol` (or `max_sweeps`).  Returns the buffer holding the result:
+// rows [0, rows) = rotated Wk, rows [rows, rows + cols) = accumulated V, `cols_pad` columns in tournament
+// order (padding columns are entirely zero).
+template <class T>
+int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, long long ldw, double tol,
+                 int max_sweeps, void** xbuf, long long* ldx_out, long long* cols_pad_out, bool* converged) {
+    *converged = false;
+    const long long cpad = (cols + BJ_W - 1) / BJ_W * BJ_W;
+    const int nb = (int)(cpad / BJ_B), np = nb / 2;
+    const long long rt = rows + cols, ldx = rt;
+    void *xa = nullptr, *xb = nullptr, *gbuf = nullptr, *jbuf = nullptr, *flag = nullptr, *cmapd = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(ldx * cpad) * sizeof(T), &xa));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(ldx * cpad) * sizeof(T), &xb));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)np * BJ_W * BJ_W * sizeof(T), &gbuf));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)np * BJ_W * BJ_W * sizeof(T), &jbuf));
+    QIL_TRY(qil_ctx_alloc(ctx, 256, &flag));
+    // tournament bookkeeping: lab[r][s] = block label in slot s during round r (pairs = slots 2i, 2i+1);
+    // cmap[r][s] = slot of that label in round r + 1
+    const int nr = std::max(nb - 1, 1);
+    std::vector<int> lab((size_t)nr * nb), pos((size_t)nr * nb), cmap((size_t)nr * nb + (size_t)nr * np);
+    for (int r = 0; r < nr; ++r)
+        for (int i = 0; i < np; ++i) {
+            int p, q;
+            if (i == 0) {
+                p = nb - 1;
+                q = r;
+            } else {
+                p = (r + i) % (nb - 1);
+                q = (r + nb - 1 - i) % (nb - 1);
+            }
+            if (nb == 2) { p = 1; q = 0; }
+            lab[(size_t)r * nb + 2 * i] = p;
+            lab[(size_t)r * nb + 2 * i + 1] = q;
+            pos[(size_t)r * nb + p] = 2 * i;
+            pos[(size_t)r * nb + q] = 2 * i + 1;
+        }
+    for (int r = 0; r < nr; ++r)
+        for (int s2 = 0; s2 < nb; ++s2)
+            cmap[(size_t)r * nb + s2] = pos[(size_t)((r + 1) % nr) * nb + lab[(size_t)r * nb + s2]];
+    int* big2 = cmap.data() + (size_t)nr * nb;      // [r][i]: 1 if the pair's SECOND slot holds the smaller label
+    for (int r = 0; r < nr; ++r)
+        for (int i = 0; i < np; ++i)
+            big2[(size_t)r * np + i] = lab[(size_t)r * nb + 2 * i] > lab[(size_t)r * nb + 2 * i + 1] ? 1 : 0;
+    QIL_TRY(qil_ctx_alloc(ctx, cmap.size() * sizeof(int), &cmapd));
+    QIL_HIP(hipMemcpyAsync(cmapd, cmap.data(), cmap.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    T* Xc = static_cast<T*>(xa);
+    T* Xn = static_cast<T*>(xb);
+    QIL_HIP(hipMemsetAsync(Xc, 0, (size_t)(ldx * cpad) * sizeof(T), ctx->stream));
+    QIL_HIP(hipMemcpy2DAsync(Xc, (size_t)ldx * sizeof(T), Wk, (size_t)ldw * sizeof(T), (size_t)rows * sizeof(T),
+                             (size_t)cols, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(set_identity<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
+                       dim3(256), 0, ctx->stream, Xc + rows, ldx, (int)cols);
+    const size_t lds = (size_t)2 * BJ_W * (BJ_W + 1) * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bj_pair_evd<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int opH = sizeof(T) == 16 ? 2 : 1;
+    static const int inner_sweeps = getenv("QIL_BJ_INNER") ? atoi(getenv("QIL_BJ_INNER")) : 2;   // tuning aid
+    gemm_batch bg, bu;
+    bg.count = np;
+    bg.a_bs = bg.b_bs = (long long)BJ_W * ldx;
+    bg.c_bs = BJ_W * BJ_W;
+    bu.count = np;
+    bu.a_bs = (long long)BJ_W * ldx;
+    bu.b_bs = BJ_W * BJ_W;
+    bu.cmap_blk = BJ_B;
+    int status = QIL_OK;
+    for (int sweep = 0; sweep < max_sweeps && status == QIL_OK; ++sweep) {
+        QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
+        for (int r = 0; r < nr && status == QIL_OK; ++r) {
+            status = gemm_dispatch<T>(ctx, opH, 0, BJ_W, BJ_W, rows, Xc, ldx, Xc, ldx, static_cast<T*>(gbuf), BJ_W, bg);
+            if (status != QIL_OK) break;
+            hipLaunchKernelGGL(bj_pair_evd<T>, dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
+                               static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
+                               static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np);
+            bu.cmap = static_cast<const int*>(cmapd) + (size_t)r * nb;
+            status = gemm_dispatch<T>(ctx, 0, 0, rt, BJ_W, BJ_W, Xc, ldx, static_cast<const T*>(jbuf), BJ_W, Xn, ldx, bu);
+            std::swap(Xc, Xn);
+        }
+        int hh[2] = {0, 0};
+        QIL_HIP(hipMemcpyAsync(hh, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        float worst;
+        memcpy(&worst, &hh[1], sizeof(float));
+        if (getenv("QIL_SVD_DEBUG"))
+            fprintf(stderr, "[svd] block sweep %d (cols %lld): above tol=%d, worst relative off-diagonal %.3g\n", sweep,
+                    cols, hh[0], (double)worst);
+        if (!hh[0]) {
+            *converged = true;
+            break;
+        }
+    }
+    QIL_HIP(hipStreamSynchronize(ctx->stream));   // cmap (host vector) upload has completed
+    qil_ctx_free(ctx, Xc == xa ? xb : xa);
+    qil_ctx_free(ctx, gbuf);
+    qil_ctx_free(ctx, jbuf);
+    qil_ctx_free(ctx, flag);
+    qil_ctx_free(ctx, cmapd);
+    *xbuf = Xc;
+    *ldx_out = ldx;
+    *cols_pad_out = cpad;
+    return status;
+}
 
 // Thin SVD A = U diag(S) Vh by one-sided Jacobi on the SHORT side.
 //   1. orientation: the work matrix has rows >= cols (A^H if m < n);
@@ -588,6 +855,16 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
              double* S_host, T* Vh, long long ldvh) {
     const long long r0 = std::min(m, n);
     if (r0 == 0) return QIL_OK;
+    const bool dbg = getenv("QIL_SVD_DEBUG") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[svd] %lld x %lld: %s %.1f ms\n", m, n, what,
+                std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     const bool flip = m < n;
     T* Wk = A;           // work matrix (rows x cols), columns get orthogonalised
     long long ldw = lda, rows = m, cols = n;
@@ -601,11 +878,17 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)),
                            dim3(256), 0, ctx->stream, A, lda, m, n, Wk, ldw);
     }
-    // tall-skinny: Wk = Q R, rotate R instead
+    // tall-skinny: Wk = Q R, rotate R instead.  Large column counts (block path): always, and rotate R^H --
+    // the rows of a triangular factor are far closer to orthogonal than its columns, which saves sweeps
+    // (the classical preconditioning of one-sided Jacobi); then R^H = L S V^H gives Wk = (Q V) S L^H.
+    static const long long bj_min = getenv("QIL_BJ_MIN") ? atoll(getenv("QIL_BJ_MIN")) : 512;   // tuning aids
+    static const bool bj_rt = !(getenv("QIL_BJ_RT") && atoi(getenv("QIL_BJ_RT")) == 0);
+    const bool blocked = cols >= bj_min;
+    const bool rt = blocked && bj_rt;
     T* Q = nullptr;
     long long ldq = 0, qrows = 0;
-    void* rbuf = nullptr;
-    if (rows >= 8 * cols && rows >= 512) {
+    void *rbuf = nullptr, *rtbuf = nullptr;
+    if ((rows >= 8 * cols && rows >= 512) || rt) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rbuf));
         QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols));
         Q = Wk;
@@ -614,17 +897,27 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         Wk = static_cast<T*>(rbuf);
         ldw = cols;
         rows = cols;
+        if (rt) {
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rtbuf));
+            hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
+                               dim3(256), 0, ctx->stream, (const T*)Wk, ldw, cols, cols, static_cast<T*>(rtbuf), cols);
+            Wk = static_cast<T*>(rtbuf);
+        }
     }
-    void *vbuf = nullptr, *flag = nullptr, *nrm = nullptr, *permd = nullptr, *scd = nullptr;
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &vbuf));
+    lap("orientation + QR");
+    void *vbuf = nullptr, *flag = nullptr, *nrm = nullptr, *permd = nullptr, *scd = nullptr, *xbuf = nullptr;
+    if (!blocked) QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &vbuf));
     QIL_TRY(qil_ctx_alloc(ctx, 256, &flag));
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)cols * sizeof(double), &nrm));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)2 * (cols + BJ_W) * sizeof(double), &nrm));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)cols * sizeof(int), &permd));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)cols * sizeof(double), &scd));
     T* V = static_cast<T*>(vbuf);
+    long long ldv = cols;
+    long long nj = cols;          // columns of the rotated work area (> cols only with block padding)
     const int ncol = (int)cols;
-    const int npad = ncol + (ncol & 1);
-    const double tol = 1e-15;
+    // convergence threshold on |a_p . a_q| / (|a_p| |a_q|): 1e-15, but never below the rounding noise of the
+    // dot products themselves (~ eps sqrt(rows)), which long columns cannot get under
+    const double tol = std::max(1e-15, 4.0 * 1.1e-16 * std::sqrt((double)rows));
     if (ncol <= 96 && rows * cols <= (1LL << 19)) {
         const size_t lds_need = ((size_t)((rows | 1) * cols) + (size_t)((cols | 1) * cols)) * sizeof(T);
         if (lds_need <= 150 * 1024) {
@@ -641,27 +934,52 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
                                V, cols, ncol, tol, 40, (double*)nrm);
         }
     } else {
-        hipLaunchKernelGGL(set_identity<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
-                           dim3(256), 0, ctx->stream, V, cols, (int)cols);
-        for (int sweep = 0; sweep < 40 && ncol > 1; ++sweep) {
+        bool bj_done = false;
+        if (blocked) {
+            // GEMM-shaped block sweeps; the scalar tournament below only runs if they hit their sweep limit
+            long long ldx = 0, cpad = 0;
+            QIL_TRY(block_jacobi<T>(ctx, rows, cols, Wk, ldw, tol, 20, &xbuf, &ldx, &cpad, &bj_done));
+            Wk = static_cast<T*>(xbuf);
+            ldw = ldx;
+            V = Wk + rows;
+            ldv = ldx;
+            nj = cpad;
+            lap("block sweeps");
+        } else {
+            hipLaunchKernelGGL(set_identity<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
+                               dim3(256), 0, ctx->stream, V, cols, (int)cols);
+        }
+        const int nn = (int)nj, npad = nn + (nn & 1);
+        for (int sweep = 0; sweep < 40 && nn > 1 && !bj_done; ++sweep) {
             QIL_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
             for (int round = 0; round < npad - 1; ++round)
                 hipLaunchKernelGGL(jacobi_round<T>, dim3(npad / 2), dim3(256), 0, ctx->stream, Wk, ldw, rows, V,
-                                   cols, ncol, npad, round, tol, (int*)flag);
+                                   ldv, (int)cols, nn, npad, round, tol, (int*)flag);
             int h = 0;
             QIL_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             QIL_HIP(hipStreamSynchronize(ctx->stream));
+            if (getenv("QIL_SVD_DEBUG")) fprintf(stderr, "[svd] scalar sweep %d (cols %lld): rotated=%d\n", sweep, nj, h);
             if (!h) break;
         }
-        hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)cols), dim3(256), 0, ctx->stream, Wk, ldw, rows,
+        hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)nj), dim3(256), 0, ctx->stream, Wk, ldw, rows,
                            (double*)nrm);
+        if (blocked)   // padding columns are zero in the V part too; genuine columns have unit V columns
+            hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)nj), dim3(256), 0, ctx->stream, (const T*)V, ldv, cols,
+                               (double*)nrm + nj);
     }
-    std::vector<double> sig((size_t)cols);
-    QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)cols * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    lap("scalar sweeps");
+    std::vector<double> sig((size_t)nj * 2, 1.0);
+    QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)nj * (blocked && nj > 96 ? 2 : 1) * sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
     QIL_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<int> perm((size_t)cols);
+    std::vector<int> perm((size_t)nj);
     std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return sig[(size_t)a] > sig[(size_t)b]; });
+    const double* vn = sig.data() + nj;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+        const bool pa = vn[a] < 0.5, pb = vn[b] < 0.5;      // padding columns last
+        if (pa != pb) return pb;
+        return sig[(size_t)a] > sig[(size_t)b];
+    });
     std::vector<double> inv((size_t)cols);
     for (long long j = 0; j < cols; ++j) {
         const double s = sig[(size_t)perm[(size_t)j]];
@@ -670,49 +988,53 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     }
     QIL_HIP(hipMemcpyAsync(permd, perm.data(), (size_t)cols * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     QIL_HIP(hipMemcpyAsync(scd, inv.data(), (size_t)cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    const unsigned gb = (unsigned)std::min<long long>((rows * cols + 255) / 256, 65536);
-    const unsigned gv = (unsigned)std::min<long long>((cols * cols + 255) / 256, 65536);
-    // left factor of the work matrix: Wk[:, perm] D^-1 (rows x cols); with QR preprocessing it is Q * that
+    // Work problem: Wk[:, perm] = Fw diag(S), Fw orthonormal columns, and Fv = V[:, perm]:  Wk = Fw S Fv^H.
+    //   plain:        oriented A = Wk            = (Fw)   S (Fv)^H
+    //   QR:           oriented A = Q Wk          = (Q Fw) S (Fv)^H
+    //   QR, R^H:      oriented A = Q Wk^H        = (Q Fv) S (Fw)^H
+    // and for the flipped orientation (A^H was factored) left and right swap once more.
+    struct small_factor {
+        const T* p;
+        long long ld, nrows;
+        const double* scale;
+    };
+    const small_factor fw{Wk, ldw, rows, (const double*)scd}, fv{V, ldv, cols, nullptr};
+    const small_factor ls = rt ? fv : fw, rs = rt ? fw : fv;      // small left / right factors
+    auto gather = [&](const small_factor& f, T* dst, long long ldd, int conjT) {
+        const unsigned g = (unsigned)std::min<long long>((f.nrows * cols + 255) / 256, 65536);
+        hipLaunchKernelGGL(gather_cols<T>, dim3(g), dim3(256), 0, ctx->stream, f.p, f.ld, f.nrows, (const int*)permd,
+                           f.scale, dst, ldd, (int)cols, conjT);
+    };
     void* lbuf = nullptr;
-    T* Lw = nullptr;      // where the (orthonormal) left factor of the ORIENTED problem goes
-    long long ldl = 0, lrows = Q ? qrows : rows;
-    T* left_dst = flip ? nullptr : U;   // not flipped: left factor is U itself
+    const long long lrows = Q ? qrows : rows;
     if (Q) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &lbuf));
-        hipLaunchKernelGGL(gather_cols<T>, dim3(gv), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
-                           (const int*)permd, (const double*)scd, static_cast<T*>(lbuf), cols, (int)cols, 0);
+        gather(ls, static_cast<T*>(lbuf), cols, 0);
     }
     if (!flip) {
-        // A = L D V^H : U = L, Vh = V[:, perm]^H
-        if (Q) {
+        if (Q)
             QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, lrows, cols, cols, Q, ldq, static_cast<T*>(lbuf), cols, U, ldu));
-        } else {
-            hipLaunchKernelGGL(gather_cols<T>, dim3(gb), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
-                               (const int*)permd, (const double*)scd, U, ldu, (int)cols, 0);
-        }
-        hipLaunchKernelGGL(gather_cols<T>, dim3(gv), dim3(256), 0, ctx->stream, (const T*)V, cols, cols,
-                           (const int*)permd, (const double*)nullptr, Vh, ldvh, (int)cols, 1);
+        else
+            gather(ls, U, ldu, 0);
+        gather(rs, Vh, ldvh, 1);
     } else {
-        // A^H = L D V^H  =>  A = V D L^H : U = V[:, perm], Vh = L^H
-        hipLaunchKernelGGL(gather_cols<T>, dim3(gv), dim3(256), 0, ctx->stream, (const T*)V, cols, cols,
-                           (const int*)permd, (const double*)nullptr, U, ldu, (int)cols, 0);
-        if (Q) {
-            // Vh (cols x lrows) = (Q * Lsmall)^H = Lsmall^H * Q^H
+        gather(rs, U, ldu, 0);
+        if (Q)   // Vh (cols x lrows) = (Q * small)^H = small^H * Q^H
             QIL_TRY(gemm_dispatch<T>(ctx, sizeof(T) == 16 ? 2 : 1, sizeof(T) == 16 ? 2 : 1, cols, lrows, cols,
                                      static_cast<T*>(lbuf), cols, Q, ldq, Vh, ldvh));
-        } else {
-            hipLaunchKernelGGL(gather_cols<T>, dim3(gb), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
-                               (const int*)permd, (const double*)scd, Vh, ldvh, (int)cols, 1);
-        }
+        else
+            gather(ls, Vh, ldvh, 1);
     }
-    (void)Lw; (void)ldl; (void)left_dst;
     QIL_HIP(hipGetLastError());
     // perm/inv are host vectors read by async copies: finish before they go out of scope
     QIL_HIP(hipStreamSynchronize(ctx->stream));
+    lap("factors out");
     if (tbuf) qil_ctx_free(ctx, tbuf);
     if (rbuf) qil_ctx_free(ctx, rbuf);
+    if (rtbuf) qil_ctx_free(ctx, rtbuf);
     if (lbuf) qil_ctx_free(ctx, lbuf);
-    qil_ctx_free(ctx, vbuf);
+    if (vbuf) qil_ctx_free(ctx, vbuf);
+    if (xbuf) qil_ctx_free(ctx, xbuf);
     qil_ctx_free(ctx, flag);
     qil_ctx_free(ctx, nrm);
     qil_ctx_free(ctx, permd);

@@ -791,3 +791,33 @@ def test_qr_tall_panels_tree(qil, m, n, cplx, rank):
     assert kept.sum() == (rank or n)
     assert np.abs(G - np.diag(kept.astype(float))).max() < 1e-13
     assert np.abs(np.tril(R, -1)).max() == 0 and np.real(np.diag(R)).min() >= 0
+
+
+@pytest.mark.parametrize("m,n,cplx,kind", [(600, 600, 0, "rand"), (700, 520, 1, "rand"), (530, 900, 0, "rand"),
+                                            (1100, 1100, 0, "rand"), (640, 640, 1, "graded"), (900, 600, 0, "rank40"),
+                                            (576, 576, 0, "dup")])
+def test_svd_block_jacobi_path(qil, m, n, cplx, kind):
+    """>= 512 columns on the short side: QR, then GEMM-shaped block Jacobi sweeps on R^H (batched Gram /
+    in-LDS pair eigen-solve / batched update).  Same contract as every svd call site (mps.jl:929,946;
+    SignalConverters.jl:84): A = U S Vh to rounding, singular values equal LAPACK's, isometric factors."""
+    rng = np.random.default_rng(m + 3 * n)
+    r0 = min(m, n)
+    A = rng.standard_normal((m, n))
+    if cplx:
+        A = A + 1j * rng.standard_normal((m, n))
+    if kind == "graded":
+        U0, _ = np.linalg.qr(A)
+        V0, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+        A = (U0[:, :r0] * np.logspace(0, -12, r0)) @ V0[:, :r0].conj().T
+    elif kind == "rank40":
+        A = rng.standard_normal((m, 40)) @ rng.standard_normal((40, n))
+    elif kind == "dup":
+        A[:, 100:200] = A[:, 0:100]
+    U, S, Vh = qil.svd_trunc(A, cutoff=None)
+    Sref = np.linalg.svd(A, compute_uv=False)
+    assert len(S) == r0 and np.all(np.diff(S) <= 0) and S.min() >= 0
+    assert np.abs((U * S) @ Vh - A).max() < 1e-12 * np.abs(A).max()
+    assert np.abs(S - Sref).max() < 1e-12 * Sref[0]
+    live = S > 1e-10 * S[0]
+    assert np.abs(U[:, live].conj().T @ U[:, live] - np.eye(live.sum())).max() < 1e-11
+    assert np.abs(Vh[live] @ Vh[live].conj().T - np.eye(live.sum())).max() < 1e-11
