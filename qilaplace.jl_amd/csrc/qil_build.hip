@@ -208,13 +208,9 @@ __device__ __forceinline__ void jacobi_sweeps_nov(T* A, int lda, int m, int n, d
                 al = group_sum<G>(al);
                 be = group_sum<G>(be);
                 gr = group_sum<G>(gr);
-                const double g = fabs(gr);
-                if (!(g > tol * sqrt(al * be)) || g == 0.0) continue;
+                double c, sn, pr, pi_unused;
+                if (!jacobi_rotation<false>(al, be, gr, 0.0, tol, c, sn, pr, pi_unused)) continue;
                 if (lane == 0) *s_rot = 1;
-                const double zeta = (be - al) / (2.0 * g);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                const double pr = gr / g;
                 for (int r = lane; r < m; r += G) {
                     T x = ap[r], y = aq[r];
                     rotate_pair(x, y, c, sn, pr, 0.0);

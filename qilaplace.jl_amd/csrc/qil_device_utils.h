@@ -105,6 +105,45 @@ __device__ __forceinline__ void dot_parts(c64 x, c64 y, double& gr, double& gi) 
     gi += x.re * y.im - x.im * y.re;
 }
 
+// Rotation that orthogonalises a column pair with alpha = |x|^2, beta = |y|^2, gamma = x^H y = gr + i gi.
+// Returns false when the pair already passes |gamma| <= tol |x| |y|.  The rotation is a dependent chain of
+// double-precision sqrt / divide sequences executed once per pair per round -- on the latency-bound
+// in-LDS paths it IS the round time, so it is kept to one divide, one sqrt + divide and one rsqrt
+// (real: |gamma| and its sign need neither a sqrt nor a divide).
+// 1 / sqrt(x) to within an ulp: the library rsqrt plus one Newton step (3 FMAs).  The rotations must be
+// unitary to rounding level -- a 2-3 ulp bias in c accumulates over the thousands of rotations V receives.
+__device__ __forceinline__ double rsqrt_refined(double x) {
+    const double y = rsqrt(x);
+    return y * fma(-0.5 * x * y, y, 1.5);
+}
+
+template <bool CX>
+__device__ __forceinline__ bool jacobi_rotation(double al, double be, double gr, double gi, double tol,
+                                                double& c, double& s, double& pr, double& pi) {
+    double g, half_inv_g;
+    if (CX) {
+        const double g2 = gr * gr + gi * gi;
+        if (!(g2 > tol * tol * al * be) || g2 == 0.0) return false;
+        const double inv_g = rsqrt_refined(g2);
+        g = g2 * inv_g;
+        pr = gr * inv_g;
+        pi = gi * inv_g;
+        half_inv_g = 0.5 * inv_g;
+    } else {
+        g = fabs(gr);
+        if (!(g * g > tol * tol * al * be) || g == 0.0) return false;
+        pr = gr >= 0 ? 1.0 : -1.0;
+        pi = 0.0;
+        half_inv_g = 0.5 / g;
+    }
+    const double zeta = (be - al) * half_inv_g;
+    const double az = fabs(zeta);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (az + sqrt(1.0 + az * az));
+    c = rsqrt_refined(1.0 + t * t);
+    s = c * t;
+    return true;
+}
+
 // Whole one-sided Jacobi SVD iteration in ONE launch of ONE 1024-thread workgroup: V = I, sweeps of the
 // round-robin tournament until no pair rotates, then the column norms.  Each wave owns whole column
 // pairs (lanes stride over rows, shuffle reductions), pairs of a round are disjoint, rounds are
@@ -151,13 +190,9 @@ __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ld
                 be = group_sum<G>(be);
                 gr = group_sum<G>(gr);
                 if (sizeof(T) == 16) gi = group_sum<G>(gi);
-                const double g = sqrt(gr * gr + gi * gi);
-                if (!(g > tol * sqrt(al * be)) || g == 0.0) continue;
+                double c, sn, pr, pi;
+                if (!jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, tol, c, sn, pr, pi)) continue;
                 if (lane == 0) *s_rot = 1;
-                const double zeta = (be - al) / (2.0 * g);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                const double pr = gr / g, pi = gi / g;
                 for (int r = lane; r < m; r += G) {
                     T x = ap[r], y = aq[r];
                     rotate_pair(x, y, c, sn, pr, pi);

@@ -354,14 +354,9 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
         dot_parts(x, y, v[2], v[3]);
     }
     block_sum<4>(v, red);
-    const double alpha = v[0], beta = v[1];
-    const double g = sqrt(v[2] * v[2] + v[3] * v[3]);
-    if (!(g > tol * sqrt(alpha * beta)) || g == 0.0) return;
+    double c, s, pr, pi;
+    if (!jacobi_rotation<sizeof(T) == 16>(v[0], v[1], v[2], v[3], tol, c, s, pr, pi)) return;
     if (threadIdx.x == 0) *rotated = 1;
-    const double zeta = (beta - alpha) / (2.0 * g);
-    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-    const double pr = v[2] / g, pi = v[3] / g;
     for (long long r = threadIdx.x; r < m; r += 256) {
         T x = ap[r], y = aq[r];
         rotate_pair(x, y, c, s, pr, pi);
@@ -659,33 +654,34 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
         }
         return;
     }
-    // Cholesky of the (semi-definite) Gram matrix, lower triangle, right-looking; a pivot at rounding level
-    // of its original diagonal closes that column (dependent / zero / padding columns)
+    // Cholesky of the (semi-definite) Gram matrix, lower triangle, right-looking, ONE barrier per step: the
+    // trailing update uses the UNSCALED column j and 1 / pivot, the columns are scaled by 1 / sqrt(pivot) only
+    // when L^H is written out.  A pivot at rounding level of its original diagonal closes that column
+    // (dependent / zero / padding columns).
     for (int j = 0; j < N; ++j) {
+        __syncthreads();
         const double d = reinterpret_cast<const double*>(&Aw[j + LD * j])[0];
         const bool dead = !(d > 1e-14 * d0[j]);
-        const double piv = dead ? 0.0 : 1.0 / sqrt(d);
-        __syncthreads();
-        if (tid >= j && tid < N) {
-            T v = scale_t(Aw[tid + LD * j], piv);
-            if (tid == j) {
-                v = T{};
-                reinterpret_cast<double*>(&v)[0] = dead ? 0.0 : sqrt(d);
-            }
-            Aw[tid + LD * j] = v;
-        }
-        __syncthreads();
+        const double inv = dead ? 0.0 : 1.0 / d;
+        if (tid == 0) lam[j] = dead ? 0.0 : d;
         const int rem = N - 1 - j;
         for (int t = tid; t < rem * rem; t += 512) {
             const int i = j + 1 + t % rem, k = j + 1 + t / rem;
-            if (k <= i) Aw[i + LD * k] = sub_t(Aw[i + LD * k], fma_t(Aw[i + LD * j], conj_t(Aw[k + LD * j]), T{}));
+            if (k <= i)
+                Aw[i + LD * k] = sub_t(Aw[i + LD * k], scale_t(fma_t(Aw[i + LD * j], conj_t(Aw[k + LD * j]), T{}), inv));
         }
-        __syncthreads();
     }
+    __syncthreads();
     // M = L^H (upper triangular): M^H M = G, so the right rotations that orthogonalise M's columns diagonalise G
     for (int t = tid; t < N * N; t += 512) {
         const int r = t % N, c = t / N;
-        Vw[r + LD * c] = r <= c ? conj_t(Aw[c + LD * r]) : T{};
+        T v{};
+        if (r < c) {
+            v = scale_t(conj_t(Aw[c + LD * r]), lam[r] > 0 ? rsqrt(lam[r]) : 0.0);
+        } else if (r == c) {
+            reinterpret_cast<double*>(&v)[0] = sqrt(lam[r]);
+        }
+        Vw[r + LD * c] = v;
     }
     __syncthreads();
     for (int t = tid; t < N * N; t += 512) {

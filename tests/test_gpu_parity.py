@@ -253,7 +253,7 @@ def test_tutorial_pins_through_hip(qil, pins):
         bits = np.array([interleave(int_to_bits(k, n, "lsb"), int_to_bits(j, n)) for j in range(N)])
         L.append(dt * np.sqrt(N) * qil.coefficient_batch(out, bits).sum())
     assert abs(L[0] - p["L_s0"]) < 1e-13
-    assert np.abs(np.round(np.real(L), 5) - np.array(p["L_rounded5"])).max() < 1e-12
+    assert np.abs(np.real(L) - np.array(p["L_rounded5"])).max() <= 0.5e-5 + 1e-9   # printed to 5 decimals in the tutorial
     # zT tutorial (docs/src/tutorials/zt.md): 4x4 chi table
     p = pins["zt_tutorial"]
     n = p["n"]
@@ -266,8 +266,8 @@ def test_tutorial_pins_through_hip(qil, pins):
     bits = np.array([interleave(int_to_bits(k, n, "lsb"), int_to_bits(l, n, "lsb"))
                      for k in range(N) for l in range(N)])
     chi = qil.coefficient_batch(out, bits).reshape(N, N)
-    assert np.abs(np.round(chi.real, 4) - np.array(p["chi_rounded4_re"])).max() < 1e-12
-    assert np.abs(np.round(chi.imag, 4) - np.array(p["chi_rounded4_im"])).max() < 1e-12
+    assert np.abs(chi.real - np.array(p["chi_rounded4_re"])).max() <= 0.5e-4 + 1e-9   # printed to 4 decimals in the tutorial
+    assert np.abs(chi.imag - np.array(p["chi_rounded4_im"])).max() <= 0.5e-4 + 1e-9   # printed to 4 decimals in the tutorial
     # signal tutorial: bonds (1,2,2), first sample
     p = pins["signal_tutorial"]
     psi = qil.signal_mps(np.array(p["x"]), method="svd", cutoff=1e-14)
@@ -570,15 +570,15 @@ def test_laplace_values_and_grid_match_tutorial(qil, pins):
     out = qil.build_dt_mpo(psiz, wr, cutoff=1e-14, maxdim=64) * psiz
     Lv = qil.laplace_values(out, np.arange(N), dt)
     assert abs(Lv[0] - p["L_s0"]) < 1e-13
-    assert np.abs(np.round(Lv.real, 5) - np.array(p["L_rounded5"])).max() < 1e-12
+    assert np.abs(Lv.real - np.array(p["L_rounded5"])).max() <= 0.5e-5 + 1e-9   # printed to 5 decimals in the tutorial
     p = pins["zt_tutorial"]
     n = p["n"]
     N = 2 ** n
     x = np.array([p["a"] ** j * np.cos(np.pi * p["w0_over_pi"] * j) for j in range(N)])
     psiz = qil.signal_ztmps(x, cutoff=1e-14, maxdim=64)
     chi = qil.coefficient_grid(qil.build_zt_mpo(psiz, 2 * np.pi, cutoff=1e-14, maxdim=64) * psiz, np.arange(N), np.arange(N))
-    assert np.abs(np.round(chi.real, 4) - np.array(p["chi_rounded4_re"])).max() < 1e-12
-    assert np.abs(np.round(chi.imag, 4) - np.array(p["chi_rounded4_im"])).max() < 1e-12
+    assert np.abs(chi.real - np.array(p["chi_rounded4_re"])).max() <= 0.5e-4 + 1e-9   # printed to 4 decimals in the tutorial
+    assert np.abs(chi.imag - np.array(p["chi_rounded4_im"])).max() <= 0.5e-4 + 1e-9   # printed to 4 decimals in the tutorial
 
 
 # ---------------------------------------------------------------- batched device DT builder

@@ -120,7 +120,7 @@ def test_dt_tutorial(pins):
 
     assert abs(laplace(0) - p["L_s0"]) < 1e-14
     L = np.array([laplace(k) for k in range(N)])
-    assert np.abs(np.round(L.real, 5) - np.array(p["L_rounded5"])).max() < 1e-12
+    assert np.abs(L.real - np.array(p["L_rounded5"])).max() <= 0.5e-5 + 1e-9   # printed to 5 decimals in the tutorial
     ref = dt * np.sqrt(N) * O.analytical_dt(x, wr)
     assert np.abs(L - ref).max() < 1e-14
 
@@ -131,7 +131,7 @@ def test_zt_tutorial(pins):
     n = p["n"]
     N = 2 ** n
     x = np.array([p["a"] ** j * np.cos(np.pi * p["w0_over_pi"] * j) for j in range(N)])
-    assert np.abs(np.round(x, 4) - np.array(p["x_rounded4"])).max() < 1e-12
+    assert np.abs(x - np.array(p["x_rounded4"])).max() <= 0.5e-4 + 1e-9   # printed to 4 decimals in the tutorial
     psiz = O.signal_ztmps(x, cutoff=1e-14, maxdim=64)
     b2 = int_to_bits(2, n)
     assert abs(O.coefficient(psiz, interleave(b2, b2)) - p["amp_match_j2"]) < 1e-15
@@ -141,8 +141,8 @@ def test_zt_tutorial(pins):
     bits = np.array([interleave(int_to_bits(k, n, "lsb"), int_to_bits(l, n, "lsb"))
                      for k in range(N) for l in range(N)])
     chi = O.coefficient_batch(out, bits).reshape(N, N)
-    assert np.abs(np.round(chi.real, 4) - np.array(p["chi_rounded4_re"])).max() < 1e-12
-    assert np.abs(np.round(chi.imag, 4) - np.array(p["chi_rounded4_im"])).max() < 1e-12
+    assert np.abs(chi.real - np.array(p["chi_rounded4_re"])).max() <= 0.5e-4 + 1e-9   # printed to 4 decimals in the tutorial
+    assert np.abs(chi.imag - np.array(p["chi_rounded4_im"])).max() <= 0.5e-4 + 1e-9   # printed to 4 decimals in the tutorial
     ref = O.analytical_zt(x, wr=2 * np.pi, wi=2 * np.pi)
     assert (np.abs(chi - ref) / np.abs(ref)).max() < 1e-13
 
