@@ -112,6 +112,17 @@ int qil_chain_set_site(qil_chain* c, int64_t i, void* p, int64_t dl, int64_t dr)
 // C[m x n] = opA(A) * opB(B); op: 0 = N, 1 = T, 2 = H, 3 = conj (no transpose).  alpha = 1, beta = 0.
 int qil_dev_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
                  const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc);
+// Strided batch of the same product (grid y = batch): operand/result b lives at base + b * stride elements;
+// optionally B of batch b is shifted by b_sel[b * b_sel_step] * b_sel_stride further elements.
+struct qil_gemm_batch {
+    int64_t count = 1;
+    int64_t a_bs = 0, b_bs = 0, c_bs = 0;
+    const uint8_t* b_sel = nullptr;
+    int64_t b_sel_step = 0, b_sel_stride = 0;
+};
+int qil_dev_gemm_batched(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+                         const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                         const qil_gemm_batch* batch);
 // At (n x m, ldt) = A^T (conj = 0) or A^H (conj = 1)
 int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t n, const void* A, int64_t lda,
                       void* At, int64_t ldt);

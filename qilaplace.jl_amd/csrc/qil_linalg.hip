@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long 
                                                  T* __restrict__ C, long long ldc, long long kchunk,
                                                  long long cstride, int tiles_m, int tiles_n, int col_fastest,
                                                  long long a_bs, long long b_bs, long long c_bs,
-                                                 const int* __restrict__ cmap, int cmap_blk) {
+                                                 const int* __restrict__ cmap, int cmap_blk,
+                                                 const uint8_t* __restrict__ b_sel, long long b_sel_step,
+                                                 long long b_sel_stride) {
     constexpr bool CX = sizeof(T) == 16;
     constexpr int NP = CX ? 2 : 1;
     constexpr int LA = BM + 2, LB = BN + 2;   // +2 doubles: <= 2-way LDS conflicts for both the k-major
@@ -90,6 +92,9 @@ __global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long 
     // (block g of width cmap_blk goes to column block cmap[y * n / cmap_blk + g] of the un-strided C)
     A += (long long)blockIdx.y * a_bs;
     B += (long long)blockIdx.y * b_bs;
+    // per-batch operand selection: batch y reads B shifted by b_sel[y * step] * stride elements (the lazy
+    // coefficient chain picks the output-bit slice of each query this way)
+    if (b_sel) B += (long long)b_sel[(long long)blockIdx.y * b_sel_step] * b_sel_stride;
     C += (long long)blockIdx.z * cstride + (long long)blockIdx.y * c_bs;
     if (cmap) cmap += (long long)blockIdx.y * (n / cmap_blk);
 
@@ -239,6 +244,8 @@ struct gemm_batch {
     long long a_bs = 0, b_bs = 0, c_bs = 0;
     const int* cmap = nullptr;
     int cmap_blk = 1;
+    const uint8_t* b_sel = nullptr;
+    long long b_sel_step = 0, b_sel_stride = 0;
 };
 
 template <class T, int BM, int BN, int WM, int WN, bool PIPE>
@@ -279,7 +286,7 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     hipLaunchKernelGGL((gemm_mfma<T, BM, BN, WM, WN, PIPE>), dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits),
                        dim3(256), lds, ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo,
                        kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,
-                       bt.cmap_blk);
+                       bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride);
     QIL_HIP(hipGetLastError());
     if (splits > 1) {
         // a packed batch reduces as one m x (n * count) matrix
@@ -1344,6 +1351,26 @@ extern "C" int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int op
     qil_ctx_free(ctx, dB);
     qil_ctx_free(ctx, dC);
     return QIL_OK;
+}
+
+int qil_dev_gemm_batched(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+                         const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                         const qil_gemm_batch* b) {
+    gemm_batch bt;
+    bt.count = (int)b->count;
+    bt.a_bs = b->a_bs;
+    bt.b_bs = b->b_bs;
+    bt.c_bs = b->c_bs;
+    bt.b_sel = b->b_sel;
+    bt.b_sel_step = b->b_sel_step;
+    bt.b_sel_stride = b->b_sel_stride;
+    if (b->count <= 0) return QIL_OK;
+    QIL_REQUIRE(b->count <= 65535, QIL_EINVAL_ARG, "gemm: batch count %lld exceeds the grid limit", (long long)b->count);
+    if (dtype == QIL_C64)
+        return gemm_dispatch<c64>(ctx, opA, opB, m, n, k, (const c64*)A, lda, (const c64*)B, ldb, (c64*)C, ldc, bt);
+    static const int real_op[4] = {0, 1, 1, 0};
+    return gemm_dispatch<double>(ctx, real_op[opA & 3], real_op[opB & 3], m, n, k, (const double*)A, lda,
+                                 (const double*)B, ldb, (double*)C, ldc, bt);
 }
 
 int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t n, const void* A, int64_t lda,

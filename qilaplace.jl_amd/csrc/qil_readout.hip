@@ -217,6 +217,105 @@ __global__ void scale_real(double* p, long long n, double s) {
         p[t] *= s;
 }
 
+// ---- lazy read-out, GEMM form (many queries, large chi * D) ----------------------------------------------
+template <class TS>
+__global__ void widen_to_c64(const TS* __restrict__ src, c64* __restrict__ dst, long long n) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+        dst[t] = to_c64(src[t]);
+}
+template <class T>
+__global__ void lazy_finish(const T* __restrict__ M, long long nb, double amplitude, c64* __restrict__ out) {
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nb; q += (long long)gridDim.x * blockDim.x) {
+        const c64 v = to_c64(M[q]);
+        out[q] = c64{v.re * amplitude, v.im * amplitude};
+    }
+}
+
+// All queries advance together; per site two strided-batch MFMA GEMMs (batch = query):
+//   X_q[alpha, (s', s, b)] = M_q[alpha, a] W[a, (s', s, b)]                     (chi_l x D_l) (D_l x 4 D_r)
+//   M'_q[beta, b]          = sum_{(alpha, s')} A[(alpha, s'), beta] X_q[(alpha, s'), s = bit_q, b]
+// W and A are used exactly as they lie in HBM (the site layouts ARE these matrices); the second product
+// reads each query's own output-bit slice of X through the per-batch operand shift, so nothing is permuted
+// or gathered between the two.  The first product computes both output bits (2x of ~half the flops): the
+// price of keeping W as one contiguous operand.
+int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64_t nb, const uint8_t* dbits,
+                   c64* dout) {
+    const int64_t n = psi->n();
+    const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;
+    const int dt = (wc || ac) ? QIL_C64 : QIL_F64;
+    const size_t e = qil_elem_size(dt);
+    long long maxM = 1, maxX = 1, maxW = 1, maxA = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+        const long long Dl = W->dims[(size_t)i], Dr = W->dims[(size_t)i + 1];
+        maxM = std::max(maxM, std::max(cl * Dl, cr * Dr));
+        maxX = std::max(maxX, cl * 4 * Dr);
+        maxW = std::max(maxW, Dl * 4 * Dr);
+        maxA = std::max(maxA, cl * 2 * cr);
+    }
+    // queries per pass: bounded scratch (X is the big one) and the grid's batch limit
+    const long long per_query = (2 * maxM + maxX) * (long long)e;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nb, 32768), (8LL << 30) / per_query));
+    void *M0 = nullptr, *M1 = nullptr, *X = nullptr, *Wc = nullptr, *Ac = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(chunk * maxM) * e, &M0));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(chunk * maxM) * e, &M1));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(chunk * maxX) * e, &X));
+    if (dt == QIL_C64 && !wc) QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxW * 16, &Wc));
+    if (dt == QIL_C64 && !ac) QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxA * 16, &Ac));
+    int st = QIL_OK;
+    for (int64_t q0 = 0; q0 < nb && st == QIL_OK; q0 += chunk) {
+        const int64_t nq = std::min<int64_t>(chunk, nb - q0);
+        const unsigned g1 = (unsigned)std::min<long long>((nq + 255) / 256, 4096);
+        if (dt == QIL_C64) hipLaunchKernelGGL(fill_ones<c64>, dim3(g1), dim3(256), 0, ctx->stream, (c64*)M0, (long long)nq);
+        else hipLaunchKernelGGL(fill_ones<double>, dim3(g1), dim3(256), 0, ctx->stream, (double*)M0, (long long)nq);
+        void *Mc = M0, *Mn = M1;
+        for (int64_t i = 0; i < n && st == QIL_OK; ++i) {
+            const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+            const long long Dl = W->dims[(size_t)i], Dr = W->dims[(size_t)i + 1];
+            const void* Wp = W->site[(size_t)i];
+            const void* Ap = psi->site[(size_t)i];
+            if (Wc) {
+                hipLaunchKernelGGL(widen_to_c64<double>, dim3((unsigned)std::min<long long>((Dl * 4 * Dr + 255) / 256, 4096)),
+                                   dim3(256), 0, ctx->stream, (const double*)Wp, (c64*)Wc, Dl * 4 * Dr);
+                Wp = Wc;
+            }
+            if (Ac) {
+                hipLaunchKernelGGL(widen_to_c64<double>, dim3((unsigned)std::min<long long>((cl * 2 * cr + 255) / 256, 4096)),
+                                   dim3(256), 0, ctx->stream, (const double*)Ap, (c64*)Ac, cl * 2 * cr);
+                Ap = Ac;
+            }
+            qil_gemm_batch b1, b2;
+            b1.count = nq;
+            b1.a_bs = cl * Dl;
+            b1.c_bs = cl * 4 * Dr;
+            st = qil_dev_gemm_batched(ctx, dt, 0, 0, cl, 4 * Dr, Dl, Mc, cl, Wp, Dl, X, cl, &b1);
+            if (st != QIL_OK) break;
+            b2.count = nq;
+            b2.b_bs = cl * 4 * Dr;
+            b2.c_bs = cr * Dr;
+            b2.b_sel = dbits + q0 * n + i;
+            b2.b_sel_step = n;
+            b2.b_sel_stride = 2 * cl;
+            st = qil_dev_gemm_batched(ctx, dt, 1, 0, cr, Dr, 2 * cl, Ap, 2 * cl, X, 4 * cl, Mn, cr, &b2);
+            std::swap(Mc, Mn);
+        }
+        if (st != QIL_OK) break;
+        if (dt == QIL_C64)
+            hipLaunchKernelGGL(lazy_finish<c64>, dim3(g1), dim3(256), 0, ctx->stream, (const c64*)Mc, (long long)nq,
+                               psi->amplitude, dout + q0);
+        else
+            hipLaunchKernelGGL(lazy_finish<double>, dim3(g1), dim3(256), 0, ctx->stream, (const double*)Mc, (long long)nq,
+                               psi->amplitude, dout + q0);
+        if (hipGetLastError() != hipSuccess) st = qil_fail(QIL_EHIP, "lazy coefficient (GEMM form): launch failed");
+    }
+    qil_ctx_free(ctx, M0);
+    qil_ctx_free(ctx, M1);
+    qil_ctx_free(ctx, X);
+    if (Wc) qil_ctx_free(ctx, Wc);
+    if (Ac) qil_ctx_free(ctx, Ac);
+    return st;
+}
+
 int upload_bits(qil_context* ctx, int64_t nb, int64_t n, const uint8_t* bits, uint8_t** dbits, int max_bit = 1) {
     for (int64_t t = 0; t < nb * n; ++t)
         QIL_REQUIRE(bits[t] <= max_bit, QIL_EINVAL_CONFIG, "coefficient: bit value %d outside [0,%d]", (int)bits[t],
@@ -360,8 +459,20 @@ extern "C" int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi,
     QIL_TRY(upload_bits(ctx, nb, n, bits, &dbits));
     void *scratch = nullptr, *dout = nullptr, *pin = nullptr, *dtab = nullptr;
     int slot = 0;
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(4 * nb * msz) * 16, &scratch));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout));
+    // Many queries on a wide product bond: the per-query chains (one workgroup each, vector ALU) give way to
+    // batched MFMA GEMMs.  Tuning aid: QIL_LAZY_GEMM_MIN = smallest chi * D that takes the GEMM form.
+    static const long long lazy_min = getenv("QIL_LAZY_GEMM_MIN") ? atoll(getenv("QIL_LAZY_GEMM_MIN")) : 2048;
+    if (nb >= 16 && msz >= lazy_min) {
+        int st = lazy_gemm_path(ctx, W, psi, nb, dbits, (c64*)dout);
+        if (st == QIL_OK && hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+            st = qil_fail(QIL_EHIP, "apply_coefficient: download failed");
+        if (st == QIL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = qil_fail(QIL_EHIP, "sync failed");
+        qil_ctx_free(ctx, dout);
+        qil_ctx_free(ctx, dbits);
+        return st;
+    }
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(4 * nb * msz) * 16, &scratch));
     QIL_TRY(qil_ctx_desc_acquire(ctx, tab.size() * sizeof(ChainSite), &pin, &dtab, &slot));
     memcpy(pin, tab.data(), tab.size() * sizeof(ChainSite));
     QIL_HIP(hipMemcpyAsync(dtab, pin, tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, ctx->stream));

@@ -821,3 +821,21 @@ def test_svd_block_jacobi_path(qil, m, n, cplx, kind):
     live = S > 1e-10 * S[0]
     assert np.abs(U[:, live].conj().T @ U[:, live] - np.eye(live.sum())).max() < 1e-11
     assert np.abs(Vh[live] @ Vh[live].conj().T - np.eye(live.sum())).max() < 1e-11
+
+
+@pytest.mark.parametrize("wdt,adt", [(np.complex128, np.float64), (np.complex128, np.complex128),
+                                     (np.float64, np.float64), (np.float64, np.complex128)])
+def test_lazy_coefficient_gemm_form(qil, wdt, adt):
+    """coefficient(apply(W, psi), cfg) without materialising W psi (mps.jl:669-678 on apply.jl:75-122), at a
+    product bond wide enough (chi * D = 64 * 40 >= 2048) and with enough queries to take the batched-GEMM
+    form; odd bond sizes exercise the tile edges.  Checked against the materialised HIP result and the oracle."""
+    rng = np.random.default_rng(77)
+    L = 10
+    a = random_mps_data([2, 4, 8, 16, 33, 64, 37, 4, 2], rng, dtype=adt)
+    w = random_mpo_data([4, 16, 40, 40, 29, 40, 16, 4, 2], rng, dtype=wdt)
+    W, psi = qil.SingleSiteMPO(w), qil.SignalMPS(a, amplitude=2.5)
+    bits = rng.integers(0, 2, size=(200, L))
+    lazy = qil.apply_coefficient_batch(W, psi, bits)
+    mat = qil.coefficient_batch(W * psi, bits)
+    ref = O.coefficient_batch(O.apply(O.SingleSiteMPO(w), O.SignalMPS(a, amplitude=2.5)), bits)
+    assert rel(lazy, mat) < 1e-12 and rel(lazy, ref) < 1e-12
