@@ -178,6 +178,13 @@ int qil_canonicalize(qil_mps* psi, int direction, int64_t center, double cutoff,
 /* compress!(psi; maxdim, tol=1e-12, sweeps=1) src/mps.jl:913-999.  In place.        */
 int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps);
 
+/* zip_to_compress_mpo over a whole MPO, in place (src/transforms/dt_transformer.jl:167-288; the step the
+ * reference runs on the MPO x MPO product in zt_transformer.jl:103-104).  direction 0 = "down" (exact gauge
+ * sweep left -> right, truncating SVD sweep right -> left), 1 = "up" (mirror).  cutoff / maxdim follow the
+ * ITensors truncation rule (maxdim <= 0: no cap).  QIL_EINVAL_ARG for any other direction (the reference's
+ * `error("unknown direction")`).                                                                         */
+int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_t maxdim);
+
 /* Fused apply-and-truncate: the result of compress!(apply(W, psi); maxdim, tol, sweeps)
  * (apply.jl:75-122 followed by mps.jl:913-973) without materialising the (D chi)^2 product: a zip-up sweep
  * with intermediate bond cap zip_maxdim (<= 0: 2 maxdim) followed by the exact-gauge compress!.  Same error

@@ -154,6 +154,13 @@ function compress!(psi::DeviceMPS; maxdim::Int=typemax(Int), tol::Float64=1e-12,
     check(ccall((:qil_compress, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Cint), psi.h, maxdim, tol, sweeps))
     return psi
 end
+# zip_to_compress_mpo over a whole MPO (dt_transformer.jl:167-288), in place
+function compress_mpo!(W::DeviceMPO, direction::AbstractString="down"; cutoff::Float64=1e-14, maxdim::Int=1000)
+    direction in ("down", "up") || error("zip_to_compress_mpo: unknown direction '$direction'")
+    check(ccall((:qil_mpo_compress, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Int64), W.h,
+                direction == "down" ? 0 : 1, cutoff, maxdim))
+    return W
+end
 function canonicalize!(psi::DeviceMPS, direction::Symbol; center=nothing, cutoff::Float64=1e-12,
                        maxdim::Int=typemax(Int))                                                   # mps.jl:787
     direction in (:right, :left) || throw(ArgumentError("Direction must be :right or :left"))

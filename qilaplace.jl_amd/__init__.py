@@ -14,12 +14,13 @@ loudly if that library has not been built.
 from ._lib import QilError, QilDomainError, LIB_PATH, last_error  # noqa: F401
 from .containers import (Context, default_context, set_default_context, device_count,  # noqa: F401
                          SignalMPS, ZTMPS, SingleSiteMPO, PairedSiteMPO)
-from .ops import (apply, apply_compress, coefficient, coefficient_batch, apply_coefficient_batch,  # noqa: F401
+from .ops import (apply, apply_compress, mpo_compress, coefficient, coefficient_batch, apply_coefficient_batch,  # noqa: F401
                   marginal_batch, coefficient_grid, laplace_values,
                   mps_to_vector, norm, canonicalize, compress, signal_mps, signal_ztmps, rsvd,
                   svd_trunc, gemm, gemm_device_time, qr_positive)
 from .builders import (build_qft_mpo, build_dt_mpo, build_zt_mpo, qft_mpo_tensors,  # noqa: F401
-                       dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many, build_dt_mpo_batch)
+                       dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many, build_dt_mpo_batch,
+                       build_zt_mpo_batch, zt_qft_chain_tensors)
 from .interchange import save, load  # noqa: F401
 from .sweep import shard_items, sweep, damping_sweep, gather_results  # noqa: F401
 
@@ -29,7 +30,7 @@ __all__ = [
     "apply", "apply_compress", "coefficient", "coefficient_batch", "apply_coefficient_batch", "marginal_batch", "coefficient_grid", "laplace_values", "mps_to_vector", "norm",
     "canonicalize", "compress", "signal_mps", "signal_ztmps", "rsvd", "svd_trunc", "gemm",
     "build_qft_mpo", "build_dt_mpo", "build_zt_mpo", "qft_mpo_tensors", "dt_mpo_tensors", "zt_mpo_tensors",
-    "dt_mpo_tensors_many", "build_dt_mpo_batch",
+    "dt_mpo_tensors_many", "build_dt_mpo_batch", "build_zt_mpo_batch", "zt_qft_chain_tensors", "mpo_compress",
     "save", "load",
     "shard_items", "sweep", "damping_sweep", "gather_results",
     "QilError", "QilDomainError",

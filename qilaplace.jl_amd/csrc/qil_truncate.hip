@@ -74,7 +74,11 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
 }
 
 // ---------------------------------------------------------------- canonicalize!
-int canonicalize_impl(qil_mps* psi, int direction, int64_t center, double cutoff, int64_t maxdim) {
+// Works on any chain: the physical block is 2 (MPS site A[a,s,b]) or 4 (MPO site W[a,s',s,b]) wide and sits
+// between the two bonds in memory, so "rows (a, phys) | cols b" and "rows a | cols (phys, b)" are the site
+// buffer as it lies in both cases.
+int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cutoff, int64_t maxdim) {
+    const int64_t pd = psi->phys_rank == 1 ? 2 : 4;
     qil_context* ctx = psi->ctx;
     const int64_t N = psi->n();
     const int dt = psi->dtype;
@@ -88,11 +92,11 @@ int canonicalize_impl(qil_mps* psi, int direction, int64_t center, double cutoff
             int64_t r = 0;
             void *U = nullptr, *SV = nullptr;
             // rows (alpha, s) | cols beta : the site buffer as it lies
-            QIL_TRY(svd_trunc_dev(ctx, dt, 2 * cl, cr, psi->site[(size_t)i], 2 * cl, cutoff, true, maxdim, 1, 2, &r,
+            QIL_TRY(svd_trunc_dev(ctx, dt, pd * cl, cr, psi->site[(size_t)i], pd * cl, cutoff, true, maxdim, 1, 2, &r,
                                   &U, &SV, nullptr));
             void* next = nullptr;
-            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * 2 * cr2) * e, &next));
-            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, r, 2 * cr2, cr, SV, r, psi->site[(size_t)i + 1], cr, next, r));
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * pd * cr2) * e, &next));
+            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, r, pd * cr2, cr, SV, r, psi->site[(size_t)i + 1], cr, next, r));
             qil_ctx_free(ctx, SV);
             QIL_TRY(qil_chain_set_site(psi, i, U, cl, r));
             QIL_TRY(qil_chain_set_site(psi, i + 1, next, r, cr2));
@@ -106,12 +110,12 @@ int canonicalize_impl(qil_mps* psi, int direction, int64_t center, double cutoff
             int64_t r = 0;
             void *US = nullptr, *Vh = nullptr;
             // rows alpha | cols (s, beta)
-            QIL_TRY(svd_trunc_dev(ctx, dt, cl, 2 * cr, psi->site[(size_t)i], cl, cutoff, true, maxdim, 1, 1, &r,
+            QIL_TRY(svd_trunc_dev(ctx, dt, cl, pd * cr, psi->site[(size_t)i], cl, cutoff, true, maxdim, 1, 1, &r,
                                   &US, &Vh, nullptr));
             void* prev = nullptr;
-            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl0 * 2 * r) * e, &prev));
-            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, 2 * cl0, r, cl, psi->site[(size_t)i - 1], 2 * cl0, US, cl, prev,
-                                 2 * cl0));
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl0 * pd * r) * e, &prev));
+            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, pd * cl0, r, cl, psi->site[(size_t)i - 1], pd * cl0, US, cl, prev,
+                                 pd * cl0));
             qil_ctx_free(ctx, US);
             QIL_TRY(qil_chain_set_site(psi, i, Vh, r, cr));
             QIL_TRY(qil_chain_set_site(psi, i - 1, prev, cl0, r));
@@ -600,6 +604,27 @@ extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps
         std::vector<double> s((size_t)psi->dims[1], inv);
         QIL_TRY(qil_dev_scale(ctx, dt, 1, 2 * psi->dims[0], psi->dims[1], psi->site[0], 2 * psi->dims[0], s.data()));
     }
+    return QIL_OK;
+}
+
+// zip_to_compress_mpo over a whole MPO (dt_transformer.jl:167-288; called on the MPO x MPO product in
+// zt_transformer.jl:103-104): an exact gauge sweep towards one end, then a truncating sweep back.  In the gauged
+// chain the reference's two-site core has the singular values of the single site next to the centre, so the
+// truncating sweep is the same one-site sweep compress! uses.  direction 0 = "down" (gauge left -> right, truncate
+// right -> left), 1 = "up" (mirror image).  The gauge sweep runs with cutoff 0: only exactly-zero singular
+// values (rank-deficient bonds of a product) are dropped.
+extern "C" int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_t maxdim) {
+    QIL_REQUIRE(W, QIL_EINVAL_ARG, "mpo_compress: null argument");
+    QIL_REQUIRE(direction == 0 || direction == 1, QIL_EINVAL_ARG,
+                "zip_to_compress_mpo: unknown direction %d (0 = down, 1 = up)", direction);
+    QIL_REQUIRE(cutoff >= 0, QIL_EINVAL_ARG, "mpo_compress: cutoff must be >= 0");
+    if (W->n() < 2) return QIL_OK;
+    QIL_TRY(qil_ctx_activate(W->ctx));
+    if (maxdim <= 0) maxdim = kNoCap;
+    const int gauge = direction == 0 ? QIL_DIR_RIGHT : QIL_DIR_LEFT;
+    const int trunc = direction == 0 ? QIL_DIR_LEFT : QIL_DIR_RIGHT;
+    QIL_TRY(canonicalize_impl(W, gauge, 0, 0.0, kNoCap));
+    QIL_TRY(canonicalize_impl(W, trunc, 0, cutoff, maxdim));
     return QIL_OK;
 }
 

@@ -216,6 +216,15 @@ def compress(psi, maxdim=None, tol=1e-12, sweeps=1):
     return psi
 
 
+def mpo_compress(W, direction="down", cutoff=1e-14, maxdim=None):
+    """zip_to_compress_mpo(W, direction; cutoff, maxdim) over the whole MPO (dt_transformer.jl:167-288) -- in
+    place, returns W.  "down": exact gauge sweep left -> right, truncating sweep right -> left; "up": mirror."""
+    if direction not in ("down", "up"):
+        raise ValueError(f"zip_to_compress_mpo: unknown direction '{direction}'")
+    L.check(L.lib.qil_mpo_compress(W.handle, 0 if direction == "down" else 1, float(cutoff), _maxdim(maxdim)))
+    return W
+
+
 def apply_compress(W, psi, maxdim=None, tol=1e-12, sweeps=1, zip_maxdim=None):
     """compress(apply(W, psi), maxdim, tol, sweeps) fused: a zip-up sweep that never writes the (D chi)^2
     product tensors, then the exact-gauge compress.  (The reference's `apply` ignores cutoff/maxdim, and so

@@ -839,3 +839,51 @@ def test_lazy_coefficient_gemm_form(qil, wdt, adt):
     mat = qil.coefficient_batch(W * psi, bits)
     ref = O.coefficient_batch(O.apply(O.SingleSiteMPO(w), O.SignalMPS(a, amplitude=2.5)), bits)
     assert rel(lazy, mat) < 1e-12 and rel(lazy, ref) < 1e-12
+
+
+def test_mpo_compress_matches_host_zip_to_compress(qil):
+    """zip_to_compress_mpo over a whole chain (dt_transformer.jl:167-288) on the device: the MPO x MPO product of
+    a DT and a paired-QFT MPO (zt_transformer.jl:103) compressed "down" and "up" keeps the operator, and gives
+    the bond dimensions of the oracle's restatement of the same step."""
+    n, wr = 5, 1.7
+    Wdt = O.build_dt_mpo(n, wr, cutoff=1e-14)
+    Wq = O.build_zt_mpo(n, 0.0, cutoff=1e-14)          # any second paired MPO with complex entries
+    prod = O.apply_mpo_mpo(Wdt, Wq)
+    from oracle.builders import _compress
+    rng = np.random.default_rng(9)
+    a = random_mps_data(saturated_profile(2 * n, 4), rng)
+    bits = rng.integers(0, 2, size=(64, 2 * n))
+    ref = O.coefficient_batch(O.apply(prod, O.ZTMPS(a)), bits)
+    for direction in ("down", "up"):
+        want = _compress(list(prod.data), direction, 1e-13, 1000)
+        W = qil.PairedSiteMPO([np.array(t) for t in prod.data])
+        got = qil.mpo_compress(W, direction, cutoff=1e-13, maxdim=1000)
+        assert got is W
+        assert W.bond_dims == [t.shape[3] for t in want[:-1]]
+        got_c = qil.coefficient_batch(W * qil.ZTMPS(a), bits)
+        assert rel(got_c, ref) < 1e-5                                   # truncation at cutoff 1e-13 per bond
+        assert rel(got_c, O.coefficient_batch(O.apply(O.PairedSiteMPO(want), O.ZTMPS(a)), bits)) < 1e-9
+    W = qil.PairedSiteMPO([np.array(t) for t in prod.data])
+    qil.mpo_compress(W, "down", cutoff=1e-13, maxdim=7)
+    assert max(W.bond_dims) <= 7
+    with pytest.raises(ValueError):
+        qil.mpo_compress(W, "sideways")
+
+
+def test_build_zt_mpo_batch_device_assisted(qil, pins):
+    """build_zt_mpo for several damping values with the DT halves, the MPO x MPO product and the final
+    compression on the device: same operators as the host builder, and the reference's own max-bond series
+    (mpo_bond_dim.jld2: 8, 8, 37, 39, 78 for n = 2..6 at wr = 2 pi, cutoff 1e-15) for the default damping."""
+    series = pins["mpo_maxbond_n2_30"]["zt"]
+    for n in (2, 3, 4, 5, 6):
+        W = qil.build_zt_mpo_batch(n, [2 * np.pi], cutoff=1e-15, maxdim=None)[0]    # the artifact's settings
+        assert max(W.bond_dims) == series[n - 2]
+    n, wrs = 5, [0.3, 2 * np.pi, 11.0]
+    rng = np.random.default_rng(4)
+    a = random_mps_data(saturated_profile(2 * n, 6), rng)
+    psi = qil.ZTMPS(a)
+    bits = rng.integers(0, 2, size=(128, 2 * n))
+    Ws = qil.build_zt_mpo_batch(psi, wrs, cutoff=1e-14, maxdim=1000)
+    for W, wr in zip(Ws, wrs):
+        host = qil.build_zt_mpo(psi, wr, cutoff=1e-14, maxdim=1000)
+        assert rel(qil.coefficient_batch(W * psi, bits), qil.coefficient_batch(host * psi, bits)) < 1e-9
