@@ -886,8 +886,9 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     // (the classical preconditioning of one-sided Jacobi); then R^H = L S V^H gives Wk = (Q V) S L^H.
     static const long long bj_min = getenv("QIL_BJ_MIN") ? atoll(getenv("QIL_BJ_MIN")) : 512;   // tuning aids
     static const bool bj_rt = !(getenv("QIL_BJ_RT") && atoi(getenv("QIL_BJ_RT")) == 0);
+    static const long long rt_min = getenv("QIL_RT_MIN") ? atoll(getenv("QIL_RT_MIN")) : (1LL << 40);
     const bool blocked = cols >= bj_min;
-    const bool rt = blocked && bj_rt;
+    const bool rt = (blocked && bj_rt) || cols >= rt_min;
     T* Q = nullptr;
     long long ldq = 0, qrows = 0;
     void *rbuf = nullptr, *rtbuf = nullptr;
