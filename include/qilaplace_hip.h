@@ -81,6 +81,12 @@ int qil_context_synchronize(qil_context* ctx);
 int qil_context_trim(qil_context* ctx);
 int qil_context_mem_info(qil_context* ctx, int64_t* pool_bytes_in_use, int64_t* pool_bytes_cached,
                          int64_t* device_free, int64_t* device_total);
+/* Testing aid: the n-th pool allocation from now (0 = the next one) fails with QIL_ENOMEM; n < 0 switches the
+ * injection off.  Used to check that a failing call leaves no device memory behind and its operands intact. */
+int qil_context_fail_alloc_after(qil_context* ctx, int64_t n);
+/* Testing aid: pool bytes in use that no MPS/MPO handle owns.  Zero between calls -- every temporary is back in
+ * the pool whether the last call succeeded or failed.                                                        */
+int qil_context_unowned_bytes(qil_context* ctx, int64_t* out);
 
 /* HIP-event timing on the context's stream (hipEventRecord / hipEventElapsedTime). */
 int qil_timer_start(qil_context* ctx);

@@ -38,6 +38,16 @@ class Context:
         L.check(L.lib.qil_context_mem_info(self.handle, *[C.byref(x) for x in v]))
         return dict(zip(("pool_in_use", "pool_cached", "device_free", "device_total"), (x.value for x in v)))
 
+    def unowned_bytes(self) -> int:
+        """Testing aid: pool bytes in use that no MPS/MPO handle owns (0 between calls)."""
+        v = C.c_int64()
+        L.check(L.lib.qil_context_unowned_bytes(self.handle, C.byref(v)))
+        return v.value
+
+    def fail_alloc_after(self, n):
+        """Testing aid: make the n-th pool allocation from now fail (None / negative: off)."""
+        L.check(L.lib.qil_context_fail_alloc_after(self.handle, -1 if n is None else int(n)))
+
     def timer_start(self):
         L.check(L.lib.qil_timer_start(self.handle))
 

@@ -360,6 +360,7 @@ extern "C" int qil_apply_into(const qil_mpo* W, const qil_mps* psi, qil_mps* out
                     "qil_apply_into: output bond %lld has dimension %lld, expected %lld", (long long)i,
                     (long long)out->dims[(size_t)i], (long long)(W->dims[(size_t)i] * psi->dims[(size_t)i]));
     QIL_TRY(qil_ctx_activate(W->ctx));
+    qil_call_scope call_scope(W->ctx);
     out->amplitude = psi->amplitude;  // apply.jl:121, :216
     out->site_ids = psi->site_ids;
     out->paired = psi->paired;
@@ -390,6 +391,7 @@ extern "C" int qil_apply_mpo_mpo(const qil_mpo* W1, const qil_mpo* W2, qil_mpo**
     QIL_REQUIRE(W1->paired == W2->paired, QIL_EINVAL_ARG, "apply: cannot mix paired and single-site MPOs");
     qil_context* ctx = W1->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const int64_t n1 = W1->n(), n2 = W2->n();
     // 1. window (apply.jl:128-139)
     int64_t start1 = -1, start2 = -1;

@@ -696,6 +696,7 @@ extern "C" int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, c
     QIL_REQUIRE(n >= 1, QIL_EINVAL_ARG, "build_dt_mpo: n must be >= 1. Found n=%lld", (long long)n);
     QIL_REQUIRE(nb >= 1 && nb <= 4096, QIL_EINVAL_ARG, "build_dt_mpo: batch of %lld damping values", (long long)nb);
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     Builder bd{ctx, (int)nb, cutoff, maxdim <= 0 ? INT64_MAX : maxdim};
     const int B = (int)nb;
     std::vector<BSite> M;

@@ -5,6 +5,8 @@
 
 // ---------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
+static thread_local unsigned g_fail_count = 0;
+unsigned qil_fail_count() { return g_fail_count; }
 
 void qil_set_error(const char* fmt, ...) {
     va_list ap;
@@ -18,6 +20,7 @@ int qil_fail(int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    ++g_fail_count;
     return code;
 }
 
@@ -84,7 +87,7 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->free_blocks) hipFree(kv.second);
-    for (auto& kv : ctx->live_blocks) hipFree(kv.first);  // leaked handles
+    for (auto& kv : ctx->live_blocks) hipFree(kv.first);  // handles the caller never destroyed
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->dev_scratch) hipFree(ctx->dev_scratch);
     if (ctx->desc_host) hipHostFree(ctx->desc_host);
@@ -115,7 +118,24 @@ extern "C" int qil_context_mem_info(qil_context* ctx, int64_t* in_use, int64_t* 
     return QIL_OK;
 }
 
+extern "C" int qil_context_unowned_bytes(qil_context* ctx, int64_t* out) {
+    QIL_REQUIRE(ctx && out, QIL_EINVAL_ARG, "null argument");
+    int64_t tot = 0;
+    for (const auto& kv : ctx->live_blocks)
+        if (!kv.second.owned) tot += (int64_t)kv.second.bytes;
+    *out = tot;
+    return QIL_OK;
+}
+
+extern "C" int qil_context_fail_alloc_after(qil_context* ctx, int64_t n) {
+    QIL_REQUIRE(ctx, QIL_EINVAL_ARG, "null context");
+    ctx->fail_alloc_countdown = n;
+    return QIL_OK;
+}
+
 int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out) {
+    if (ctx->fail_alloc_countdown >= 0 && ctx->fail_alloc_countdown-- == 0)
+        return qil_fail(QIL_ENOMEM, "injected allocation failure (qil_context_fail_alloc_after)");
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~(size_t)255;
     auto it = ctx->free_blocks.find(bytes);
@@ -140,7 +160,7 @@ int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out) {
                             "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         }
     }
-    ctx->live_blocks[*out] = bytes;
+    ctx->live_blocks[*out] = qil_context::live_block{bytes, ++ctx->alloc_serial, false};
     ctx->bytes_in_use += bytes;
     return QIL_OK;
 }
@@ -150,13 +170,42 @@ int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out) {
 int qil_ctx_free(qil_context* ctx, void* p) {
     if (!p) return QIL_OK;
     auto it = ctx->live_blocks.find(p);
-    if (it == ctx->live_blocks.end()) return qil_fail(QIL_EINVAL_ARG, "qil_ctx_free: unknown block");
-    size_t bytes = it->second;
+    if (it == ctx->live_blocks.end()) {
+        // not counted as a call failure: cleanup code may free a block the error path already reclaimed
+        qil_set_error("qil_ctx_free: unknown block");
+        return QIL_EINVAL_ARG;
+    }
+    size_t bytes = it->second.bytes;
     ctx->live_blocks.erase(it);
     ctx->bytes_in_use -= bytes;
     ctx->free_blocks.emplace(bytes, p);
     ctx->bytes_cached += bytes;
     return QIL_OK;
+}
+
+static void mark_owned(qil_context* ctx, void* p) {
+    auto it = ctx->live_blocks.find(p);
+    if (it != ctx->live_blocks.end()) it->second.owned = true;
+}
+
+qil_call_scope::qil_call_scope(qil_context* c)
+    : ctx(c), serial0(c ? c->alloc_serial : 0), fails0(qil_fail_count()) {}
+
+qil_call_scope::~qil_call_scope() {
+    if (!ctx || qil_fail_count() == fails0) return;
+    // the call failed: nothing it allocated for itself may survive it.  Work that still touches these blocks
+    // was enqueued on the context's stream, and the pool recycles in stream order, so this is safe without
+    // waiting.
+    for (auto it = ctx->live_blocks.begin(); it != ctx->live_blocks.end();) {
+        if (it->second.serial > serial0 && !it->second.owned) {
+            ctx->bytes_in_use -= it->second.bytes;
+            ctx->free_blocks.emplace(it->second.bytes, it->first);
+            ctx->bytes_cached += it->second.bytes;
+            it = ctx->live_blocks.erase(it);
+        } else {
+            ++it;
+        }
+    }
 }
 
 int qil_ctx_pinned(qil_context* ctx, size_t bytes, void** out) {
@@ -310,6 +359,7 @@ int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int pa
             qil_chain_release(c);
             return s;
         }
+        mark_owned(ctx, c->site[(size_t)i]);
     }
     return QIL_OK;
 }
@@ -326,9 +376,15 @@ int qil_chain_release(qil_chain* c) {
 int qil_chain_set_site(qil_chain* c, int64_t i, void* p, int64_t dl, int64_t dr) {
     if (c->site[(size_t)i]) QIL_TRY(qil_ctx_free(c->ctx, c->site[(size_t)i]));
     c->site[(size_t)i] = p;
+    mark_owned(c->ctx, p);
     c->dims[(size_t)i] = dl;
     c->dims[(size_t)i + 1] = dr;
     return QIL_OK;
+}
+
+void qil_chain_adopt(qil_chain* c, int64_t i, void* p) {
+    c->site[(size_t)i] = p;
+    mark_owned(c->ctx, p);
 }
 
 template <class H>

@@ -44,7 +44,14 @@ struct qil_context {
     bool owns_stream = false;
     // caching pool: exact-size free lists (apply outputs recur with identical sizes)
     std::multimap<size_t, void*> free_blocks;
-    std::map<void*, size_t> live_blocks;
+    struct live_block {
+        size_t bytes;
+        uint64_t serial;   // allocation order (error-path reclamation, see qil_call_scope)
+        bool owned;        // attached to a chain handle: outlives the call that allocated it
+    };
+    std::map<void*, live_block> live_blocks;
+    uint64_t alloc_serial = 0;
+    int64_t fail_alloc_countdown = -1;   // fault injection (qil_context_fail_alloc_after); < 0 = off
     size_t bytes_in_use = 0, bytes_cached = 0;
     // pinned staging for small descriptor / bit uploads
     void* pinned = nullptr;
@@ -106,6 +113,23 @@ int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int pa
 int qil_chain_release(qil_chain* c);
 // replace site i's buffer (takes ownership of `p`), updating the bond dims
 int qil_chain_set_site(qil_chain* c, int64_t i, void* p, int64_t dl, int64_t dr);
+// attach a pool block to an EMPTY site slot of a chain under construction (ownership moves to the chain)
+void qil_chain_adopt(qil_chain* c, int64_t i, void* p);
+
+// Error-path reclamation.  Every C entry point opens one of these; temporaries come from the context pool and
+// are released explicitly on the success path.  If the call FAILS (qil_fail ran on this thread while the scope
+// was open), the destructor returns to the pool every block that was allocated during the call and is not
+// owned by a chain handle -- so an early `return status` can never strand device memory.
+unsigned qil_fail_count();
+struct qil_call_scope {
+    qil_context* ctx;
+    uint64_t serial0;
+    unsigned fails0;
+    explicit qil_call_scope(qil_context* c);
+    ~qil_call_scope();
+    qil_call_scope(const qil_call_scope&) = delete;
+    qil_call_scope& operator=(const qil_call_scope&) = delete;
+};
 
 // ---------------------------------------------------------------- device linear algebra (qil_linalg.hip)
 // All matrices column-major on the device, dtype QIL_F64/QIL_C64.

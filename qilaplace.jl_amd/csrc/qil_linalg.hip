@@ -1282,6 +1282,7 @@ extern "C" int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m
     QIL_REQUIRE(m >= 1 && n >= 1 && k >= 1, QIL_EINVAL_ARG, "gemm: empty operand");
     QIL_REQUIRE(opA >= 0 && opA <= 3 && opB >= 0 && opB <= 3, QIL_EINVAL_ARG, "gemm: bad op code");
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const size_t e = qil_elem_size(dtype);
     const int64_t a_cols = (opA == 0 || opA == 3) ? k : m, b_cols = (opB == 0 || opB == 3) ? n : k;
     void *dA = nullptr, *dB = nullptr, *dC = nullptr;
@@ -1306,6 +1307,7 @@ extern "C" int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n
     QIL_REQUIRE(ctx && A && Q && R, QIL_EINVAL_ARG, "qr: null argument");
     QIL_REQUIRE(m >= n && n >= 1, QIL_EINVAL_ARG, "qr: needs m >= n >= 1 (got %lld x %lld)", (long long)m, (long long)n);
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const size_t e = qil_elem_size(dtype);
     void *dA = nullptr, *dR = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
@@ -1326,6 +1328,7 @@ extern "C" int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int op
                                     int reps, double* ms_per_call) {
     QIL_REQUIRE(ctx && ms_per_call && reps >= 1, QIL_EINVAL_ARG, "gemm_device_time: bad argument");
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const size_t e = qil_elem_size(dtype);
     const int64_t a_rows = (opA == 0 || opA == 3) ? m : k, a_cols = (opA == 0 || opA == 3) ? k : m;
     const int64_t b_rows = (opB == 0 || opB == 3) ? k : n, b_cols = (opB == 0 || opB == 3) ? n : k;

@@ -352,6 +352,7 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
     if (nb == 0) return QIL_OK;
     qil_context* ctx = psi->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const int64_t n = psi->n();
     std::vector<ChainSite> tab((size_t)n);
     long long maxchi = 1;
@@ -444,6 +445,7 @@ extern "C" int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi,
     if (nb == 0) return QIL_OK;
     qil_context* ctx = psi->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const int64_t n = psi->n();
     std::vector<ChainSite> tab((size_t)n);
     long long msz = 1;
@@ -499,6 +501,7 @@ extern "C" int qil_mps_to_vector(const qil_mps* psi, int reverse, void* host_out
     QIL_REQUIRE(psi && host_out, QIL_EINVAL_ARG, "mps_to_vector: null argument");
     qil_context* ctx = psi->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const int64_t n = psi->n();
     QIL_REQUIRE(n <= 34, QIL_EINVAL_LENGTH, "mps_to_vector: %lld sites is too many for a dense vector", (long long)n);
     const size_t esz = qil_elem_size(psi->dtype);
@@ -544,6 +547,7 @@ extern "C" int qil_norm(const qil_mps* psi, double* out) {
     QIL_REQUIRE(psi && out, QIL_EINVAL_ARG, "norm: null argument");
     qil_context* ctx = psi->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const int64_t n = psi->n();
     const size_t esz = qil_elem_size(psi->dtype);
     long long maxchi = 1;

@@ -335,6 +335,7 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
                 "tensor_to_mps: unknown method %d. Use :svd or :rsvd.", P.method);
     QIL_REQUIRE(len >= 1, QIL_EINVAL_LENGTH, "signal_mps: empty signal");
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     // _array_to_tensor (SignalConverters.jl:16-46): n = round(log2 N), zero-fill, normalise
     const int64_t n = std::max<int64_t>(1, (int64_t)std::llround(std::log2((double)len)));
     const int64_t N = 1LL << n;
@@ -391,7 +392,8 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
     psi->paired = 0;
     psi->phys_rank = 1;
     psi->dims = dims;
-    psi->site = sites;
+    psi->site.assign(sites.size(), nullptr);
+    for (size_t i = 0; i < sites.size(); ++i) qil_chain_adopt(psi, (int64_t)i, sites[i]);
     psi->site_ids.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) psi->site_ids[(size_t)i] = i + 1;
     psi->amplitude = amp;
@@ -477,6 +479,7 @@ extern "C" int qil_canonicalize(qil_mps* psi, int direction, int64_t center, dou
     QIL_REQUIRE(direction == QIL_DIR_RIGHT || direction == QIL_DIR_LEFT, QIL_EINVAL_ARG,
                 "Direction must be :right or :left");
     QIL_TRY(qil_ctx_activate(psi->ctx));
+    qil_call_scope call_scope(psi->ctx);
     // the ZTMPS method forwards `center` unchanged to the 2n-site chain (mps.jl:880-881)
     return canonicalize_impl(psi, direction, center, cutoff, maxdim);
 }
@@ -505,6 +508,7 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
     QIL_REQUIRE(sweeps >= 1, QIL_EINVAL_ARG, "compress!: sweeps must be >= 1");
     qil_context* ctx = psi->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     if (maxdim <= 0) maxdim = kNoCap;
     if (zip_maxdim <= 0) zip_maxdim = maxdim > kNoCap / 2 ? kNoCap : 2 * maxdim;
     const double cutoff = tol * tol / ((double)(N - 1) * sweeps);
@@ -549,7 +553,7 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
         qil_ctx_free(ctx, Rm);
         Rm = nullptr;
         if (i + 1 == N) {                       // last site: theta is (R, 2, 1)
-            res->site[(size_t)i] = theta;
+            qil_chain_adopt(res, i, theta);
             res->dims[(size_t)i] = R;
             break;
         }
@@ -559,7 +563,7 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
                            &SV, nullptr);
         qil_ctx_free(ctx, theta);
         if (st != QIL_OK) break;
-        res->site[(size_t)i] = U;               // [R, s, r]
+        qil_chain_adopt(res, i, U);             // [R, s, r]
         res->dims[(size_t)i] = R;
         res->dims[(size_t)i + 1] = r;
         Rm = SV;                                // [r, (beta, b)] == R[r, alpha, a] of the next site
@@ -583,6 +587,7 @@ extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps
     QIL_REQUIRE(sweeps >= 1, QIL_EINVAL_ARG, "compress!: sweeps must be >= 1");
     qil_context* ctx = psi->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const int dt = psi->dtype;
     const double cutoff = tol * tol / ((double)(N - 1) * sweeps);               // mps.jl:920
     QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, 1e-12, kNoCap));            // mps.jl:923
@@ -620,6 +625,7 @@ extern "C" int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_
     QIL_REQUIRE(cutoff >= 0, QIL_EINVAL_ARG, "mpo_compress: cutoff must be >= 0");
     if (W->n() < 2) return QIL_OK;
     QIL_TRY(qil_ctx_activate(W->ctx));
+    qil_call_scope call_scope(W->ctx);
     if (maxdim <= 0) maxdim = kNoCap;
     const int gauge = direction == 0 ? QIL_DIR_RIGHT : QIL_DIR_LEFT;
     const int trunc = direction == 0 ? QIL_DIR_LEFT : QIL_DIR_RIGHT;
@@ -633,6 +639,7 @@ extern "C" int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t
     QIL_REQUIRE(ctx && A && rank && U && S && Vh, QIL_EINVAL_ARG, "svd: null argument");
     QIL_REQUIRE(m >= 1 && n >= 1, QIL_EEMPTY, "svd: empty matrix");
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const size_t e = qil_elem_size(dtype);
     void* dA = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
@@ -662,6 +669,7 @@ extern "C" int qil_rsvd(qil_context* ctx, const void* A, int64_t m, int64_t n, i
                 "In `rsvd`, left or right index set is empty.");               // rsvd.jl:56-60
     QIL_REQUIRE(k >= 1 && p >= 0 && q >= 0, QIL_EINVAL_ARG, "rsvd: need k >= 1, p >= 0, q >= 0");
     QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
     const size_t e = qil_elem_size(dtype);
     void *dA = nullptr, *Z = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
@@ -708,7 +716,8 @@ extern "C" int qil_signal_mps(qil_context* ctx, const void* x, int64_t len, int 
 extern "C" int qil_signal_ztmps(qil_context* ctx, const void* x, int64_t len, int dtype, int method,
                                 double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed,
                                 int64_t mindim, qil_mps** out) {
-    QIL_REQUIRE(out, QIL_EINVAL_ARG, "signal_ztmps: null out");
+    QIL_REQUIRE(ctx && out, QIL_EINVAL_ARG, "signal_ztmps: null argument");
+    qil_call_scope call_scope(ctx);
     EncodeParams P{method, cutoff, maxdim <= 0 ? kNoCap : maxdim, k, p, q, seed, mindim < 1 ? 1 : mindim};
     qil_mps* sig = nullptr;
     QIL_TRY(signal_mps_impl(ctx, x, len, dtype, P, &sig));                        // SignalConverters.jl:251
@@ -742,8 +751,8 @@ extern "C" int qil_signal_ztmps(qil_context* ctx, const void* x, int64_t len, in
                                nullptr);
         qil_ctx_free(ctx, T);
         if (status != QIL_OK) break;
-        zt->site[(size_t)(2 * i)] = U;        // core_main [b_{i-1}, s_main, c]
-        zt->site[(size_t)(2 * i + 1)] = SV;   // core_copy [c, s_copy, b_i]
+        qil_chain_adopt(zt, 2 * i, U);        // core_main [b_{i-1}, s_main, c]
+        qil_chain_adopt(zt, 2 * i + 1, SV);   // core_copy [c, s_copy, b_i]
         zt->dims[(size_t)(2 * i)] = cl;
         zt->dims[(size_t)(2 * i + 1)] = r;
         zt->dims[(size_t)(2 * i + 2)] = cr;

@@ -23,6 +23,13 @@ def qil():
     return q
 
 
+@pytest.fixture(autouse=True)
+def _no_stranded_temporaries(qil):
+    """After every test: all pool memory in use belongs to some MPS/MPO handle (no temporary outlives a call)."""
+    yield
+    assert qil.default_context().unowned_bytes() == 0
+
+
 def rel(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(np.asarray(b)).max())
 
@@ -887,3 +894,66 @@ def test_build_zt_mpo_batch_device_assisted(qil, pins):
     for W, wr in zip(Ws, wrs):
         host = qil.build_zt_mpo(psi, wr, cutoff=1e-14, maxdim=1000)
         assert rel(qil.coefficient_batch(W * psi, bits), qil.coefficient_batch(host * psi, bits)) < 1e-9
+
+
+def test_failed_calls_leave_no_device_memory_behind(qil):
+    """Error-path reclamation: whichever allocation inside a call fails, the pool's in-use byte count returns to
+    what the live handles account for, in-place operands stay usable, and the same call succeeds afterwards."""
+    ctx = qil.default_context()
+    rng = np.random.default_rng(12)
+    L = 8
+    a = random_mps_data(saturated_profile(L, 16), rng)
+    w = random_mpo_data(saturated_profile(L, 12, base=4), rng)
+    x = rng.standard_normal(1 << 12)
+    bits = rng.integers(0, 2, size=(64, L))
+    big = random_mps_data([2, 4, 8, 16, 32, 64, 128, 256, 300, 256, 128, 64, 32, 16, 8, 4, 2], rng)
+    bits_big = rng.integers(0, 2, size=(32, 18))
+    A = rng.standard_normal((700, 520))
+
+    def ops(psi, W, wide):
+        return [
+            ("apply", lambda: W * psi),
+            ("apply_compress", lambda: qil.apply_compress(W, psi, maxdim=8, tol=1e-8)),
+            ("compress", lambda: qil.compress(psi, maxdim=4, tol=1e-6)),
+            ("canonicalize", lambda: qil.canonicalize(psi, "left")),
+            ("coefficient_batch", lambda: qil.coefficient_batch(psi, bits)),
+            ("coefficient_batch (GEMM form)", lambda: qil.coefficient_batch(wide, bits_big)),
+            ("apply_coefficient_batch", lambda: qil.apply_coefficient_batch(W, psi, bits)),
+            ("mps_to_vector", lambda: qil.mps_to_vector(psi)),
+            ("norm", lambda: qil.norm(psi)),
+            ("signal_mps svd", lambda: qil.signal_mps(x, method="svd", cutoff=1e-12)),
+            ("signal_mps rsvd", lambda: qil.signal_mps(x, method="rsvd", k=12, p=4, q=1)),
+            ("signal_ztmps", lambda: qil.signal_ztmps(x, cutoff=1e-10, maxdim=16)),
+            ("svd_trunc (block path)", lambda: qil.svd_trunc(A, cutoff=1e-12)),
+            ("build_dt_mpo_batch", lambda: qil.build_dt_mpo_batch(4, [0.5, 1.5])),
+        ]
+
+    names = [n for n, _ in ops(None, None, None)]
+    import gc
+    fn = None
+    for idx, name in enumerate(names):
+        fn = psi = W = wide = None                       # drop the previous round's handles (closures hold them)
+        gc.collect()
+        psi, W, wide = qil.SignalMPS(a), qil.SingleSiteMPO(w), qil.SignalMPS(big)
+        assert ctx.unowned_bytes() == 0
+        failures = 0
+        for k in list(range(0, 12)) + [20, 40, 80, 160]:
+            fn = ops(psi, W, wide)[idx][1]
+            ctx.fail_alloc_after(k)
+            try:
+                out = fn()
+                failed = False
+            except MemoryError:
+                failed = True
+            finally:
+                ctx.fail_alloc_after(None)
+            if not failed:
+                del out
+                break                                    # the call needs fewer than k allocations
+            failures += 1
+            assert ctx.unowned_bytes() == 0, (name, k)      # every temporary is back in the pool
+            assert np.isfinite(qil.norm(psi))            # in-place operands are still whole chains
+        assert failures >= 1, name
+        res = ops(psi, W, wide)[idx][1]()               # and the call works afterwards
+        assert ctx.unowned_bytes() == 0, name
+        del res
