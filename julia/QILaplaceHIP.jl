@@ -10,7 +10,7 @@ using ITensors
 import ITensors: apply
 import Base: *, getindex, length
 import LinearAlgebra: norm
-using ..Mps: SignalMPS, ZTMPS, _as_signal_2n
+using ..Mps: SignalMPS, ZTMPS, _as_signal_2n, _writeback_signal_2n
 using ..Mpo: SingleSiteMPO, PairedSiteMPO
 using ..ApplyMPO: _as_single_site_mpo
 
@@ -195,6 +195,71 @@ function signal_mps_device(x::AbstractVector{<:Number}; method::Symbol=:svd, cut
     n = round(Int, log2(length(xs)))
     sites = [Index(2; tags="site-$i") for i in 1:(paired ? 2n : n)]
     return finalizer(_free!, DeviceMPS(r[], sites, paired))
+end
+
+# ---------------------------------------------------------------- back to the reference's host types
+# Site tensors come back in the canonical order (left bond, s, right bond); fresh bond Indices are made
+# (the reference does the same after every apply: apply.jl:105-119) and the site Indices are the shared ones.
+function to_host(psi::DeviceMPS)
+    n = length(psi.sites)
+    dims = Vector{Int64}(undef, max(n - 1, 0))
+    check(ccall((:qil_mps_bond_dims, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), psi.h, dims))
+    d = Ref{Cint}(0)
+    check(ccall((:qil_mps_dtype, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), psi.h, d))
+    T = d[] == 1 ? ComplexF64 : Float64
+    amp = Ref{Cdouble}(0)
+    check(ccall((:qil_mps_amplitude, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}), psi.h, amp))
+    bonds = [Index(Int(dims[i]); tags="bond-$i") for i in 1:(n - 1)]
+    data = Vector{ITensor}(undef, n)
+    for i in 1:n
+        dl = i == 1 ? 1 : Int(dims[i - 1])
+        dr = i == n ? 1 : Int(dims[i])
+        A = Array{T}(undef, dl, 2, dr)
+        check(ccall((:qil_mps_download_site, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}), psi.h, i - 1, A))
+        if n == 1
+            data[i] = ITensor(A[1, :, 1], psi.sites[i])
+        elseif i == 1
+            data[i] = ITensor(A[1, :, :], psi.sites[i], bonds[i])
+        elseif i == n
+            data[i] = ITensor(A[:, :, 1], bonds[i - 1], psi.sites[i])
+        else
+            data[i] = ITensor(A, bonds[i - 1], psi.sites[i], bonds[i])
+        end
+    end
+    sig = SignalMPS(data, psi.sites, bonds; amplitude=amp[])                    # mps.jl:75
+    return psi.paired ? _writeback_signal_2n(sig) : sig                     # mps.jl:447-472
+end
+
+# ---------------------------------------------------------------- beyond the reference's surface (SURVEY 8f)
+# compress!(apply(W, psi); maxdim, tol, sweeps) without materialising the (D chi)^2 product
+function apply_compress(W::DeviceMPO, psi::DeviceMPS; maxdim::Int=typemax(Int), tol::Float64=1e-12,
+                        sweeps::Int=1, zip_maxdim::Int=0)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:qil_apply_compress, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cdouble, Cint, Int64, Ref{Ptr{Cvoid}}),
+                W.h, psi.h, maxdim == typemax(Int) ? 0 : maxdim, tol, sweeps, zip_maxdim, r))
+    return finalizer(_free!, DeviceMPS(r[], copy(psi.sites), psi.paired))
+end
+# coefficient(apply(W, psi), cfg) for a batch of configurations (rows of `bits`) without forming W * psi
+function coefficient(W::DeviceMPO, psi::DeviceMPS, bits::AbstractMatrix{<:Integer})
+    nb, L = size(bits)
+    L == length(psi.sites) || throw(ArgumentError("Configuration length $L does not match number of sites $(length(psi.sites))"))
+    b = Matrix{UInt8}(permutedims(bits))                                        # site-major rows for the C side
+    out = Vector{ComplexF64}(undef, nb)
+    check(ccall((:qil_apply_coefficient_batch, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cvoid}),
+                W.h, psi.h, nb, b, out))
+    return out
+end
+# build_dt_mpo for a sweep of damping values, built together on the device (dt_transformer.jl:312-412)
+function build_dt_mpo_batch(psi::DeviceMPS, wrs::AbstractVector{<:Real}; cutoff::Float64=1e-14, maxdim::Int=1000)
+    psi.paired || throw(ArgumentError("build_dt_mpo: needs a paired-register (ZTMPS) operand"))
+    n = length(psi.sites) ÷ 2
+    w = Vector{Float64}(wrs)
+    hs = Vector{Ptr{Cvoid}}(undef, length(w))
+    check(ccall((:qil_build_dt_mpo_batch, LIB), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Cdouble, Int64, Ptr{Ptr{Cvoid}}),
+                ctx().h, n, length(w), w, cutoff, maxdim, hs))
+    return [finalizer(_free!, DeviceMPO(h, copy(psi.sites), true)) for h in hs]
 end
 
 end # module
