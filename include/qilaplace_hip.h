@@ -201,7 +201,8 @@ int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, dou
 
 /* ------------------------------------------------------------------ encode (E1-E4) */
 /* signal_mps(x; method, cutoff, maxdim, k, p, q, random_seed, mindim)
- * src/signals/SignalConverters.jl:228-233.  x: host, len values of `dtype`.        */
+ * src/signals/SignalConverters.jl:228-233.  x: len values of `dtype`, in host memory OR already in HBM (a device
+ * pointer is recognised through unified addressing; the caller orders its producer before the call).       */
 int qil_signal_mps(qil_context* ctx, const void* x, int64_t len, int dtype, int method,
                    double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed,
                    int64_t mindim, qil_mps** out);

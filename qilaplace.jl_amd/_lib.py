@@ -27,12 +27,34 @@ class QilDomainError(ArithmeticError):
     """Counterpart of Julia's DomainError (compress! on N < 2, bad canonical centre)."""
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as the system
+    one) and load it by path; if the system copy is already in the process (pulled in by libqilhip.so), torch then
+    brings a SECOND runtime and finds no GPUs.  The other order is fine (our NEEDED entry matches torch's copy by
+    SONAME), so when torch is installed but not yet imported its copy is loaded first -- without importing torch.
+    QIL_SYSTEM_HIP=1 skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("QIL_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C qilaplace.jl_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "The HIP path is the product; there is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     return C.CDLL(LIB_PATH)
 
 

@@ -347,7 +347,8 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
     const size_t e = qil_elem_size(dtype);
     void* X = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)N * e, &X));
-    QIL_HIP(hipMemcpyAsync(X, x, (size_t)len * e, hipMemcpyHostToDevice, ctx->stream));
+    // `x` may live on the host or already in HBM (unified addressing resolves the direction)
+    QIL_HIP(hipMemcpyAsync(X, x, (size_t)len * e, hipMemcpyDefault, ctx->stream));
     if (len < N)
         QIL_HIP(hipMemsetAsync(static_cast<char*>(X) + (size_t)len * e, 0, (size_t)(N - len) * e, ctx->stream));
     void* part = nullptr;

@@ -242,15 +242,34 @@ def _encode(fn, cls, x, method, cutoff, maxdim, k, p, q, random_seed, mindim, ct
     if method not in ("svd", "rsvd"):
         raise ValueError(f"tensor_to_mps: unknown method {method}. Use :svd or :rsvd.")
     ctx = ctx or default_context()
-    x = np.asarray(x)
-    code = L.QIL_C64 if np.iscomplexobj(x) else L.QIL_F64
-    xs = np.ascontiguousarray(x, dtype=_np_dtype(code))
-    N = len(xs)
-    n = max(1, int(round(np.log2(N))))
+    cai = getattr(x, "__cuda_array_interface__", None)
+    if cai is not None:
+        # samples already in HBM (a torch / cupy-style device array): hand the device pointer over, no PCIe
+        # trip.  Must be 1-D, contiguous, float64 or complex128; the producer's stream is drained first.
+        if len(cai["shape"]) != 1 or cai.get("strides") not in (None, (np.dtype(cai["typestr"]).itemsize,)):
+            raise ValueError("signal_mps: device signal must be a contiguous 1-D array")
+        dt = np.dtype(cai["typestr"])
+        if dt not in (np.dtype(np.float64), np.dtype(np.complex128)):
+            raise ValueError(f"signal_mps: device signal must be float64 or complex128, got {dt}")
+        code = L.QIL_C64 if dt == np.dtype(np.complex128) else L.QIL_F64
+        N = int(cai["shape"][0])
+        ptr = C.c_void_p(int(cai["data"][0]))
+        sync = getattr(x, "device", None)
+        if sync is not None and "torch" in type(x).__module__:
+            import torch
+            torch.cuda.current_stream(x.device).synchronize()
+        keep = x
+    else:
+        x = np.asarray(x)
+        code = L.QIL_C64 if np.iscomplexobj(x) else L.QIL_F64
+        keep = np.ascontiguousarray(x, dtype=_np_dtype(code))
+        N = len(keep)
+        ptr = keep.ctypes.data_as(C.c_void_p)
+    n = max(1, int(round(np.log2(max(N, 1)))))
     if N < 2 ** n:
         warnings.warn(f"_array_to_tensor: input length {N} is not a power of 2; zero-filling to {2**n}")
     h = C.c_void_p()
-    L.check(fn(ctx.handle, xs.ctypes.data_as(C.c_void_p), N, code,
+    L.check(fn(ctx.handle, ptr, N, code,
                L.QIL_METHOD_SVD if method == "svd" else L.QIL_METHOD_RSVD, float(cutoff), _maxdim(maxdim),
                int(k), int(p), int(q), C.c_uint64(random_seed), int(mindim), C.byref(h)))
     return cls(ctx=ctx, _handle=h)

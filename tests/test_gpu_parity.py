@@ -957,3 +957,26 @@ def test_failed_calls_leave_no_device_memory_behind(qil):
         res = ops(psi, W, wide)[idx][1]()               # and the call works afterwards
         assert ctx.unowned_bytes() == 0, name
         del res
+
+
+def test_signal_encoders_take_device_resident_signals(qil):
+    """The samples may already be in HBM (torch tensor / anything with __cuda_array_interface__): same MPS as
+    from the host copy, no PCIe trip.  SignalConverters.jl:228-233, 247-283."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(31)
+    n = 12
+    x = np.sin(0.01 * np.arange(2 ** n)) * np.exp(-1e-3 * np.arange(2 ** n)) + 1e-3 * rng.standard_normal(2 ** n)
+    xd = torch.from_numpy(x).cuda()
+    a = qil.signal_mps(x, method="svd", cutoff=1e-12)
+    b = qil.signal_mps(xd, method="svd", cutoff=1e-12)
+    assert a.bond_dims == b.bond_dims and abs(a.amplitude - b.amplitude) < 1e-12 * a.amplitude
+    assert np.abs(qil.mps_to_vector(b) - x).max() < 1e-5 * np.abs(x).max()
+    z = x * np.exp(0.3j * np.arange(2 ** n))
+    zd = torch.from_numpy(z).cuda()
+    c = qil.signal_ztmps(zd, method="rsvd", k=24, p=6, q=1, cutoff=1e-12, maxdim=32)
+    d = qil.signal_ztmps(z, method="rsvd", k=24, p=6, q=1, cutoff=1e-12, maxdim=32)
+    assert c.bonds_main == d.bonds_main and c.bonds_copy == d.bonds_copy
+    with pytest.raises(ValueError):
+        qil.signal_mps(torch.zeros(8, 2, dtype=torch.float64).cuda())
+    with pytest.raises(ValueError):
+        qil.signal_mps(torch.zeros(8, dtype=torch.float32).cuda())
