@@ -174,6 +174,13 @@ int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi, int64_t nb
                                 const uint8_t* bits, double* out);
 /* mps_to_vector(psi; reverse) src/mps.jl:716-743: 2^n values of psi's dtype, times amplitude. */
 int qil_mps_to_vector(const qil_mps* psi, int reverse, void* host_out);
+/* Dense read-out of a sub-lattice of configurations: spec[i] = 0 / 1 fixes site i's bit, 2 sums the site
+ * (marginal), 3 leaves it free; host_out receives the 2^(#free) coefficients (psi's dtype, times amplitude),
+ * free sites in chain order, the first one the most significant bit (reverse = 0) or the least (reverse = 1).
+ * All free = mps_to_vector (mps.jl:716-743), none free = coefficient (mps.jl:669-678); in between it is the
+ * (k, l) grid scan of docs/src/tutorials/zt.jl:283-309 or the N-term Laplace sums of dt.jl:187-197 as one
+ * contraction.  QIL_EINVAL_CONFIG for spec values > 3, QIL_EINVAL_LENGTH for more than 34 free sites.      */
+int qil_mps_block(const qil_mps* psi, const uint8_t* spec, int reverse, void* host_out);
 /* norm(psi) src/mps.jl:754-771 (without amplitude). */
 int qil_norm(const qil_mps* psi, double* out);
 

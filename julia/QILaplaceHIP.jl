@@ -250,6 +250,19 @@ function coefficient(W::DeviceMPO, psi::DeviceMPS, bits::AbstractMatrix{<:Intege
                 W.h, psi.h, nb, b, out))
     return out
 end
+# all coefficients of the configurations that agree with `spec` (0 / 1 = fixed bit, 2 = summed, 3 = free) in one
+# dense contraction; free sites in chain order, first one most significant (reverse = false)
+function mps_block(psi::DeviceMPS, spec::AbstractVector{<:Integer}; reverse::Bool=false)
+    length(spec) == length(psi.sites) ||
+        throw(ArgumentError("Configuration length $(length(spec)) does not match number of sites $(length(psi.sites))"))
+    d = Ref{Cint}(0)
+    check(ccall((:qil_mps_dtype, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), psi.h, d))
+    nfree = count(==(3), spec)
+    out = d[] == 1 ? Vector{ComplexF64}(undef, 2^nfree) : Vector{Float64}(undef, 2^nfree)
+    check(ccall((:qil_mps_block, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ptr{Cvoid}),
+                psi.h, Vector{UInt8}(spec), reverse, out))
+    return out
+end
 # build_dt_mpo for a sweep of damping values, built together on the device (dt_transformer.jl:312-412)
 function build_dt_mpo_batch(psi::DeviceMPS, wrs::AbstractVector{<:Real}; cutoff::Float64=1e-14, maxdim::Int=1000)
     psi.paired || throw(ArgumentError("build_dt_mpo: needs a paired-register (ZTMPS) operand"))

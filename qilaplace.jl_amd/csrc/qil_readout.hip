@@ -217,6 +217,30 @@ __global__ void scale_real(double* p, long long n, double s) {
         p[t] *= s;
 }
 
+// ---- dense read-out of a sub-lattice of configurations (grid scans) --------------------------------------
+template <class T>
+__global__ void slice_sum(const T* __restrict__ A, int cl, int cr, T* __restrict__ out) {
+    // out[alpha, beta] = A[alpha, 0, beta] + A[alpha, 1, beta]
+    const long long total = (long long)cl * cr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int al = (int)(t % cl);
+        const long long be = t / cl;
+        out[t] = add_t(A[al + (long long)cl * (2 * be)], A[al + (long long)cl * (2 * be + 1)]);
+    }
+}
+template <class T>
+__global__ void bit_reverse_scale(const T* __restrict__ in, T* __restrict__ out, int nbits, double scale, int rev) {
+    const long long N = 1LL << nbits;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < N; t += (long long)gridDim.x * blockDim.x) {
+        long long d = t;
+        if (rev) d = nbits == 0 ? 0 : (long long)(__brevll((unsigned long long)t) >> (64 - nbits));
+        T v = in[t];
+        reinterpret_cast<double*>(&v)[0] *= scale;
+        if (sizeof(T) == 16) reinterpret_cast<double*>(&v)[1] *= scale;
+        out[d] = v;
+    }
+}
+
 // ---- lazy read-out, GEMM form (many queries, large chi * D) ----------------------------------------------
 template <class TS>
 __global__ void widen_to_c64(const TS* __restrict__ src, c64* __restrict__ dst, long long n) {
@@ -494,6 +518,118 @@ extern "C" int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi,
     qil_ctx_free(ctx, scratch);
     qil_ctx_free(ctx, dout);
     qil_ctx_free(ctx, dbits);
+    return QIL_OK;
+}
+
+// All 2^F coefficients of the configurations that agree with `spec` on the fixed sites -- the (k, l) grid scans
+// of docs/src/tutorials/zt.jl:283-309 and the Laplace-value sums of dt.jl:187-197 as ONE dense contraction
+// instead of 2^F chains.  spec[i]: 0 / 1 = the site's bit is fixed, 2 = the site is summed (marginal),
+// 3 = the site is free.  The running tensor T[idx, beta] (idx over the free sites so far) advances by one MFMA
+// GEMM per site: a fixed site multiplies by the slice A[:, b, :], a summed site by A[:, 0, :] + A[:, 1, :], a
+// free site by the whole site viewed as (chi_l x 2 chi_r) -- the product's (idx, s, beta) order IS the next
+// T[(idx, s), beta], nothing is permuted.  Output index: free sites in chain order, first free site = most
+// significant bit (reverse = 0, as mps_to_vector) or least significant (reverse = 1).
+extern "C" int qil_mps_block(const qil_mps* psi, const uint8_t* spec, int reverse, void* host_out) {
+    QIL_REQUIRE(psi && spec && host_out, QIL_EINVAL_ARG, "mps_block: null argument");
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
+    const int64_t n = psi->n();
+    int nfree = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        QIL_REQUIRE(spec[i] <= 3, QIL_EINVAL_CONFIG, "mps_block: spec value %d outside [0,3]", (int)spec[i]);
+        nfree += spec[i] == 3;
+    }
+    QIL_REQUIRE(nfree <= 34, QIL_EINVAL_LENGTH, "mps_block: %d free sites is too many for a dense block", nfree);
+    const int dt = psi->dtype;
+    const size_t e = qil_elem_size(dt);
+    long long maxel = 1, rows = 1, maxslice = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        if (spec[i] == 3) rows *= 2;
+        maxel = std::max<long long>(maxel, rows * psi->dims[(size_t)i + 1]);
+        maxslice = std::max<long long>(maxslice, psi->dims[(size_t)i] * psi->dims[(size_t)i + 1]);
+    }
+    void *bufA = nullptr, *bufB = nullptr, *sl = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxel * e, &bufA));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxel * e, &bufB));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxslice * e, &sl));
+    const double one[2] = {1.0, 0.0};
+    QIL_HIP(hipMemcpyAsync(bufA, one, e, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    // the fixed / summed sites BEHIND the last free one fold into a right boundary vector first (O(chi^2) each,
+    // instead of dragging the 2^F rows of T through them)
+    int64_t last_free = -1;
+    for (int64_t i = 0; i < n; ++i)
+        if (spec[i] == 3) last_free = i;
+    long long maxchi = 1;
+    for (int64_t i = 0; i <= n; ++i) maxchi = std::max<long long>(maxchi, psi->dims[(size_t)i]);
+    void *rv = nullptr, *rv2 = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxchi * e, &rv));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxchi * e, &rv2));
+    QIL_HIP(hipMemcpyAsync(rv, one, e, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    auto site_slice = [&](int64_t i, const void** B, long long* ldb) -> int {   // the (chi_l x chi_r) factor of site i
+        const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+        const char* A = static_cast<const char*>(psi->site[(size_t)i]);
+        if (spec[i] == 2) {
+            const unsigned g = (unsigned)std::min<long long>((cl * cr + 255) / 256, 4096);
+            if (dt == QIL_C64)
+                hipLaunchKernelGGL(slice_sum<c64>, dim3(g), dim3(256), 0, ctx->stream, (const c64*)A, (int)cl, (int)cr, (c64*)sl);
+            else
+                hipLaunchKernelGGL(slice_sum<double>, dim3(g), dim3(256), 0, ctx->stream, (const double*)A, (int)cl, (int)cr,
+                                   (double*)sl);
+            *B = sl;
+            *ldb = cl;
+        } else {
+            *B = A + (size_t)spec[i] * (size_t)cl * e;
+            *ldb = 2 * cl;
+        }
+        return QIL_OK;
+    };
+    for (int64_t i = n - 1; i > last_free; --i) {
+        const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+        const void* B = nullptr;
+        long long ldb = 0;
+        QIL_TRY(site_slice(i, &B, &ldb));
+        QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, cl, 1, cr, B, ldb, rv, cr, rv2, cl));
+        std::swap(rv, rv2);
+    }
+    void *cur = bufA, *nxt = bufB;
+    rows = 1;
+    for (int64_t i = 0; i <= last_free; ++i) {
+        const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+        if (spec[i] == 3) {
+            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, rows, 2 * cr, cl, cur, rows, psi->site[(size_t)i], cl, nxt, rows));
+            rows *= 2;
+        } else {
+            const void* B = nullptr;
+            long long ldb = 0;
+            QIL_TRY(site_slice(i, &B, &ldb));
+            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, rows, cr, cl, cur, rows, B, ldb, nxt, rows));
+        }
+        std::swap(cur, nxt);
+    }
+    {   // close with the boundary vector: T (rows x chi) r (chi x 1)
+        const long long cb = psi->dims[(size_t)(last_free + 1)];
+        QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, rows, 1, cb, cur, rows, rv, cb, nxt, rows));
+        std::swap(cur, nxt);
+    }
+    // natural order: the first free site is the LOWEST bit of idx
+    const unsigned g = (unsigned)std::min<long long>((rows + 255) / 256, 65536);
+    if (dt == QIL_C64)
+        hipLaunchKernelGGL(bit_reverse_scale<c64>, dim3(g), dim3(256), 0, ctx->stream, (const c64*)cur, (c64*)nxt, nfree,
+                           psi->amplitude, reverse ? 0 : 1);
+    else
+        hipLaunchKernelGGL(bit_reverse_scale<double>, dim3(g), dim3(256), 0, ctx->stream, (const double*)cur, (double*)nxt,
+                           nfree, psi->amplitude, reverse ? 0 : 1);
+    QIL_HIP(hipGetLastError());
+    QIL_HIP(hipMemcpyAsync(host_out, nxt, (size_t)rows * e, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    qil_ctx_free(ctx, bufA);
+    qil_ctx_free(ctx, bufB);
+    qil_ctx_free(ctx, sl);
+    qil_ctx_free(ctx, rv);
+    qil_ctx_free(ctx, rv2);
     return QIL_OK;
 }
 

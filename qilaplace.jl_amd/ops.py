@@ -135,6 +135,18 @@ def coefficient_grid(psi, ks, ls, chunk=1 << 16):
     of docs/src/tutorials/zt.jl:152-157, 283-309) -- all pairs in batched launches."""
     n = len(psi)
     ks, ls = np.asarray(ks, dtype=np.int64), np.asarray(ls, dtype=np.int64)
+    a, b = _full_low_range(ks), _full_low_range(ls)
+    if a is not None and b is not None and a <= n and b <= n and a + b <= 30:
+        # a full 2^a x 2^b grid over the low bits = every configuration of the first sites of each register with
+        # the rest fixed at 0: one dense block read-out instead of 2^(a+b) chains
+        spec = np.zeros(2 * n, dtype=np.uint8)
+        spec[0:2 * a:2] = FREE
+        spec[1:2 * b:2] = FREE
+        t = np.asarray(mps_block(psi, spec, reverse=True)).reshape([2] * (a + b))   # axis 0 = LAST free site
+        free_sites = sorted([2 * i for i in range(a)] + [2 * i + 1 for i in range(b)])
+        axis_of = {site: (a + b - 1 - pos) for pos, site in enumerate(free_sites)}
+        order = [axis_of[2 * i] for i in range(a - 1, -1, -1)] + [axis_of[2 * i + 1] for i in range(b - 1, -1, -1)]
+        return np.ascontiguousarray(t.transpose(order)).reshape(2 ** a, 2 ** b).astype(np.complex128)
     kb, lb = _lsb_bits(ks, n), _lsb_bits(ls, n)
     out = np.empty((len(ks), len(ls)), dtype=np.complex128)
     rows = max(1, chunk // max(len(ls), 1))
@@ -152,6 +164,13 @@ def laplace_values(psi_out, ks, dt):
     ZTMPS (docs/src/tutorials/dt.jl:172-197).  The sum over the copy register is a marginal: one chain per
     k instead of N coefficient calls."""
     n = len(psi_out)
+    a = _full_low_range(ks)
+    if a is not None and a <= min(n, 30):
+        # all of k = 0 .. 2^a - 1: main bits free (lsb first), copy register summed -- one dense contraction
+        spec = np.full(2 * n, SUM, dtype=np.uint8)
+        spec[0::2] = FIX0
+        spec[0:2 * a:2] = FREE
+        return dt * np.sqrt(2.0 ** n) * mps_block(psi_out, spec, reverse=True)
     kb = _lsb_bits(ks, n)
     bits = np.full((len(kb), 2 * n), 2, dtype=np.uint8)
     bits[:, 0::2] = kb
@@ -188,6 +207,35 @@ def mps_to_vector(psi, reverse=False):
     out = np.empty(2 ** n, dtype=psi.dtype)
     L.check(L.lib.qil_mps_to_vector(psi.handle, 1 if reverse else 0, out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+FIX0, FIX1, SUM, FREE = 0, 1, 2, 3
+
+
+def mps_block(psi, spec, reverse=False):
+    """All 2^F coefficients of the configurations that agree with `spec` on its fixed sites, as one dense
+    contraction: spec[i] = 0 / 1 fixes site i's bit, 2 (SUM) sums the site, 3 (FREE) leaves it free.  The result is
+    indexed by the free sites in chain order, the first one the most significant bit (reverse=False, like
+    mps_to_vector) or the least (reverse=True)."""
+    n = _ntensors(psi)
+    sp = np.ascontiguousarray(np.asarray(spec), dtype=np.uint8)
+    if sp.shape != (n,):
+        raise ValueError(f"coefficient: expected {n} entries, got {sp.shape}")
+    if sp.size and sp.max() > 3:
+        raise ValueError(f"coefficient: spec value {int(sp.max())} outside [0,3]")
+    out = np.empty(2 ** int((sp == FREE).sum()), dtype=psi.dtype)
+    L.check(L.lib.qil_mps_block(psi.handle, sp.ctypes.data_as(C.POINTER(C.c_uint8)), 1 if reverse else 0,
+                                out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def _full_low_range(v):
+    """log2(len) if v == arange(2^a), else None."""
+    v = np.asarray(v)
+    a = int(round(np.log2(len(v)))) if len(v) else -1
+    if a < 0 or len(v) != 2 ** a or not np.array_equal(v, np.arange(2 ** a)):
+        return None
+    return a
 
 
 def norm(psi) -> float:

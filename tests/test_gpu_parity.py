@@ -980,3 +980,58 @@ def test_signal_encoders_take_device_resident_signals(qil):
         qil.signal_mps(torch.zeros(8, 2, dtype=torch.float64).cuda())
     with pytest.raises(ValueError):
         qil.signal_mps(torch.zeros(8, dtype=torch.float32).cuda())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_mps_block_dense_sublattice_readout(qil, dtype):
+    """qil_mps_block: every configuration that agrees with a spec (fixed / summed / free sites) from ONE dense
+    contraction equals the same numbers read one `coefficient` (mps.jl:669-678) / marginal at a time; all sites free
+    is mps_to_vector (mps.jl:716-743) in both bit orders."""
+    rng = np.random.default_rng(5)
+    L = 9
+    a = random_mps_data(saturated_profile(L, 12), rng, dtype=dtype)
+    psi = qil.SignalMPS(a, amplitude=1.7)
+    for trial in range(4):
+        spec = rng.integers(0, 4, size=L).astype(np.uint8)
+        free = np.flatnonzero(spec == 3)
+        F = len(free)
+        bits = np.tile(spec, (2 ** F, 1))
+        for idx in range(2 ** F):
+            for pos, site in enumerate(free):                       # first free site = most significant bit
+                bits[idx, site] = (idx >> (F - 1 - pos)) & 1
+        ref = qil.marginal_batch(psi, bits)
+        got = qil.mps_block(psi, spec)
+        assert got.shape == (2 ** F,) and rel(got, ref) < 1e-12
+        got_r = qil.mps_block(psi, spec, reverse=True)
+        perm = [int(format(i, f"0{F}b")[::-1], 2) if F else 0 for i in range(2 ** F)]
+        assert rel(got_r[perm], ref) < 1e-12
+    assert rel(qil.mps_block(psi, [3] * L), qil.mps_to_vector(psi)) < 1e-12
+    assert rel(qil.mps_block(psi, [3] * L, reverse=True), qil.mps_to_vector(psi, reverse=True)) < 1e-12
+    assert abs(qil.mps_block(psi, [1, 0, 1, 1, 0, 0, 1, 0, 1])[0] - qil.coefficient(psi, "101100101")) < 1e-13
+    with pytest.raises(ValueError):
+        qil.mps_block(psi, [0] * (L - 1))
+    with pytest.raises(ValueError):
+        qil.mps_block(psi, [4] + [0] * (L - 1))
+
+
+def test_grid_scan_and_laplace_fast_paths_equal_chains(qil):
+    """coefficient_grid / laplace_values on full low-bit ranges take the dense block read-out; any other index set
+    takes the per-query chains (zt.jl:283-309, dt.jl:187-197).  Same numbers."""
+    rng = np.random.default_rng(8)
+    n = 6
+    a = random_mps_data(saturated_profile(2 * n, 10), rng, dtype=np.complex128)
+    psi = qil.ZTMPS(a, amplitude=0.9)
+    for (ka, lb) in [(3, 5), (6, 6), (0, 4), (5, 0)]:
+        ks, ls = np.arange(2 ** ka), np.arange(2 ** lb)
+        fast = qil.coefficient_grid(psi, ks, ls)
+        pk, pl = rng.permutation(len(ks)), rng.permutation(len(ls))
+        slow = qil.coefficient_grid(psi, ks[pk] if len(ks) > 1 else np.array([0, 0]), ls[pl] if len(ls) > 1 else np.array([0, 0]))
+        if len(ks) > 1 and len(ls) > 1:
+            assert rel(fast[np.ix_(pk, pl)], slow) < 1e-12
+        else:
+            assert fast.shape == (2 ** ka, 2 ** lb) and np.isfinite(fast).all()
+    for ka in (2, 6):
+        ks = np.arange(2 ** ka)
+        fast = qil.laplace_values(psi, ks, 0.3)
+        slow = qil.laplace_values(psi, ks[::-1].copy(), 0.3)[::-1]
+        assert rel(fast, slow) < 1e-12

@@ -13,4 +13,8 @@ ks = np.arange(256); ls = np.arange(256)
 for name, obj in (("materialised product (bond %d)" % max(full.bond_dims), full), ("compressed (bond %d)" % max(fast.bond_dims), fast)):
     qil.coefficient_grid(obj, ks[:8], ls[:8])
     t0 = time.perf_counter(); chi = qil.coefficient_grid(obj, ks, ls); t = time.perf_counter() - t0
-    print(dict(case=name, queries=chi.size, seconds=round(t, 4), q_per_s=int(chi.size / t), gemm_minchi=os.environ.get("QIL_COEFF_GEMM_MINCHI", "512")), flush=True)
+    print(dict(case=name, path="dense block read-out (qil_mps_block)", queries=chi.size, seconds=round(t, 4), q_per_s=int(chi.size / t)), flush=True)
+    pk = np.random.default_rng(0).permutation(256)        # any non-contiguous index set takes the per-query path
+    t0 = time.perf_counter(); chi2 = qil.coefficient_grid(obj, ks[pk], ls[pk]); t = time.perf_counter() - t0
+    print(dict(case=name, path="batched chains / GEMM", queries=chi2.size, seconds=round(t, 4), q_per_s=int(chi2.size / t),
+               max_diff=float(np.abs(chi2 - chi[np.ix_(pk, pk)]).max())), flush=True)
