@@ -45,6 +45,14 @@ __device__ __forceinline__ double one_t(double) { return 1.0; }
 __device__ __forceinline__ c64 one_t(c64) { return c64{1.0, 0.0}; }
 __device__ __forceinline__ c64 to_c64(double v) { return c64{v, 0.0}; }
 __device__ __forceinline__ c64 to_c64(c64 v) { return v; }
+template <class TD>
+__device__ __forceinline__ TD cast_elem(double v);
+template <>
+__device__ __forceinline__ double cast_elem<double>(double v) { return v; }
+template <>
+__device__ __forceinline__ c64 cast_elem<c64>(double v) { return c64{v, 0.0}; }
+template <class TD>
+__device__ __forceinline__ TD cast_elem(c64 v) { return v; }
 __device__ __forceinline__ double conj_t(double v) { return v; }
 __device__ __forceinline__ c64 conj_t(c64 v) { return c64{v.re, -v.im}; }
 
@@ -247,6 +255,21 @@ __global__ void widen_to_c64(const TS* __restrict__ src, c64* __restrict__ dst, 
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
         dst[t] = to_c64(src[t]);
 }
+// W[a, s', s, b] -> Wp[a, s', b, s] (output bit slowest), optionally widened: each output-bit slice becomes one
+// contiguous (D_l x 2 D_r) operand
+template <class TS, class TD>
+__global__ void mpo_site_bit_major(const TS* __restrict__ W, TD* __restrict__ Wp, int Dl, int Dr) {
+    const long long total = 4LL * Dl * Dr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % Dl);
+        long long u = t / Dl;
+        const int sp = (int)(u & 1);
+        u >>= 1;
+        const int b = (int)(u % Dr);
+        const int bit = (int)(u / Dr);
+        Wp[t] = cast_elem<TD>(W[a + (long long)Dl * (sp + 2 * (bit + 2LL * b))]);
+    }
+}
 template <class T>
 __global__ void lazy_finish(const T* __restrict__ M, long long nb, double amplitude, c64* __restrict__ out) {
     for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nb; q += (long long)gridDim.x * blockDim.x) {
@@ -256,12 +279,11 @@ __global__ void lazy_finish(const T* __restrict__ M, long long nb, double amplit
 }
 
 // All queries advance together; per site two strided-batch MFMA GEMMs (batch = query):
-//   X_q[alpha, (s', s, b)] = M_q[alpha, a] W[a, (s', s, b)]                     (chi_l x D_l) (D_l x 4 D_r)
-//   M'_q[beta, b]          = sum_{(alpha, s')} A[(alpha, s'), beta] X_q[(alpha, s'), s = bit_q, b]
-// W and A are used exactly as they lie in HBM (the site layouts ARE these matrices); the second product
-// reads each query's own output-bit slice of X through the per-batch operand shift, so nothing is permuted
-// or gathered between the two.  The first product computes both output bits (2x of ~half the flops): the
-// price of keeping W as one contiguous operand.
+//   X_q[alpha, (s', b)] = M_q[alpha, a] W[a, (s', b) | s = bit_q]               (chi_l x D_l) (D_l x 2 D_r)
+//   M'_q[beta, b]     = sum_{(alpha, s')} A[(alpha, s'), beta] X_q[(alpha, s'), b]  (chi_r x 2 chi_l) (2 chi_l x D_r)
+// The MPO site is re-laid once per site with the output bit slowest (a few hundred KB), so each query's
+// output-bit slice is one contiguous operand picked by the per-batch operand shift of the GEMM; A is used
+// exactly as it lies in HBM, and X_q comes out of the first product in the layout the second one reads.
 int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64_t nb, const uint8_t* dbits,
                    c64* dout) {
     const int64_t n = psi->n();
@@ -273,7 +295,7 @@ int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64
         const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
         const long long Dl = W->dims[(size_t)i], Dr = W->dims[(size_t)i + 1];
         maxM = std::max(maxM, std::max(cl * Dl, cr * Dr));
-        maxX = std::max(maxX, cl * 4 * Dr);
+        maxX = std::max(maxX, cl * 2 * Dr);
         maxW = std::max(maxW, Dl * 4 * Dr);
         maxA = std::max(maxA, cl * 2 * cr);
     }
@@ -284,7 +306,7 @@ int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(chunk * maxM) * e, &M0));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(chunk * maxM) * e, &M1));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(chunk * maxX) * e, &X));
-    if (dt == QIL_C64 && !wc) QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxW * 16, &Wc));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxW * e, &Wc));
     if (dt == QIL_C64 && !ac) QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxA * 16, &Ac));
     int st = QIL_OK;
     for (int64_t q0 = 0; q0 < nb && st == QIL_OK; q0 += chunk) {
@@ -296,12 +318,19 @@ int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64
         for (int64_t i = 0; i < n && st == QIL_OK; ++i) {
             const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
             const long long Dl = W->dims[(size_t)i], Dr = W->dims[(size_t)i + 1];
-            const void* Wp = W->site[(size_t)i];
             const void* Ap = psi->site[(size_t)i];
-            if (Wc) {
-                hipLaunchKernelGGL(widen_to_c64<double>, dim3((unsigned)std::min<long long>((Dl * 4 * Dr + 255) / 256, 4096)),
-                                   dim3(256), 0, ctx->stream, (const double*)Wp, (c64*)Wc, Dl * 4 * Dr);
-                Wp = Wc;
+            {
+                const unsigned g = (unsigned)std::min<long long>((Dl * 4 * Dr + 255) / 256, 4096);
+                const void* Ws = W->site[(size_t)i];
+                if (dt == QIL_F64)
+                    hipLaunchKernelGGL((mpo_site_bit_major<double, double>), dim3(g), dim3(256), 0, ctx->stream,
+                                       (const double*)Ws, (double*)Wc, (int)Dl, (int)Dr);
+                else if (wc)
+                    hipLaunchKernelGGL((mpo_site_bit_major<c64, c64>), dim3(g), dim3(256), 0, ctx->stream, (const c64*)Ws,
+                                       (c64*)Wc, (int)Dl, (int)Dr);
+                else
+                    hipLaunchKernelGGL((mpo_site_bit_major<double, c64>), dim3(g), dim3(256), 0, ctx->stream,
+                                       (const double*)Ws, (c64*)Wc, (int)Dl, (int)Dr);
             }
             if (Ac) {
                 hipLaunchKernelGGL(widen_to_c64<double>, dim3((unsigned)std::min<long long>((cl * 2 * cr + 255) / 256, 4096)),
@@ -311,16 +340,16 @@ int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64
             qil_gemm_batch b1, b2;
             b1.count = nq;
             b1.a_bs = cl * Dl;
-            b1.c_bs = cl * 4 * Dr;
-            st = qil_dev_gemm_batched(ctx, dt, 0, 0, cl, 4 * Dr, Dl, Mc, cl, Wp, Dl, X, cl, &b1);
+            b1.c_bs = cl * 2 * Dr;
+            b1.b_sel = dbits + q0 * n + i;
+            b1.b_sel_step = n;
+            b1.b_sel_stride = Dl * 2 * Dr;
+            st = qil_dev_gemm_batched(ctx, dt, 0, 0, cl, 2 * Dr, Dl, Mc, cl, Wc, Dl, X, cl, &b1);
             if (st != QIL_OK) break;
             b2.count = nq;
-            b2.b_bs = cl * 4 * Dr;
+            b2.b_bs = cl * 2 * Dr;
             b2.c_bs = cr * Dr;
-            b2.b_sel = dbits + q0 * n + i;
-            b2.b_sel_step = n;
-            b2.b_sel_stride = 2 * cl;
-            st = qil_dev_gemm_batched(ctx, dt, 1, 0, cr, Dr, 2 * cl, Ap, 2 * cl, X, 4 * cl, Mn, cr, &b2);
+            st = qil_dev_gemm_batched(ctx, dt, 1, 0, cr, Dr, 2 * cl, Ap, 2 * cl, X, 2 * cl, Mn, cr, &b2);
             std::swap(Mc, Mn);
         }
         if (st != QIL_OK) break;
@@ -335,7 +364,7 @@ int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64
     qil_ctx_free(ctx, M0);
     qil_ctx_free(ctx, M1);
     qil_ctx_free(ctx, X);
-    if (Wc) qil_ctx_free(ctx, Wc);
+    qil_ctx_free(ctx, Wc);
     if (Ac) qil_ctx_free(ctx, Ac);
     return st;
 }
