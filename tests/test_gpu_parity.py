@@ -5,6 +5,7 @@ Tolerances (fp64): apply / coefficient / dense read-out 1e-12 relative (exact li
 different summation order only); transforms vs closed forms 1e-10 (QFT, n <= 5 builders at
 cutoff 1e-14 ... 1e-7 for DT / 2e-7 for zT, the reference's own bounds, MPO-cutoff limited);
 truncating ops compared through gauge-invariant quantities only."""
+import warnings
 import numpy as np
 import pytest
 
@@ -1035,3 +1036,66 @@ def test_grid_scan_and_laplace_fast_paths_equal_chains(qil):
         fast = qil.laplace_values(psi, ks, 0.3)
         slow = qil.laplace_values(psi, ks[::-1].copy(), 0.3)[::-1]
         assert rel(fast, slow) < 1e-12
+
+
+def test_smallest_chains(qil):
+    """One- and two-site chains through every entry point (the reference's loops all have N = 1 / N = 2 special
+    cases: mps.jl:918 DomainError, SignalConverters.jl n = 1, build_*_mpo n = 1 branches)."""
+    rng = np.random.default_rng(2)
+    # --- single site
+    a1 = [rng.standard_normal((1, 2, 1))]
+    w1 = [rng.standard_normal((1, 2, 2, 1)) + 1j * rng.standard_normal((1, 2, 2, 1))]
+    psi, W = qil.SignalMPS(a1, amplitude=3.0), qil.SingleSiteMPO(w1)
+    assert psi.bond_dims == [] and len(psi) == 1
+    assert rel(qil.mps_to_vector(psi), 3.0 * a1[0][0, :, 0]) < 1e-15
+    assert abs(qil.coefficient(psi, [1]) - 3.0 * a1[0][0, 1, 0]) < 1e-15
+    assert abs(qil.norm(psi) - np.linalg.norm(a1[0])) < 1e-15
+    out = W * psi
+    ref = O.apply(O.SingleSiteMPO(w1), O.SignalMPS(a1, amplitude=3.0))
+    assert rel(qil.mps_to_vector(out), O.mps_to_vector(ref)) < 1e-14
+    assert rel(qil.apply_coefficient_batch(W, psi, [[0], [1]]), O.mps_to_vector(ref)) < 1e-14
+    assert rel(qil.mps_block(psi, [3]), qil.mps_to_vector(psi)) < 1e-15
+    assert abs(qil.mps_block(psi, [2])[0] - 3.0 * a1[0].sum()) < 1e-14
+    qil.canonicalize(psi, "left")
+    qil.canonicalize(psi, "right")
+    assert rel(qil.mps_to_vector(psi), 3.0 * a1[0][0, :, 0]) < 1e-14
+    with pytest.raises(ArithmeticError):
+        qil.compress(psi)                                   # DomainError: SignalMPS must have at least 2 sites
+    with pytest.raises(ArithmeticError):
+        qil.apply_compress(W, psi, maxdim=2)
+    WW = W * W
+    assert rel(qil.mps_to_vector(WW * qil.SignalMPS(a1)), O.mps_to_vector(O.apply(O.apply_mpo_mpo(O.SingleSiteMPO(w1), O.SingleSiteMPO(w1)), O.SignalMPS(a1)))) < 1e-14
+    qil.mpo_compress(WW, "down")
+    # --- encoders at n = 1
+    for x in ([0.6, -0.8], [2.0], [1.0 + 1j, 0.5]):
+        x = np.asarray(x)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s = qil.signal_mps(x, method="svd")
+            r = qil.signal_mps(x, method="rsvd", k=4, p=2)
+            z = qil.signal_ztmps(x, cutoff=1e-14)
+        xp = np.concatenate([x, np.zeros(2 - len(x))])
+        assert rel(qil.mps_to_vector(s), xp) < 1e-14 and rel(qil.mps_to_vector(r), xp) < 1e-14
+        oz = O.signal_ztmps(xp, cutoff=1e-14)
+        assert z.bonds_copy == oz.bonds_copy and z.bonds_main == oz.bonds_main
+        assert rel(qil.mps_to_vector(z), O.mps_to_vector(oz)) < 1e-13
+    # --- transforms at n = 1 and n = 2 against the closed forms
+    x = np.array([0.3, -1.1])
+    psi = qil.signal_mps(x)
+    assert rel(qil.mps_to_vector(qil.build_qft_mpo(1) * psi), np.fft.fft(x) / np.sqrt(2)) < 1e-13
+    pz = qil.signal_ztmps(x, cutoff=1e-14)
+    for wr in (0.0, 1.3):
+        chi = qil.coefficient_grid(qil.build_zt_mpo(pz, wr) * pz, np.arange(2), np.arange(2))
+        assert rel(chi, O.analytical_zt(x, wr=wr)) < 1e-10
+        chi_b = qil.coefficient_grid(qil.build_zt_mpo_batch(pz, [wr])[0] * pz, np.arange(2), np.arange(2))
+        assert rel(chi_b, O.analytical_zt(x, wr=wr)) < 1e-10
+        Lv = qil.laplace_values(qil.build_dt_mpo(pz, wr) * pz, np.arange(2), 1.0)
+        assert rel(Lv, np.sqrt(2) * O.analytical_dt(x, wr)) < 1e-10
+    # --- two sites: compress / canonicalize touch exactly one bond
+    a2 = random_mps_data([2], rng)
+    p2 = qil.SignalMPS(a2, amplitude=1.5)
+    v = qil.mps_to_vector(p2)
+    qil.compress(p2, maxdim=2, tol=1e-12)
+    assert rel(qil.mps_to_vector(p2), v) < 1e-12 and abs(qil.norm(p2) - 1.0) < 1e-12
+    qil.compress(p2, maxdim=1)
+    assert p2.bond_dims == [1]
