@@ -1099,3 +1099,79 @@ def test_smallest_chains(qil):
     assert rel(qil.mps_to_vector(p2), v) < 1e-12 and abs(qil.norm(p2) - 1.0) < 1e-12
     qil.compress(p2, maxdim=1)
     assert p2.bond_dims == [1]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomised_truncation_pipeline_against_oracle(qil, seed):
+    """Random shapes / dtypes / tolerances through canonicalize!, compress!, apply, apply_compress and the encoders;
+    everything gauge-invariant must agree with the oracle's restatement of the reference (mps.jl:787-999,
+    SignalConverters.jl:16-283): dense vectors, norms, amplitudes, and the bond dimensions the truncation rule yields."""
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.integers(3, 9))
+    adt = np.complex128 if rng.random() < 0.4 else np.float64
+    wdt = np.complex128 if rng.random() < 0.6 else np.float64
+    chi = int(rng.integers(2, 9))
+    D = int(rng.integers(2, 7))
+    a = random_mps_data(saturated_profile(L, chi), rng, dtype=adt)
+    w = random_mpo_data(saturated_profile(L, D, base=4), rng, dtype=wdt)
+    amp = float(rng.uniform(0.5, 3.0))
+    # canonicalize: same state, isometric sites on the swept side
+    for direction in ("left", "right"):
+        psi = qil.SignalMPS(a, amplitude=amp)
+        center = int(rng.integers(1, L + 1))
+        qil.canonicalize(psi, direction, center=center)
+        ref = O.SignalMPS([t.copy() for t in a], amplitude=amp)
+        O.canonicalize(ref, direction, center=center)
+        assert psi.bond_dims == ref.bond_dims
+        assert rel(qil.mps_to_vector(psi), O.mps_to_vector(ref)) < 1e-11
+    # compress at a random cap / tolerance
+    maxdim = int(rng.integers(1, chi + 2))
+    tol = float(10.0 ** rng.uniform(-12, -2))
+    psi = qil.SignalMPS(a, amplitude=amp)
+    qil.compress(psi, maxdim=maxdim, tol=tol, sweeps=int(rng.integers(1, 3)))
+    ref = O.SignalMPS([t.copy() for t in a], amplitude=amp)
+    O.compress(ref, maxdim=maxdim, tol=tol, sweeps=1)
+    assert max(psi.bond_dims) <= maxdim and abs(qil.norm(psi) - 1.0) < 1e-10
+    v_ref = O.mps_to_vector(O.SignalMPS(a, amplitude=amp))
+    err_h = np.linalg.norm(qil.mps_to_vector(psi) - v_ref)
+    err_o = np.linalg.norm(O.mps_to_vector(ref) - v_ref)
+    assert err_h <= 1.5 * err_o + 1e-9 * np.linalg.norm(v_ref)          # as good an approximation as the reference's
+    # apply (exact) and the fused apply-and-truncate (lossless setting reproduces apply)
+    W, psi = qil.SingleSiteMPO(w), qil.SignalMPS(a, amplitude=amp)
+    dense = O.mps_to_vector(O.apply(O.SingleSiteMPO(w), O.SignalMPS(a, amplitude=amp)))
+    assert rel(qil.mps_to_vector(W * psi), dense) < 1e-12
+    fused = qil.apply_compress(W, psi, maxdim=None, tol=1e-13)
+    # not 1e-13: compress! gauges with canonicalize!'s fixed cutoff 1e-12 (mps.jl:923, 963), i.e. ~1e-6 per bond in norm
+    assert rel(qil.mps_to_vector(fused), dense) < 1e-5
+    # encoders on a random smooth-plus-noise signal
+    n = int(rng.integers(3, 11))
+    t = np.arange(2 ** n) / 2 ** n
+    x = np.sin(2 * np.pi * rng.integers(1, 6) * t) * np.exp(-rng.uniform(0, 4) * t) + 10.0 ** rng.uniform(-9, -2) * rng.standard_normal(2 ** n)
+    if rng.random() < 0.3:
+        x = x * np.exp(2j * np.pi * rng.uniform(0, 3) * t)
+    cutoff = float(10.0 ** rng.uniform(-15, -6))
+    md = int(rng.integers(2, 40))
+    s = qil.signal_mps(x, method="svd", cutoff=cutoff, maxdim=md)
+    so = O.signal_mps(x, method="svd", cutoff=cutoff, maxdim=md)
+    assert s.bond_dims == so.bond_dims and abs(s.amplitude - so.amplitude) < 1e-12 * so.amplitude
+    assert rel(qil.mps_to_vector(s), O.mps_to_vector(so)) < 1e-9
+    z = qil.signal_ztmps(x, cutoff=cutoff, maxdim=md)
+    zo = O.signal_ztmps(x, cutoff=cutoff, maxdim=md)
+    assert z.bonds_main == zo.bonds_main and z.bonds_copy == zo.bonds_copy
+    # randomised encoder: different random numbers than the oracle's.  NOTE the reference's bisection scheme
+    # (SignalConverters.jl:145-184) re-splits the ISOMETRIC factor of every split, so whenever k + p is below the rank
+    # of such a factor it discards unit-weight directions and the error is O(1) whatever q is -- a property of the
+    # algorithm (its benchmarks use k = 2^(n/2)), reproduced by the oracle; the comparison is therefore HIP vs oracle
+    # at the same (k, p, q), plus "exact whenever the sketch is wide enough".
+    k, p, q = int(rng.integers(4, 24)), int(rng.integers(2, 8)), int(rng.integers(0, 3))
+    r = qil.signal_mps(x, method="rsvd", k=k, p=p, q=q, cutoff=cutoff)
+    assert max(r.bond_dims) <= k + p        # SignalConverters.jl:133 forwards maxdim = typemax: the cap is the sketch width
+    rc = qil.signal_mps(x, method="rsvd", k=k, p=p, q=1, cutoff=cutoff, maxdim=k)
+    assert max(rc.bond_dims) <= k
+    e_r = np.linalg.norm(qil.mps_to_vector(r) - x)
+    ro = O.signal_mps(x, method="rsvd", k=k, p=p, q=q, cutoff=cutoff)
+    e_o = np.linalg.norm(O.mps_to_vector(ro) - x)
+    assert e_r <= 10 * e_o + 1e-7 * np.linalg.norm(x)
+    wide = 2 ** (n // 2 + 1)                                   # at least the rank of every matricisation
+    rw = qil.signal_mps(x, method="rsvd", k=wide, p=4, q=q, cutoff=1e-28)
+    assert np.linalg.norm(qil.mps_to_vector(rw) - x) < 1e-9 * np.linalg.norm(x)
