@@ -1175,3 +1175,27 @@ def test_randomised_truncation_pipeline_against_oracle(qil, seed):
     wide = 2 ** (n // 2 + 1)                                   # at least the rank of every matricisation
     rw = qil.signal_mps(x, method="rsvd", k=wide, p=4, q=q, cutoff=1e-28)
     assert np.linalg.norm(qil.mps_to_vector(rw) - x) < 1e-9 * np.linalg.norm(x)
+
+
+@pytest.mark.parametrize("L,chi,maxdim,dtype", [(16, 150, 40, np.float64), (20, 520, 64, np.float64), (18, 200, 25, np.complex128)])
+def test_compress_wide_bonds_against_oracle(qil, L, chi, maxdim, dtype):
+    """compress! (mps.jl:913-973) where the per-site SVDs leave the in-LDS regime: 97..511 columns take the
+    tournament rounds, >= 512 the block Jacobi.  Same truncated state as the oracle's (gauge-invariant comparison)."""
+    rng = np.random.default_rng(L * chi)
+    a = random_mps_data(saturated_profile(L, chi), rng, dtype=dtype)
+    # give the bonds a decaying spectrum so that the cap actually selects something: damp the higher bond states
+    for i in range(len(a) - 1):
+        d = a[i].shape[2]
+        g = np.exp(-0.08 * np.arange(d))
+        a[i] = a[i] * g[None, None, :]
+    psi = qil.SignalMPS(a, amplitude=1.0)
+    ref = O.SignalMPS([t.copy() for t in a], amplitude=1.0)
+    bits = rng.integers(0, 2, size=(256, L))
+    before = O.coefficient_batch(ref, bits)
+    qil.compress(psi, maxdim=maxdim, tol=1e-10)
+    O.compress(ref, maxdim=maxdim, tol=1e-10)
+    assert psi.bond_dims == ref.bond_dims
+    assert abs(psi.amplitude - ref.amplitude) < 1e-9 * ref.amplitude
+    got, want = qil.coefficient_batch(psi, bits), O.coefficient_batch(ref, bits)
+    scale = np.abs(before).max()
+    assert np.abs(got - want).max() < 1e-7 * scale
