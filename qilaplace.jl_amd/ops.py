@@ -135,17 +135,20 @@ def coefficient_grid(psi, ks, ls, chunk=1 << 16):
     of docs/src/tutorials/zt.jl:152-157, 283-309) -- all pairs in batched launches."""
     n = len(psi)
     ks, ls = np.asarray(ks, dtype=np.int64), np.asarray(ls, dtype=np.int64)
-    a, b = _full_low_range(ks), _full_low_range(ls)
-    if a is not None and b is not None and a <= n and b <= n and a + b <= 30:
-        # a full 2^a x 2^b grid over the low bits = every configuration of the first sites of each register with
-        # the rest fixed at 0: one dense block read-out instead of 2^(a+b) chains
+    rk, rl = _bit_block_range(ks), _bit_block_range(ls)
+    if rk is not None and rl is not None and rk[0] + rk[1] <= n and rl[0] + rl[1] <= n and rk[1] + rl[1] <= 30:
+        # a 2^a x 2^b grid of aligned power-of-two strides (the tutorials' full and coarse scans) = every
+        # configuration of a bit block of each register with the other bits fixed at 0: one dense block read-out
+        # instead of 2^(a+b) chains
+        (sk, a), (sl, b) = rk, rl
         spec = np.zeros(2 * n, dtype=np.uint8)
-        spec[0:2 * a:2] = FREE
-        spec[1:2 * b:2] = FREE
+        spec[2 * sk:2 * (sk + a):2] = FREE
+        spec[2 * sl + 1:2 * (sl + b) + 1:2] = FREE
         t = np.asarray(mps_block(psi, spec, reverse=True)).reshape([2] * (a + b))   # axis 0 = LAST free site
-        free_sites = sorted([2 * i for i in range(a)] + [2 * i + 1 for i in range(b)])
+        free_sites = sorted([2 * (sk + i) for i in range(a)] + [2 * (sl + i) + 1 for i in range(b)])
         axis_of = {site: (a + b - 1 - pos) for pos, site in enumerate(free_sites)}
-        order = [axis_of[2 * i] for i in range(a - 1, -1, -1)] + [axis_of[2 * i + 1] for i in range(b - 1, -1, -1)]
+        order = ([axis_of[2 * (sk + i)] for i in range(a - 1, -1, -1)] +
+                 [axis_of[2 * (sl + i) + 1] for i in range(b - 1, -1, -1)])
         return np.ascontiguousarray(t.transpose(order)).reshape(2 ** a, 2 ** b).astype(np.complex128)
     kb, lb = _lsb_bits(ks, n), _lsb_bits(ls, n)
     out = np.empty((len(ks), len(ls)), dtype=np.complex128)
@@ -229,13 +232,24 @@ def mps_block(psi, spec, reverse=False):
     return out
 
 
+def _bit_block_range(v):
+    """(s, a) if v == arange(2^a) << s -- every pattern of bits s .. s+a-1, all other bits zero -- else None."""
+    v = np.asarray(v, dtype=np.int64)
+    a = int(round(np.log2(len(v)))) if len(v) else -1
+    if a < 0 or len(v) != 2 ** a:
+        return None
+    if a == 0:
+        return (0, 0) if v[0] == 0 else None
+    step = int(v[1] - v[0])
+    if step <= 0 or step & (step - 1) or not np.array_equal(v, step * np.arange(2 ** a, dtype=np.int64)):
+        return None
+    return step.bit_length() - 1, a
+
+
 def _full_low_range(v):
     """log2(len) if v == arange(2^a), else None."""
-    v = np.asarray(v)
-    a = int(round(np.log2(len(v)))) if len(v) else -1
-    if a < 0 or len(v) != 2 ** a or not np.array_equal(v, np.arange(2 ** a)):
-        return None
-    return a
+    r = _bit_block_range(v)
+    return r[1] if r is not None and (r[0] == 0 or r[1] == 0) else None
 
 
 def norm(psi) -> float:

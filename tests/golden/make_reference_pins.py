@@ -89,6 +89,12 @@ pins = {
         "k": 50, "p": 5, "q": 2, "cutoff": 1e-12, "maxdim": 128,
         "bonds_main": [1, 1, 1] + [2] * 16,
         "bonds_copy": [1, 1, 1, 2, 3] + [4] * 14 + [2],
+        # executed output of the three |chi(k, l)| scans, docs/src/tutorials/zt.md:452-456, 519-523, 557-561
+        "mpo_cutoff": 1e-12, "mpo_maxdim": 128,
+        "coarse": {"wr": "2pi", "step": 4096, "peak_k": 0, "peak_l": 0, "pole_error": 4.102e-03},
+        "fine": {"wr": 0.5, "peak_k": 0, "peak_l": 1047889, "z_re": 0.999992, "z_im": 0.004117, "pole_error": 1.509e-04},
+        "superfine": {"wr": 0.5, "half": 24, "peak_k": 320, "peak_l": 1047872, "z_re": 0.999839, "z_im": 0.004218,
+                      "pole_error": 1.185e-04},
     },
 }
 

@@ -1199,3 +1199,36 @@ def test_compress_wide_bonds_against_oracle(qil, L, chi, maxdim, dtype):
     got, want = qil.coefficient_batch(psi, bits), O.coefficient_batch(ref, bits)
     scale = np.abs(before).max()
     assert np.abs(got - want).max() < 1e-7 * scale
+
+
+def test_zt_tutorial_pole_scans_reproduce_published_peaks(qil, pins):
+    """docs/src/tutorials/zt.md:318-561 end to end (examples/zt_pole_scan.py): n = 20 two-pole signal, RSVD encode, zT
+    MPOs at wr = 2 pi and 0.5, and the three |chi(k, l)| scans.  The printed peak indices / locations / pole errors of
+    the reference's executed tutorial are the expected values."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("zt_pole_scan", os.path.join(root, "examples", "zt_pole_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main()
+    p = pins["zt_tutorial_big"]
+    for scan in ("coarse", "fine", "superfine"):
+        k, l, err = out[scan]
+        assert (k, l) == (p[scan]["peak_k"], p[scan]["peak_l"]), scan
+        assert abs(err - p[scan]["pole_error"]) <= 0.5e-3 * p[scan]["pole_error"] + 1e-12   # printed to 4 significant digits
+
+
+def test_grid_fast_path_on_aligned_strides(qil):
+    """coefficient_grid with power-of-two strides (the tutorial's coarse scan: k, l = 0, 2^s, 2 * 2^s, ...) takes the dense
+    block read-out on the HIGH bit block; same values as the per-query chains."""
+    rng = np.random.default_rng(21)
+    n = 7
+    a = random_mps_data(saturated_profile(2 * n, 9), rng, dtype=np.complex128)
+    psi = qil.ZTMPS(a, amplitude=1.1)
+    for (sk, ak, sl, al) in [(3, 4, 2, 5), (0, 3, 4, 3), (5, 2, 0, 7), (6, 1, 6, 1)]:
+        ks, ls = (np.arange(2 ** ak) << sk), (np.arange(2 ** al) << sl)
+        fast = qil.coefficient_grid(psi, ks, ls)
+        pk, pl = rng.permutation(len(ks)), rng.permutation(len(ls))
+        slow = qil.coefficient_grid(psi, ks[pk], ls[pl])              # shuffled index sets: per-query path
+        assert rel(fast[np.ix_(pk, pl)], slow) < 1e-12
