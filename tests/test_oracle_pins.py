@@ -155,3 +155,48 @@ def test_zt_tutorial_big_signal_bond_structure(pins):
     x = (p["a_abs"] * np.exp(1j * p["a_arg"])) ** j * np.cos(p["w0"] * j)
     zt = O.signal_ztmps(x, method="rsvd", k=p["k"], p=p["p"], q=p["q"], cutoff=p["cutoff"], maxdim=p["maxdim"])
     assert zt.bonds_main == p["bonds_main"] and zt.bonds_copy == p["bonds_copy"]
+
+
+def test_zt_tutorial_pole_scans(pins):
+    """docs/src/tutorials/zt.md:430-561: the three |chi(k, l)| scans of the n = 20 two-pole run.  The oracle's pipeline
+    (RSVD encode -> build_zt_mpo -> apply -> coefficient) lands on the peak indices and pole errors the reference's
+    executed tutorial printed."""
+    p = pins["zt_tutorial_big"]
+    n = p["n"]
+    N = 2 ** n
+    j = np.arange(N)
+    a, w0 = p["a_abs"] * np.exp(1j * p["a_arg"]), p["w0"]
+    x = a ** j * np.cos(w0 * j)
+    poles = [np.exp(1j * w0) / a, np.exp(-1j * w0) / a]
+    psi = O.signal_ztmps(x, method="rsvd", k=p["k"], p=p["p"], q=p["q"], cutoff=p["cutoff"], maxdim=p["maxdim"])
+    wi = 2 * np.pi
+
+    def scan(phi, ks, ls, wr):
+        kb, lb = ((ks[:, None] >> np.arange(n)) & 1), ((ls[:, None] >> np.arange(n)) & 1)
+        bits = np.empty((len(ks), len(ls), 2 * n), dtype=np.uint8)
+        bits[:, :, 0::2] = kb[:, None, :]
+        bits[:, :, 1::2] = lb[None, :, :]
+        chi = O.coefficient_batch(phi, bits.reshape(-1, 2 * n)).reshape(len(ks), len(ls))
+        i, m = np.unravel_index(np.argmax(np.abs(chi)), chi.shape)
+        r, th = np.exp(-wr * ks[i] / N), wi * ls[m] / N
+        z = complex(r * np.cos(th), -r * np.sin(th))
+        return int(ks[i]), int(ls[m]), min(abs(z - q) for q in poles)
+
+    def check(got, want):
+        assert got[:2] == (want["peak_k"], want["peak_l"])
+        assert abs(got[2] - want["pole_error"]) <= 0.5e-3 * want["pole_error"]
+
+    wr = 2 * np.pi
+    phi = O.apply(O.build_zt_mpo(n, wr, cutoff=p["mpo_cutoff"], maxdim=p["mpo_maxdim"]), psi)
+    ks = np.arange(0, N, p["coarse"]["step"])
+    check(scan(phi, ks, ks, wr), p["coarse"])
+    wr = 0.5
+    phi = O.apply(O.build_zt_mpo(n, wr, cutoff=p["mpo_cutoff"], maxdim=p["mpo_maxdim"]), psi)
+    ks = np.clip(np.rint((-N / wr) * np.log(np.linspace(1 - 1.6e-4, 1.0, 128))).astype(np.int64), 0, N - 1)
+    ls = np.mod(np.rint((N / wi) * np.mod(np.linspace(-5e-3, 9e-3, 128), 2 * np.pi)).astype(np.int64), N)
+    check(scan(phi, ks, ls, wr), p["fine"])
+    zt = poles[0]
+    kc = int(np.clip(np.rint((-N / wr) * np.log(abs(zt))), 0, N - 1))
+    lc = int(np.mod(np.rint((N / wi) * np.mod(-np.angle(zt), 2 * np.pi)), N))
+    h = p["superfine"]["half"]
+    check(scan(phi, np.arange(kc - h, kc + h + 1), np.mod(np.arange(lc - h, lc + h + 1), N), wr), p["superfine"])
