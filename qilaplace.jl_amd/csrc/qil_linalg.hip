@@ -28,8 +28,8 @@ using namespace qil_dev;
 //     registers right after the barrier and land while the current tile's MFMAs run, LDS double buffered,
 //     ONE barrier per K tile (f64: fewer registers, 2 waves/SIMD still fit); PIPE = false: single buffer,
 //     smaller footprint => 3 waves/SIMD, which the complex kernel (3 accumulator sets) needs to keep the
-//     matrix pipe fed.  Measured issue ceiling of this MFMA on MI355X: 47 TFLOP/s with >= 2 waves/SIMD,
-//     35 TFLOP/s with one (tools/micro/mfma_f64_peak.hip);
+//     matrix pipe fed.  Built with -amdgpu-mfma-vgpr-form: with AGPR accumulators this MFMA issues at ~0.6 of
+//     its rate on gfx950 (46 vs 77.6 TFLOP/s for a pure MFMA stream, tools/micro/mfma_f64_variants.hip);
 //   * LDS holds split re/im planes, rows padded by 2 doubles (keeps both the k-major staging writes and
 //     the fragment reads at <= 2-way bank conflicts);
 //   * the MFMA is issued as (B^T tile) x (A^T tile) = (AB)^T tile: the D fragment then has the C ROW
@@ -109,61 +109,77 @@ __global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long 
                 ri[a][b] = d4{0, 0, 0, 0};
             }
         }
-    // global -> register mapping: fastest along the contiguous index of each operand
+    // global -> register mapping: fastest along the contiguous index of each operand.  Everything that does
+    // not change from K tile to K tile is computed ONCE per thread: a pointer per staged element (advanced by one
+    // tile per iteration), its row/column validity, its k offset and its LDS slot.  Inside the loop a load is a
+    // compare, two selects and the load itself -- the per-element 64-bit index products used to cost ~20 VALU
+    // instructions per element per tile and kept the wave off the matrix pipe.
     const bool a_rows_contig = a_rs == 1, b_k_contig = b_ks == 1;
     T ra[EA], rb[EB];
+    const T* pa[EA];
+    const T* pb[EB];
+    int ka[EA], kb[EB], sa[EA], sb[EB];
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+        const int idx = tid + 256 * e;
+        const int i = a_rows_contig ? idx % BM : idx / GK;
+        const int kk = a_rows_contig ? idx / BM : idx % GK;
+        const long long gr = row0 + i;
+        ka[e] = kk;
+        sa[e] = kk * LA + i;
+        pa[e] = A + min(gr, m - 1) * a_rs + (kbeg + kk) * a_ks;
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        const int idx = tid + 256 * e;
+        const int kk = b_k_contig ? idx % GK : idx / BN;
+        const int j = b_k_contig ? idx / GK : idx % BN;
+        const long long gc = col0 + j;
+        kb[e] = kk;
+        sb[e] = kk * LB + j;
+        pb[e] = B + (kbeg + kk) * b_ks + min(gc, n - 1) * b_cs;
+    }
+    const long long a_step = (long long)GK * a_ks, b_step = (long long)GK * b_ks;
+    // Edges.  Rows / columns beyond the matrix are CLAMPED to the last valid one when the pointers are set up: such
+    // lanes load real data that only ever reaches C entries the epilogue does not store, so the M / N edges need no
+    // predicate at all.  Only the K edge matters (a partial last tile would add garbage to valid entries): full
+    // tiles -- all but possibly the last -- run plain loads and plain stores to LDS, the last one selects a valid
+    // address per lane and zeroes the k-invalid elements when the tile is staged.  Nothing touches a loaded value
+    // before store_tile, so the loads stay in flight across the MFMAs of the current tile.
     auto load_tile = [&](long long k0) {
+        if (k0 + GK <= kend) {
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            const int idx = tid + 256 * e;
-            const int i = a_rows_contig ? idx % BM : idx / GK;
-            const int kk = a_rows_contig ? idx / BM : idx % GK;
-            const long long gr = row0 + i, gk = k0 + kk;
-            // branch-free edge handling: load from a clamped (always valid) address, then zero the
-            // out-of-range lanes -- a conditional load would put every load in its own exec branch with
-            // its own vmcnt(0) wait, serialising the tile's loads
-            // (for 8-byte elements hipcc already predicates the plain conditional load, and that form is faster)
-            if constexpr (CX) {
-                T v = A[min(gr, m - 1) * a_rs + min(gk, kend - 1) * a_ks];
-                v = maybe_conj(v, conjA);
-                if (!(gr < m && gk < kend)) v = T{};
-                ra[e] = v;
-            } else {
-                ra[e] = (gr < m && gk < kend) ? A[gr * a_rs + gk * a_ks] : T{};
+            for (int e = 0; e < EA; ++e) {
+                ra[e] = *pa[e];
+                pa[e] += a_step;
             }
-        }
 #pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            const int idx = tid + 256 * e;
-            const int kk = b_k_contig ? idx % GK : idx / BN;
-            const int j = b_k_contig ? idx / GK : idx % BN;
-            const long long gc = col0 + j, gk = k0 + kk;
-            if constexpr (CX) {
-                T v = B[min(gk, kend - 1) * b_ks + min(gc, n - 1) * b_cs];
-                v = maybe_conj(v, conjB);
-                if (!(gc < n && gk < kend)) v = T{};
-                rb[e] = v;
-            } else {
-                rb[e] = (gc < n && gk < kend) ? B[gk * b_ks + gc * b_cs] : T{};
+            for (int e = 0; e < EB; ++e) {
+                rb[e] = *pb[e];
+                pb[e] += b_step;
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EA; ++e) ra[e] = *((k0 + ka[e] < kend) ? pa[e] : A);
+#pragma unroll
+            for (int e = 0; e < EB; ++e) rb[e] = *((k0 + kb[e] < kend) ? pb[e] : B);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, long long k0) {     // k0 = first k of the tile held in ra / rb
         double* a0 = As + (buf * NP) * GK * LA;
         double* b0 = Bs + (buf * NP) * GK * LB;
+        if (k0 + GK <= kend) {
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            const int idx = tid + 256 * e;
-            const int i = a_rows_contig ? idx % BM : idx / GK;
-            const int kk = a_rows_contig ? idx / BM : idx % GK;
-            put_plane(a0, a0 + GK * LA, kk * LA + i, ra[e]);
-        }
+            for (int e = 0; e < EA; ++e) put_plane(a0, a0 + GK * LA, sa[e], maybe_conj(ra[e], conjA));
 #pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            const int idx = tid + 256 * e;
-            const int kk = b_k_contig ? idx % GK : idx / BN;
-            const int j = b_k_contig ? idx / GK : idx % BN;
-            put_plane(b0, b0 + GK * LB, kk * LB + j, rb[e]);
+            for (int e = 0; e < EB; ++e) put_plane(b0, b0 + GK * LB, sb[e], maybe_conj(rb[e], conjB));
+        } else {
+#pragma unroll
+            for (int e = 0; e < EA; ++e)
+                put_plane(a0, a0 + GK * LA, sa[e], (k0 + ka[e] < kend) ? maybe_conj(ra[e], conjA) : T{});
+#pragma unroll
+            for (int e = 0; e < EB; ++e)
+                put_plane(b0, b0 + GK * LB, sb[e], (k0 + kb[e] < kend) ? maybe_conj(rb[e], conjB) : T{});
         }
     };
     int buf = 0;
@@ -173,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long 
             if (k0 > kbeg) __syncthreads();         // everyone is done reading the single buffer
             load_tile(k0);
         }
-        store_tile(buf);
+        store_tile(buf, k0);
         __syncthreads();
         if (PIPE && k0 + GK < kend) load_tile(k0 + GK);     // in flight during the MFMAs below
         const double* a0 = As + (buf * NP) * GK * LA;
