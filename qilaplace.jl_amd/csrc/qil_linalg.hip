@@ -52,8 +52,10 @@ __device__ __forceinline__ void put_plane(double* S0, double* S1, int off, c64 v
 __device__ __forceinline__ double maybe_conj(double v, int) { return v; }
 __device__ __forceinline__ c64 maybe_conj(c64 v, int cj) { return cj ? c64{v.re, -v.im} : v; }
 
-template <class T, int BM, int BN, int WM, int WN, bool PIPE>
-__global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long long k_total,
+// ARC / BKC: op(A)'s row index / op(B)'s k index is the contiguous one in memory (compile time, so that the staging
+// pattern -- which element of the tile a thread loads and where it lands in LDS -- folds into constants).
+template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC>
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 2 : 1)) void gemm_mfma(long long m, long long n, long long k_total,
                                                  const T* __restrict__ A, long long a_rs, long long a_ks, int conjA,
                                                  const T* __restrict__ B, long long b_ks, long long b_cs, int conjB,
                                                  T* __restrict__ C, long long ldc, long long kchunk,
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_mfma(long long m, long long n, long 
     // tile per iteration), its row/column validity, its k offset and its LDS slot.  Inside the loop a load is a
     // compare, two selects and the load itself -- the per-element 64-bit index products used to cost ~20 VALU
     // instructions per element per tile and kept the wave off the matrix pipe.
-    const bool a_rows_contig = a_rs == 1, b_k_contig = b_ks == 1;
+    constexpr bool a_rows_contig = ARC, b_k_contig = BKC;
     T ra[EA], rb[EB];
     const T* pa[EA];
     const T* pb[EB];
@@ -270,11 +272,19 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
                 long long ldc, const gemm_batch& bt) {
     constexpr int NP = sizeof(T) == 16 ? 2 : 1;
     constexpr size_t lds = (size_t)(PIPE ? 2 : 1) * NP * GK * ((BM + 2) + (BN + 2)) * sizeof(double);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma<T, BM, BN, WM, WN, PIPE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    const bool arc = a_rs == 1, bkc = b_ks == 1;
+    using kern_t = void (*)(long long, long long, long long, const T*, long long, long long, int, const T*, long long,
+                            long long, int, T*, long long, long long, long long, int, int, int, long long, long long,
+                            long long, const int*, int, const uint8_t*, long long, long long);
+    const kern_t kern = arc ? (bkc ? (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, true, true>
+                                   : (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, true, false>)
+                            : (bkc ? (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, false, true>
+                                   : (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    if (lds > 64 * 1024 && !attr_set[arc * 2 + bkc]) {
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr_set[arc * 2 + bkc] = true;
     }
     const long long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
     const long long tiles = tiles_m * tiles_n;
@@ -299,8 +309,7 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     }
     // narrow outputs: neighbouring workgroups share the same rows of A (served from L2 / Infinity Cache)
     const int col_fastest = tiles_n <= 8 ? 1 : 0;
-    hipLaunchKernelGGL((gemm_mfma<T, BM, BN, WM, WN, PIPE>), dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits),
-                       dim3(256), lds, ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo,
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits), dim3(256), lds, ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo,
                        kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,
                        bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride);
     QIL_HIP(hipGetLastError());
@@ -339,6 +348,13 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
         // 97..144 output columns (RSVD sketches with k + p = 133): one 144-wide tile reads A ONCE and pads
         // 133 -> 144 columns instead of 192
         if (m >= 256 && n > 96 && n <= 144) QIL_GEMM_GO(128, 144, 32, 144, true);
+        // big outputs: 128 x 128 tiles, 4 x 4 MFMA tiles per wave (two fragment reads per MFMA step pair, 64 MFMAs
+        // between barriers) at 2 waves/SIMD -- 59 vs 52 TFLOP/s for the 128 x 64 tile at 4096^3
+        {
+            const long long t128 = ((m + 127) / 128) * ((n + 127) / 128);
+            const bool fills = (double)m * (double)n >= 0.85 * 16384.0 * (double)t128;   // little padding in edge tiles
+            if (t128 * batch.count >= 512 && fills) QIL_GEMM_GO(128, 128, 64, 64, true);
+        }
         if (m >= 256) QIL_GEMM_GO(128, 64, 64, 32, true);
         QIL_GEMM_GO(64, 64, 32, 32, true);
     }
