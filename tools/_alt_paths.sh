@@ -1,0 +1,12 @@
+#!/bin/bash
+# The GPU parity suite under tuning knobs that force the alternative code paths.
+run() { echo "== $*"; env "$@" timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -2; }
+run QIL_BJ_MIN=128
+run QIL_COEFF_GEMM_MINCHI=1 QIL_LAZY_GEMM_MIN=1
+run QIL_GEMM_CFG=0
+run QIL_GEMM_CFG=3
+run QIL_GEMM_CFG=1
+run QIL_APPLY_VARIANT=0
+run QIL_APPLY_VARIANT=2
+run QIL_RT_MIN=97
+run QIL_SYSTEM_HIP=1
