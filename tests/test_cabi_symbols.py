@@ -62,3 +62,24 @@ def test_product_package_never_imports_the_oracle():
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
     bench = open(os.path.join(ROOT, "qilaplace_jl_amd.py")).read()
     assert "oracle" not in bench
+
+
+def _build_c_client(tmp_path):
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "qilaplace.jl_amd", "lib")
+    exe = os.path.join(str(tmp_path), "cabi_client")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "cabi_client.c"), "-L", lib, "-lqilhip", f"-Wl,-rpath,{lib}", "-lm",
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_plain_c99_client_compiles_and_links(tmp_path):
+    """The header is C (not C++): a C99 translation unit using the boundary compiles warning-free and links against
+    libqilhip.so.  (It is RUN by the GPU suite.)"""
+    _build_c_client(tmp_path)

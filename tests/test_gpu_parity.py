@@ -1235,3 +1235,14 @@ def test_grid_fast_path_on_aligned_strides(qil):
         pk, pl = rng.permutation(len(ks)), rng.permutation(len(ls))
         slow = qil.coefficient_grid(psi, ks[pk], ls[pl])              # shuffled index sets: per-query path
         assert rel(fast[np.ix_(pk, pl)], slow) < 1e-12
+
+
+def test_plain_c_client_of_the_boundary(qil, tmp_path):
+    """tests/cabi_client.c: a C99 program (no Python, no C++ types) creates an MPS and an MPO from host tensors, applies,
+    reads all coefficients, compares with its own dense loops, and checks the status-code / qil_last_error convention."""
+    import subprocess
+    from test_cabi_symbols import _build_c_client
+    exe = _build_c_client(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C ABI client OK" in r.stdout
