@@ -209,8 +209,9 @@ __device__ __forceinline__ void jacobi_sweeps_nov(T* A, int lda, int m, int n, d
                 be = group_sum<G>(be);
                 gr = group_sum<G>(gr);
                 double c, sn, pr, pi_unused;
-                if (!jacobi_rotation<false>(al, be, gr, 0.0, tol, c, sn, pr, pi_unused)) continue;
-                if (lane == 0) *s_rot = 1;
+                bool big;
+                if (!jacobi_rotation<false>(al, be, gr, 0.0, tol, c, sn, pr, pi_unused, big)) continue;
+                if (lane == 0) atomicOr(s_rot, big ? 3 : 1);
                 for (int r = lane; r < m; r += G) {
                     T x = ap[r], y = aq[r];
                     rotate_pair(x, y, c, sn, pr, 0.0);
@@ -223,7 +224,7 @@ __device__ __forceinline__ void jacobi_sweeps_nov(T* A, int lda, int m, int n, d
         }
         const int any = *s_rot;
         __syncthreads();
-        if (!any) break;
+        if (!(any & 2)) break;
     }
 }
 

@@ -124,10 +124,17 @@ __device__ __forceinline__ double rcp_refined(double x) {
     return y * fma(-x, y, 2.0);
 }
 
+// kQuadraticOff: once every pair a sweep meets is already orthogonal to this relative level BEFORE its rotation, that sweep
+// (quadratic convergence) leaves all of them at rounding level: the iteration stops there instead of spending one more
+// sweep on a handful of 1e-15-level rotations and another one on finding nothing to do.  `big` reports whether this
+// pair was above that level.
+constexpr double kQuadraticOff = 1e-9;
+
 template <bool CX>
 __device__ __forceinline__ bool jacobi_rotation(double al, double be, double gr, double gi, double tol,
-                                                double& c, double& s, double& pr, double& pi) {
+                                                double& c, double& s, double& pr, double& pi, bool& big) {
     double half_inv_g;
+    big = (gr * gr + gi * gi) > kQuadraticOff * kQuadraticOff * al * be;
     if (CX) {
         const double g2 = gr * gr + gi * gi;
         if (!(g2 > tol * tol * al * be) || g2 == 0.0) return false;
@@ -200,8 +207,9 @@ __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ld
                 gr = group_sum<G>(gr);
                 if (sizeof(T) == 16) gi = group_sum<G>(gi);
                 double c, sn, pr, pi;
-                if (!jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, tol, c, sn, pr, pi)) continue;
-                if (lane == 0) *s_rot = 1;
+                bool big;
+                if (!jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, tol, c, sn, pr, pi, big)) continue;
+                if (lane == 0) atomicOr(s_rot, big ? 3 : 1);
                 for (int r = lane; r < m; r += G) {
                     T x = ap[r], y = aq[r];
                     rotate_pair(x, y, c, sn, pr, pi);
@@ -222,7 +230,7 @@ __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ld
         }
         const int any = *s_rot;
         __syncthreads();
-        if (!any) break;
+        if (!(any & 2)) break;      // nothing rotated, or only pairs already below the quadratic-phase level
     }
 }
 

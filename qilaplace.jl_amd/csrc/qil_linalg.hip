@@ -396,8 +396,12 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
     }
     block_sum<4>(v, red);
     double c, s, pr, pi;
-    if (!jacobi_rotation<sizeof(T) == 16>(v[0], v[1], v[2], v[3], tol, c, s, pr, pi)) return;
-    if (threadIdx.x == 0) *rotated = 1;
+    bool big;
+    if (!jacobi_rotation<sizeof(T) == 16>(v[0], v[1], v[2], v[3], tol, c, s, pr, pi, big)) return;
+    if (threadIdx.x == 0) {      // plain stores of the same value from every rotating workgroup: no atomics needed
+        rotated[0] = 1;
+        if (big) rotated[1] = 1;
+    }
     for (long long r = threadIdx.x; r < m; r += 256) {
         T x = ap[r], y = aq[r];
         rotate_pair(x, y, c, s, pr, pi);
@@ -989,15 +993,16 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         }
         const int nn = (int)nj, npad = nn + (nn & 1);
         for (int sweep = 0; sweep < 40 && nn > 1 && !bj_done; ++sweep) {
-            QIL_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+            QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
             for (int round = 0; round < npad - 1; ++round)
                 hipLaunchKernelGGL(jacobi_round<T>, dim3(npad / 2), dim3(256), 0, ctx->stream, Wk, ldw, rows, V,
                                    ldv, (int)cols, nn, npad, round, tol, (int*)flag);
-            int h = 0;
-            QIL_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            int hv[2] = {0, 0};
+            QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             QIL_HIP(hipStreamSynchronize(ctx->stream));
-            if (getenv("QIL_SVD_DEBUG")) fprintf(stderr, "[svd] scalar sweep %d (cols %lld): rotated=%d\n", sweep, nj, h);
-            if (!h) break;
+            if (getenv("QIL_SVD_DEBUG")) fprintf(stderr, "[svd] scalar sweep %d (cols %lld): rotated=%d above-quadratic=%d\n", sweep, nj, hv[0], hv[1]);
+            static const bool early = !(getenv("QIL_JACOBI_EARLY") && atoi(getenv("QIL_JACOBI_EARLY")) == 0);   // tuning aid
+            if (!(early ? hv[1] : hv[0])) break;   // nothing rotated, or only pairs already below the quadratic-phase level
         }
         hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)nj), dim3(256), 0, ctx->stream, Wk, ldw, rows,
                            (double*)nrm);
