@@ -1246,3 +1246,46 @@ def test_plain_c_client_of_the_boundary(qil, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "C ABI client OK" in r.stdout
+
+
+def test_two_contexts_from_two_threads(qil):
+    """SURVEY 8b threading row: calls on different contexts are thread-safe (one HIP stream and one pool per context,
+    thread-local error state).  Two host threads, each with its own context, run the whole path concurrently."""
+    import threading
+    rng = np.random.default_rng(77)
+    L = 10
+    a = random_mps_data(saturated_profile(L, 12), rng)
+    w = random_mpo_data(saturated_profile(L, 8, base=4), rng)
+    bits = rng.integers(0, 2, size=(64, L))
+    ref = O.coefficient_batch(O.apply(O.SingleSiteMPO(w), O.SignalMPS(a)), bits)
+    t = np.arange(1 << 10) / 1024.0
+    x = np.sin(2 * np.pi * 3 * t) * np.exp(-2 * t)
+    errors, results = [], {}
+
+    def worker(tag):
+        try:
+            ctx = qil.Context(0)
+            for it in range(20):
+                psi, W = qil.SignalMPS(a, ctx=ctx), qil.SingleSiteMPO(w, ctx=ctx)
+                out = W * psi
+                got = qil.coefficient_batch(out, bits)
+                assert rel(got, ref) < 1e-12, (tag, it)
+                qil.compress(out, maxdim=6, tol=1e-8)
+                assert max(out.bond_dims) <= 6
+                enc = qil.signal_mps(x, method="rsvd", k=32, p=4, q=1, ctx=ctx)        # 32 = rank of every split: exact
+                assert rel(qil.mps_to_vector(enc), x) < 1e-6
+                try:
+                    qil.coefficient(psi, [0] * (L + 1))              # an error on this thread ...
+                except ValueError as e:
+                    assert "expected" in str(e) or "length" in str(e).lower() or str(e)
+            results[tag] = True
+        except Exception as e:                                       # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in ("A", "B")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert results == {"A": True, "B": True}
