@@ -1289,3 +1289,56 @@ def test_two_contexts_from_two_threads(qil):
         t.join()
     assert not errors, errors
     assert results == {"A": True, "B": True}
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_paired_pipeline_against_oracle(qil, seed):
+    """Random paired-register objects: ZTMPS x PairedSiteMPO apply, MPO x MPO products of different lengths (window
+    semantics, apply.jl:124-199), marginals and dense sub-lattice read-outs, all against the oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(1, 5))
+    L = 2 * n
+    adt = np.complex128 if rng.random() < 0.5 else np.float64
+    wdt = np.complex128 if rng.random() < 0.5 else np.float64
+    a = random_mps_data(saturated_profile(L, int(rng.integers(1, 7))), rng, dtype=adt)
+    w = random_mpo_data(saturated_profile(L, int(rng.integers(1, 6)), base=4), rng, dtype=wdt)
+    amp = float(rng.uniform(0.2, 4.0))
+    psi, W = qil.ZTMPS(a, amplitude=amp), qil.PairedSiteMPO(w)
+    opsi, oW = O.ZTMPS(a, amplitude=amp), O.PairedSiteMPO(w)
+    out, oout = W * psi, O.apply(oW, opsi)
+    assert out.bond_dims == [t.shape[2] for t in oout.data[:-1]]
+    assert rel(qil.mps_to_vector(out), O.mps_to_vector(oout)) < 1e-12
+    # MPO x MPO with a shorter second operand (window = leading sites), then applied
+    m2 = int(rng.integers(1, n + 1))
+    w2 = random_mpo_data(saturated_profile(2 * m2, 3, base=4), rng, dtype=np.complex128)
+    W2, oW2 = qil.PairedSiteMPO(w2), O.PairedSiteMPO(w2)
+    prod, oprod = W * W2, O.apply_mpo_mpo(oW, oW2)
+    assert prod.bond_dims == [t.shape[3] for t in oprod.data[:-1]]
+    assert rel(qil.mps_to_vector(prod * psi), O.mps_to_vector(O.apply(oprod, opsi))) < 1e-12
+    # marginals and sub-lattice blocks of the applied state
+    spec = rng.integers(0, 4, size=L).astype(np.uint8)
+    free = np.flatnonzero(spec == 3)
+    F = len(free)
+    cfg = np.tile(spec, (2 ** F, 1))
+    for idx in range(2 ** F):
+        for pos, site in enumerate(free):
+            cfg[idx, site] = (idx >> (F - 1 - pos)) & 1
+    want = []
+    for row in cfg:                                   # oracle: expand the summed sites explicitly
+        summed = np.flatnonzero(row == 2)
+        tot = 0.0
+        for k in range(2 ** len(summed)):
+            r = row.copy()
+            for pos, site in enumerate(summed):
+                r[site] = (k >> pos) & 1
+            tot = tot + O.coefficient(oout, list(r))
+        want.append(tot)
+    want = np.array(want)
+    assert rel(qil.marginal_batch(out, cfg), want) < 1e-12
+    assert rel(qil.mps_block(out, spec), want) < 1e-12
+    # lazy read-out of the same numbers without the product
+    if F:
+        fixed_cfg = cfg.copy()
+        fixed_cfg[fixed_cfg == 2] = 0
+        lazy = qil.apply_coefficient_batch(W, psi, fixed_cfg)
+        assert rel(lazy, O.coefficient_batch(oout, fixed_cfg)) < 1e-12
