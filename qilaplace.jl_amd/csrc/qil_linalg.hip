@@ -1184,7 +1184,8 @@ __global__ __launch_bounds__(256) void tsqr_apply_q2(T* __restrict__ P, long lon
 template <class T>
 int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, long long ldr,
                const double* ref_norm) {
-    const long long chunk = std::max<long long>(2048, (m / 512 + 255) / 256 * 256);
+    static const long long min_chunk = getenv("QIL_TSQR_MIN_CHUNK") ? atoll(getenv("QIL_TSQR_MIN_CHUNK")) : 2048;
+    const long long chunk = std::max<long long>(min_chunk, (m / 512 + 255) / 256 * 256);
     const long long nch = (m + chunk - 1) / chunk;
     void *rs = nullptr, *r2 = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nch * b * b) * sizeof(T), &rs));
@@ -1212,7 +1213,7 @@ int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, 
 //     spread over the chip by the GEMMs and the launch count drops from ~5 n to ~7 n / 16.
 template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
-    constexpr long long TALL = 8192;
+    static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 8192;   // tuning aid
     if (n <= 16 || m * n <= (1LL << 15)) {
         if (m >= TALL && n <= 16) {
             void* nb0 = nullptr;
