@@ -10,9 +10,14 @@ using ITensors
 import ITensors: apply
 import Base: *, getindex, length
 import LinearAlgebra: norm
+import ..Mps
+import ..Mps: coefficient, compress!, canonicalize!, mps_to_vector      # extended below with device methods
 using ..Mps: SignalMPS, ZTMPS, _as_signal_2n, _writeback_signal_2n
 using ..Mpo: SingleSiteMPO, PairedSiteMPO
 using ..ApplyMPO: _as_single_site_mpo
+
+export DeviceMPS, DeviceMPO, to_device, to_host, signal_mps_device, marginal, mps_block, apply_compress,
+    compress_mpo!, build_dt_mpo_batch
 
 const LIB = get(ENV, "QILHIP_LIB", "libqilhip.so")
 
@@ -130,7 +135,7 @@ function coefficient(psi::DeviceMPS, bits::AbstractMatrix{<:Integer})          #
     n == length(psi) || throw(ArgumentError("coefficient: expected $(length(psi)) entries, got $n"))
     b = Matrix{UInt8}(permutedims(bits))                                        # query-major for the ABI
     out = Vector{ComplexF64}(undef, nb)
-    check(ccall((:qil_coefficient_batch, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cdouble}),
+    check(ccall((:qil_coefficient_batch, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cvoid}),
                 psi.h, nb, b, out))
     return out
 end
@@ -139,7 +144,7 @@ function marginal(psi::DeviceMPS, bits::AbstractMatrix{<:Integer})
     nb, n = size(bits)
     b = Matrix{UInt8}(permutedims(bits))
     out = Vector{ComplexF64}(undef, nb)
-    check(ccall((:qil_coefficient_marginal_batch, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cdouble}),
+    check(ccall((:qil_coefficient_marginal_batch, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cvoid}),
                 psi.h, nb, b, out))
     return out
 end
