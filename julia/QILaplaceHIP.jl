@@ -193,10 +193,17 @@ function signal_mps_device(x::AbstractVector{<:Number}; method::Symbol=:svd, cut
     T = eltype(x) <: Complex ? ComplexF64 : Float64
     xs = Vector{T}(x)
     r = Ref{Ptr{Cvoid}}(C_NULL)
-    f = paired ? :qil_signal_ztmps : :qil_signal_mps
-    check(ccall((f, LIB), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Cint, Cdouble, Int64, Int64, Int64, Cint, UInt64, Int64, Ref{Ptr{Cvoid}}),
-        ctx().h, xs, length(xs), _code(T), method == :svd ? 0 : 1, cutoff, maxdim, k, p, q, random_seed, mindim, r))
+    meth = method == :svd ? 0 : 1
+    # (the symbol in a ccall must be a literal, hence the two branches)
+    if paired
+        check(ccall((:qil_signal_ztmps, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Cint, Cdouble, Int64, Int64, Int64, Cint, UInt64, Int64, Ref{Ptr{Cvoid}}),
+            ctx().h, xs, length(xs), _code(T), meth, cutoff, maxdim, k, p, q, random_seed, mindim, r))
+    else
+        check(ccall((:qil_signal_mps, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Cint, Cdouble, Int64, Int64, Int64, Cint, UInt64, Int64, Ref{Ptr{Cvoid}}),
+            ctx().h, xs, length(xs), _code(T), meth, cutoff, maxdim, k, p, q, random_seed, mindim, r))
+    end
     n = round(Int, log2(length(xs)))
     sites = [Index(2; tags="site-$i") for i in 1:(paired ? 2n : n)]
     return finalizer(_free!, DeviceMPS(r[], sites, paired))
