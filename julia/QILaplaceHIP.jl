@@ -204,7 +204,7 @@ function signal_mps_device(x::AbstractVector{<:Number}; method::Symbol=:svd, cut
             (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Cint, Cdouble, Int64, Int64, Int64, Cint, UInt64, Int64, Ref{Ptr{Cvoid}}),
             ctx().h, xs, length(xs), _code(T), meth, cutoff, maxdim, k, p, q, random_seed, mindim, r))
     end
-    n = round(Int, log2(length(xs)))
+    n = max(1, round(Int, log2(length(xs))))
     sites = [Index(2; tags="site-$i") for i in 1:(paired ? 2n : n)]
     return finalizer(_free!, DeviceMPS(r[], sites, paired))
 end
