@@ -79,13 +79,23 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 2 : 1)) void gemm_mfma
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = (wave % (BM / WM)) * WM, wc = (wave / (BM / WM)) * WN;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b
+    // runs on XCD b % 8.  Give every XCD one CONTIGUOUS eighth of the tile sequence instead of every eighth tile:
+    // neighbouring tiles share an operand panel, and now they also share an L2.  (bit 1 of col_fastest switches it off.)
+    int tile = blockIdx.x;
+    const int ntiles = tiles_m * tiles_n;
+    if (!(col_fastest & 2) && ntiles >= 64) {
+        const int per = (ntiles + 7) / 8;
+        const int t2 = (tile % 8) * per + tile / 8;
+        if ((ntiles % 8) == 0) tile = t2;          // exact split only: keeps the map a bijection without a table
+    }
     int tm, tn;
-    if (col_fastest) {
-        tn = blockIdx.x % tiles_n;
-        tm = blockIdx.x / tiles_n;
+    if (col_fastest & 1) {
+        tn = tile % tiles_n;
+        tm = tile / tiles_n;
     } else {
-        tm = blockIdx.x % tiles_m;
-        tn = blockIdx.x / tiles_m;
+        tm = tile % tiles_m;
+        tn = tile / tiles_m;
     }
     const long long row0 = (long long)tm * BM, col0 = (long long)tn * BN;
     const long long kbeg = (long long)blockIdx.z * kchunk;
@@ -308,7 +318,8 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
         ldo = m;
     }
     // narrow outputs: neighbouring workgroups share the same rows of A (served from L2 / Infinity Cache)
-    const int col_fastest = tiles_n <= 8 ? 1 : 0;
+    static const bool xcd_order = !(getenv("QIL_GEMM_XCD") && atoi(getenv("QIL_GEMM_XCD")) == 0);   // tuning aid
+    const int col_fastest = (tiles_n <= 8 ? 1 : 0) | (xcd_order ? 0 : 2);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits), dim3(256), lds, ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo,
                        kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,
                        bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride);
