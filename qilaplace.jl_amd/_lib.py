@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqilhip.so")
+LIB_PATH = os.environ.get("QILHIP_LIB") or os.path.join(_HERE, "lib", "libqilhip.so")   # same variable as the Julia shim
 
 QIL_F64, QIL_C64 = 0, 1
 QIL_METHOD_SVD, QIL_METHOD_RSVD = 0, 1

@@ -39,6 +39,10 @@ using namespace qil_dev;
 //     the global->register mapping follows whichever index is contiguous (coalesced either way);
 //   * gridDim.z > 1 = split-K into a workspace + fixed-order reduction (deterministic).
 constexpr int GK = 16;
+#ifndef QIL_GEMM_PAD
+#define QIL_GEMM_PAD 2
+#endif
+constexpr int GPAD = QIL_GEMM_PAD;   // LDS row padding in doubles
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void put_plane(double* S0, double* S1, int off, double v) {
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 2 : 1)) void gemm_mfma
                                                  long long b_sel_stride) {
     constexpr bool CX = sizeof(T) == 16;
     constexpr int NP = CX ? 2 : 1;
-    constexpr int LA = BM + 2, LB = BN + 2;   // +2 doubles: <= 2-way LDS conflicts for both the k-major
+    constexpr int LA = BM + GPAD, LB = BN + GPAD;   // +2 doubles: <= 2-way LDS conflicts for both the k-major
                                               // staging writes and the fragment reads
     constexpr int NBUF = PIPE ? 2 : 1;
     constexpr int TM = WM / 16, TN = WN / 16;
@@ -281,7 +285,7 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
                 long long a_ks, int conjA, const T* B, long long b_ks, long long b_cs, int conjB, T* C,
                 long long ldc, const gemm_batch& bt) {
     constexpr int NP = sizeof(T) == 16 ? 2 : 1;
-    constexpr size_t lds = (size_t)(PIPE ? 2 : 1) * NP * GK * ((BM + 2) + (BN + 2)) * sizeof(double);
+    constexpr size_t lds = (size_t)(PIPE ? 2 : 1) * NP * GK * ((BM + GPAD) + (BN + GPAD)) * sizeof(double);
     const bool arc = a_rs == 1, bkc = b_ks == 1;
     using kern_t = void (*)(long long, long long, long long, const T*, long long, long long, int, const T*, long long,
                             long long, int, T*, long long, long long, long long, int, int, int, long long, long long,
