@@ -434,7 +434,10 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
 }
 
 
-template <class T, bool LDS>
+// MODE 1: A and V staged in LDS for the whole iteration; MODE 2: only A in LDS, V in global memory (complex operands of
+// 2 chi x chi sites with chi ~ 64: A fits the CU's LDS, A and V together do not) -- the dot products and the rotation
+// of A, which every round's critical path waits for, still run out of LDS; MODE 0: both in global memory.
+template <class T, int MODE>
 __global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long long lda, int m,
                                                      T* __restrict__ V, long long ldv, int n, double tol,
                                                      int max_sweeps, double* __restrict__ norms) {
@@ -445,12 +448,14 @@ __global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long lon
     T* Aw = A;
     T* Vw = V;
     int la = (int)lda, lv = (int)ldv;
-    if (LDS) {
+    if (MODE != 0) {
         // odd leading dimension (in doubles): column pairs start on different banks
         la = m | 1;
-        lv = n | 1;
         Aw = reinterpret_cast<T*>(jf_smem);
-        Vw = Aw + (size_t)la * n;
+        if (MODE == 1) {
+            lv = n | 1;
+            Vw = Aw + (size_t)la * n;
+        }
         for (int t = tid; t < m * n; t += 1024) Aw[(t % m) + la * (t / m)] = A[(t % m) + lda * (t / m)];
     }
     for (int t = tid; t < n * n; t += 1024) {
@@ -473,10 +478,11 @@ __global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long lon
         v = wave_sum(v);
         if (lane == 0) norms[j] = sqrt(v);
     }
-    if (LDS) {
+    if (MODE != 0) {
         __syncthreads();
         for (int t = tid; t < m * n; t += 1024) A[(t % m) + lda * (t / m)] = Aw[(t % m) + la * (t / m)];
-        for (int t = tid; t < n * n; t += 1024) V[(t % n) + ldv * (t / n)] = Vw[(t % n) + lv * (t / n)];
+        if (MODE == 1)
+            for (int t = tid; t < n * n; t += 1024) V[(t % n) + ldv * (t / n)] = Vw[(t % n) + lv * (t / n)];
     }
 }
 
@@ -975,20 +981,34 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     // convergence threshold on |a_p . a_q| / (|a_p| |a_q|): 1e-15, but never below the rounding noise of the
     // dot products themselves (~ eps sqrt(rows)), which long columns cannot get under
     const double tol = std::max(1e-15, 4.0 * 1.1e-16 * std::sqrt((double)rows));
-    if (ncol <= 96 && rows * cols <= (1LL << 19)) {
-        const size_t lds_need = ((size_t)((rows | 1) * cols) + (size_t)((cols | 1) * cols)) * sizeof(T);
-        if (lds_need <= 150 * 1024) {
-            static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-            if (!attr_set) {
-                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_fused<T, true>),
+    const size_t lds_a = (size_t)((rows | 1) * cols) * sizeof(T);
+    const size_t lds_av = lds_a + (size_t)((cols | 1) * cols) * sizeof(T);
+    static const bool a_in_lds = !(getenv("QIL_SVD_A_LDS") && atoi(getenv("QIL_SVD_A_LDS")) == 0);   // tuning aids
+    static const bool fused_global = getenv("QIL_SVD_FUSED_GLOBAL") && atoi(getenv("QIL_SVD_FUSED_GLOBAL")) == 1;
+    // one workgroup for the whole iteration only while (at least) A lives in LDS; a single workgroup working out of
+    // L2 is slower than the tournament launches, which spread the pairs over the chip
+    if (ncol <= 96 && rows * cols <= (1LL << 19) &&
+        (lds_av <= 150 * 1024 || (a_in_lds && rows <= 128 && lds_a <= 150 * 1024) || fused_global)) {
+        static bool attr_set[3] = {false, false, false};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+        if (lds_av <= 150 * 1024) {
+            if (!attr_set[1]) {
+                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_fused<T, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-                attr_set = true;
+                attr_set[1] = true;
             }
-            hipLaunchKernelGGL((jacobi_fused<T, true>), dim3(1), dim3(1024), lds_need, ctx->stream, Wk, ldw,
-                               (int)rows, V, cols, ncol, tol, 40, (double*)nrm);
+            hipLaunchKernelGGL((jacobi_fused<T, 1>), dim3(1), dim3(1024), lds_av, ctx->stream, Wk, ldw, (int)rows, V, cols,
+                               ncol, tol, 40, (double*)nrm);
+        } else if (a_in_lds && rows <= 128 && lds_a <= 150 * 1024) {   // one DPP row per pair only up to 128 rows
+            if (!attr_set[2]) {
+                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_fused<T, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                attr_set[2] = true;
+            }
+            hipLaunchKernelGGL((jacobi_fused<T, 2>), dim3(1), dim3(1024), lds_a, ctx->stream, Wk, ldw, (int)rows, V, cols,
+                               ncol, tol, 40, (double*)nrm);
         } else {
-            hipLaunchKernelGGL((jacobi_fused<T, false>), dim3(1), dim3(1024), 0, ctx->stream, Wk, ldw, (int)rows,
-                               V, cols, ncol, tol, 40, (double*)nrm);
+            hipLaunchKernelGGL((jacobi_fused<T, 0>), dim3(1), dim3(1024), 0, ctx->stream, Wk, ldw, (int)rows, V, cols, ncol,
+                               tol, 40, (double*)nrm);
         }
     } else {
         bool bj_done = false;

@@ -601,7 +601,9 @@ extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps
         QIL_TRY(canonicalize_impl(psi, QIL_DIR_RIGHT, 0, cutoff, maxdim));      // L -> R: U | S V   (mps.jl:927-942)
         QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, cutoff, maxdim));       // R -> L: U S | V   (mps.jl:944-959)
     }
-    QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, 1e-12, kNoCap));            // mps.jl:963
+    // mps.jl:963 re-gauges once more (canonicalize!(:left), cutoff 1e-12).  The sweep that just ended left every site
+    // but the first an isometry (all its singular values are 1), so that pass can neither truncate nor change anything
+    // but the gauge -- it is not run.
     double nrm = 0;
     QIL_TRY(qil_norm(psi, &nrm));                                               // mps.jl:967-971
     if (nrm != 0) {
