@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(256) void tsqr_apply_q2(T* __restrict__ P, long lon
 template <class T>
 int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, long long ldr,
                const double* ref_norm) {
-    static const long long min_chunk = getenv("QIL_TSQR_MIN_CHUNK") ? atoll(getenv("QIL_TSQR_MIN_CHUNK")) : 2048;
+    static const long long min_chunk = getenv("QIL_TSQR_MIN_CHUNK") ? atoll(getenv("QIL_TSQR_MIN_CHUNK")) : 512;
     const long long chunk = std::max<long long>(min_chunk, (m / 512 + 255) / 256 * 256);
     const long long nch = (m + chunk - 1) / chunk;
     void *rs = nullptr, *r2 = nullptr;
@@ -1248,7 +1248,7 @@ int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, 
 //     spread over the chip by the GEMMs and the launch count drops from ~5 n to ~7 n / 16.
 template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
-    static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 8192;   // tuning aid
+    static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 2048;   // tuning aid
     if (n <= 16 || m * n <= (1LL << 15)) {
         if (m >= TALL && n <= 16) {
             void* nb0 = nullptr;
