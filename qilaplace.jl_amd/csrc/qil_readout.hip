@@ -170,26 +170,6 @@ __global__ __launch_bounds__(kThreads) void lazy_coefficient_chain(const ChainSi
 // One step of the dense contraction: T_k[beta + cr*idx'] = sum_alpha T_{k-1}[alpha + cl*idx] * A[alpha, s, beta]
 //   reverse = 0: idx' = 2*idx + s (site 1 = MSB);  reverse = 1: idx' = idx + s * 2^(k-1) (site 1 = LSB)
 template <class T>
-__global__ void to_vector_step(const T* __restrict__ Tin, const T* __restrict__ A, T* __restrict__ Tout, int cl,
-                               int cr, long long nprev, int reverse) {
-    const long long total = nprev * 2 * cr;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
-         t += (long long)gridDim.x * blockDim.x) {
-        const int beta = (int)(t % cr);
-        const long long u = t / cr;  // (idx, s) with s fastest
-        const int s = (int)(u & 1);
-        const long long idx = u >> 1;
-        const long long idxp = reverse ? idx + (long long)s * nprev : 2 * idx + s;
-        const T* row = Tin + (long long)cl * idx;
-        const T* col = A + (long long)cl * (s + 2LL * beta);
-        T acc{};
-        for (int al = 0; al < cl; ++al) acc = cmul_add(acc, row[al], col[al]);
-        Tout[beta + (long long)cr * idxp] = acc;
-    }
-}
-
-// batched path: Vn[q, beta] = T[q, bit_q + 2*beta]  (T = V * A_i viewed as chi_l x (2 chi_r))
-template <class T>
 __global__ void select_slice(const T* __restrict__ Tm, long long nb, int cr, const uint8_t* __restrict__ bits,
                              int n, int site, T* __restrict__ Vn) {
     const long long total = nb * cr;
@@ -219,11 +199,6 @@ __global__ void finish_coeff(const T* __restrict__ v, long long nb, double ampli
     }
 }
 
-__global__ void scale_real(double* p, long long n, double s) {
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
-         t += (long long)gridDim.x * blockDim.x)
-        p[t] *= s;
-}
 
 // ---- dense read-out of a sub-lattice of configurations (grid scans) --------------------------------------
 template <class T>
@@ -663,48 +638,13 @@ extern "C" int qil_mps_block(const qil_mps* psi, const uint8_t* spec, int revers
 }
 
 extern "C" int qil_mps_to_vector(const qil_mps* psi, int reverse, void* host_out) {
+    // every site free: the dense block read-out above (one MFMA GEMM per site; at n = 24 with 4096-wide bonds 0.73 s
+    // of vector-ALU steps became a few tens of ms)
     QIL_REQUIRE(psi && host_out, QIL_EINVAL_ARG, "mps_to_vector: null argument");
-    qil_context* ctx = psi->ctx;
-    QIL_TRY(qil_ctx_activate(ctx));
-    qil_call_scope call_scope(ctx);
-    const int64_t n = psi->n();
-    QIL_REQUIRE(n <= 34, QIL_EINVAL_LENGTH, "mps_to_vector: %lld sites is too many for a dense vector", (long long)n);
-    const size_t esz = qil_elem_size(psi->dtype);
-    long long maxel = 1;
-    for (int64_t k = 0; k < n; ++k) maxel = std::max<long long>(maxel, (1LL << (k + 1)) * psi->dims[(size_t)k + 1]);
-    void *bufA = nullptr, *bufB = nullptr;
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxel * esz, &bufA));
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxel * esz, &bufB));
-    // T_0 = [1]
-    const double one[2] = {1.0, 0.0};
-    QIL_HIP(hipMemcpyAsync(bufA, one, esz, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
-    void *cur = bufA, *nxt = bufB;
-    long long nprev = 1;
-    for (int64_t k = 0; k < n; ++k) {
-        const int cl = (int)psi->dims[(size_t)k], cr = (int)psi->dims[(size_t)k + 1];
-        const long long total = nprev * 2 * cr;
-        const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 65536);
-        if (psi->dtype == QIL_C64)
-            hipLaunchKernelGGL(to_vector_step<c64>, dim3(blocks), dim3(256), 0, ctx->stream, (const c64*)cur,
-                               (const c64*)psi->site[(size_t)k], (c64*)nxt, cl, cr, nprev, reverse ? 1 : 0);
-        else
-            hipLaunchKernelGGL(to_vector_step<double>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               (const double*)cur, (const double*)psi->site[(size_t)k], (double*)nxt, cl, cr,
-                               nprev, reverse ? 1 : 0);
-        std::swap(cur, nxt);
-        nprev *= 2;
-    }
-    const long long N = 1LL << n;
-    const long long nd = N * (psi->dtype == QIL_C64 ? 2 : 1);
-    hipLaunchKernelGGL(scale_real, dim3((unsigned)std::min<long long>((nd + 255) / 256, 65536)), dim3(256), 0,
-                       ctx->stream, (double*)cur, nd, psi->amplitude);
-    QIL_HIP(hipGetLastError());
-    QIL_HIP(hipMemcpyAsync(host_out, cur, (size_t)N * esz, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
-    qil_ctx_free(ctx, bufA);
-    qil_ctx_free(ctx, bufB);
-    return QIL_OK;
+    QIL_REQUIRE(psi->n() <= 34, QIL_EINVAL_LENGTH, "mps_to_vector: %lld sites is too many for a dense vector",
+                (long long)psi->n());
+    std::vector<uint8_t> spec((size_t)psi->n(), (uint8_t)3);
+    return qil_mps_block(psi, spec.data(), reverse, host_out);
 }
 
 // norm(psi) = sqrt(|<psi|psi>|): E' = A^H (E A) per site, two GEMMs on the matricised site tensor.
