@@ -860,7 +860,7 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
         attr_set = true;
     }
     const int opH = sizeof(T) == 16 ? 2 : 1;
-    static const int inner_sweeps = getenv("QIL_BJ_INNER") ? atoi(getenv("QIL_BJ_INNER")) : 2;   // tuning aid
+    static const int inner_sweeps = getenv("QIL_BJ_INNER") ? atoi(getenv("QIL_BJ_INNER")) : 1;   // tuning aid
     gemm_batch bg, bu;
     bg.count = np;
     bg.a_bs = bg.b_bs = (long long)BJ_W * ldx;
