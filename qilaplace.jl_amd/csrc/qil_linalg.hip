@@ -679,7 +679,10 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
 constexpr int BJ_B = 32;
 constexpr int BJ_W = 2 * BJ_B;
 
-template <class T>
+// TWO_SIDED: the visit's sweep is run as two-sided rotations on G itself (G <- R^H G R, angles from the current
+// 2 x 2 blocks) instead of a Cholesky factorisation followed by a one-sided sweep on L^H: no factorisation, no dot
+// products, three short phases per round.
+template <class T, bool TWO_SIDED>
 __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* __restrict__ Jm, double tol,
                                                     int max_sweeps, int* __restrict__ flag,
                                                     const int* __restrict__ big_second) {
@@ -720,59 +723,142 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
         }
         return;
     }
-    // Cholesky of the (semi-definite) Gram matrix, lower triangle, right-looking, ONE barrier per step: the
-    // trailing update uses the UNSCALED column j and 1 / pivot, the columns are scaled by 1 / sqrt(pivot) only
-    // when L^H is written out.  A pivot at rounding level of its original diagonal closes that column
-    // (dependent / zero / padding columns).
-    for (int j = 0; j < N; ++j) {
+    if (TWO_SIDED) {
+        __shared__ double rc[N / 2], rs[N / 2], rpr[N / 2], rpi[N / 2];
+        __shared__ int rp[N / 2], rq[N / 2];
+        for (int t = tid; t < N * N; t += 512) {
+            const int r = t % N, c = t / N;
+            T v{};
+            if (r == c) reinterpret_cast<double*>(&v)[0] = 1.0;
+            Vw[r + LD * c] = v;
+        }
         __syncthreads();
-        const double d = reinterpret_cast<const double*>(&Aw[j + LD * j])[0];
-        const bool dead = !(d > 1e-14 * d0[j]);
-        const double inv = dead ? 0.0 : 1.0 / d;
-        if (tid == 0) lam[j] = dead ? 0.0 : d;
-        const int rem = N - 1 - j;
-        for (int t = tid; t < rem * rem; t += 512) {
-            const int i = j + 1 + t % rem, k = j + 1 + t / rem;
-            if (k <= i)
-                Aw[i + LD * k] = sub_t(Aw[i + LD * k], scale_t(fma_t(Aw[i + LD * j], conj_t(Aw[k + LD * j]), T{}), inv));
+        const int lane = tid & 15, grp = tid >> 4;       // 32 groups of 16 lanes, one column pair each
+        for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+            for (int round = 0; round < N - 1; ++round) {
+                // phase A: rotation of every pair from the current 2 x 2 blocks
+                if (tid < N / 2) {
+                    int p, q;
+                    if (tid == 0) {
+                        p = N - 1;
+                        q = round;
+                    } else {
+                        p = (round + tid) % (N - 1);
+                        q = (round + N - 1 - tid) % (N - 1);
+                    }
+                    if (p > q) {
+                        const int t2 = p;
+                        p = q;
+                        q = t2;
+                    }
+                    const double al = reinterpret_cast<const double*>(&Aw[p + LD * p])[0];
+                    const double be = reinterpret_cast<const double*>(&Aw[q + LD * q])[0];
+                    const T g = Aw[p + LD * q];
+                    const double gr = reinterpret_cast<const double*>(&g)[0];
+                    const double gi = sizeof(T) == 16 ? reinterpret_cast<const double*>(&g)[1] : 0.0;
+                    double c = 1.0, sn = 0.0, pr = 1.0, pi = 0.0;
+                    bool big;
+                    if (!jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, 1e-15, c, sn, pr, pi, big)) {
+                        c = 1.0;
+                        sn = 0.0;
+                    }
+                    rp[tid] = p;
+                    rq[tid] = q;
+                    rc[tid] = c;
+                    rs[tid] = sn;
+                    rpr[tid] = pr;
+                    rpi[tid] = pi;
+                }
+                __syncthreads();
+                {   // phase B: columns p, q of G and of J
+                    const int p = rp[grp], q = rq[grp];
+                    const double c = rc[grp], sn = rs[grp], pr = rpr[grp], pi = rpi[grp];
+                    if (sn != 0.0) {
+                        for (int r = lane; r < N; r += 16) {
+                            T x = Aw[r + LD * p], y = Aw[r + LD * q];
+                            rotate_pair(x, y, c, sn, pr, pi);
+                            Aw[r + LD * p] = x;
+                            Aw[r + LD * q] = y;
+                            T u = Vw[r + LD * p], w = Vw[r + LD * q];
+                            rotate_pair(u, w, c, sn, pr, pi);
+                            Vw[r + LD * p] = u;
+                            Vw[r + LD * q] = w;
+                        }
+                    }
+                }
+                __syncthreads();
+                {   // phase C: rows p, q of G (R^H from the left = the conjugate rotation)
+                    const int p = rp[grp], q = rq[grp];
+                    const double c = rc[grp], sn = rs[grp], pr = rpr[grp], pi = rpi[grp];
+                    if (sn != 0.0) {
+                        for (int cc = lane; cc < N; cc += 16) {
+                            T x = Aw[p + LD * cc], y = Aw[q + LD * cc];
+                            rotate_pair(x, y, c, sn, pr, -pi);
+                            Aw[p + LD * cc] = x;
+                            Aw[q + LD * cc] = y;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
         }
-    }
-    __syncthreads();
-    // M = L^H (upper triangular): M^H M = G, so the right rotations that orthogonalise M's columns diagonalise G
-    for (int t = tid; t < N * N; t += 512) {
-        const int r = t % N, c = t / N;
-        T v{};
-        if (r < c) {
-            v = scale_t(conj_t(Aw[c + LD * r]), lam[r] > 0 ? rsqrt(lam[r]) : 0.0);
-        } else if (r == c) {
-            reinterpret_cast<double*>(&v)[0] = sqrt(lam[r]);
+        if (tid < N) lam[tid] = reinterpret_cast<const double*>(&Aw[tid + LD * tid])[0];
+        __syncthreads();
+    } else {
+    // Cholesky of the (semi-definite) Gram matrix, lower triangle, right-looking, ONE barrier per step: the
+        // trailing update uses the UNSCALED column j and 1 / pivot, the columns are scaled by 1 / sqrt(pivot) only
+        // when L^H is written out.  A pivot at rounding level of its original diagonal closes that column
+        // (dependent / zero / padding columns).
+        for (int j = 0; j < N; ++j) {
+            __syncthreads();
+            const double d = reinterpret_cast<const double*>(&Aw[j + LD * j])[0];
+            const bool dead = !(d > 1e-14 * d0[j]);
+            const double inv = dead ? 0.0 : 1.0 / d;
+            if (tid == 0) lam[j] = dead ? 0.0 : d;
+            const int rem = N - 1 - j;
+            for (int t = tid; t < rem * rem; t += 512) {
+                const int i = j + 1 + t % rem, k = j + 1 + t / rem;
+                if (k <= i)
+                    Aw[i + LD * k] = sub_t(Aw[i + LD * k], scale_t(fma_t(Aw[i + LD * j], conj_t(Aw[k + LD * j]), T{}), inv));
+            }
         }
-        Vw[r + LD * c] = v;
+        __syncthreads();
+        // M = L^H (upper triangular): M^H M = G, so the right rotations that orthogonalise M's columns diagonalise G
+        for (int t = tid; t < N * N; t += 512) {
+            const int r = t % N, c = t / N;
+            T v{};
+            if (r < c) {
+                v = scale_t(conj_t(Aw[c + LD * r]), lam[r] > 0 ? rsqrt(lam[r]) : 0.0);
+            } else if (r == c) {
+                reinterpret_cast<double*>(&v)[0] = sqrt(lam[r]);
+            }
+            Vw[r + LD * c] = v;
+        }
+        __syncthreads();
+        for (int t = tid; t < N * N; t += 512) {
+            const int r = t % N, c = t / N;
+            Aw[r + LD * c] = Vw[r + LD * c];
+        }
+        __syncthreads();
+        for (int t = tid; t < N * N; t += 512) {
+            const int r = t % N, c = t / N;
+            T v{};
+            if (r == c) reinterpret_cast<double*>(&v)[0] = 1.0;
+            Vw[r + LD * c] = v;
+        }
+        __threadfence_block();
+        __syncthreads();
+        jacobi_sweeps<T, 16, 512>(Aw, LD, N, Vw, LD, N, 1e-15, max_sweeps, &s_rot);
+        __syncthreads();
+        if (tid < N) {
+            double v = 0;
+            for (int r = 0; r < N; ++r) v += abs2_t(Aw[r + LD * tid]);
+            lam[tid] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int t = tid; t < N * N; t += 512) {
-        const int r = t % N, c = t / N;
-        Aw[r + LD * c] = Vw[r + LD * c];
-    }
-    __syncthreads();
-    for (int t = tid; t < N * N; t += 512) {
-        const int r = t % N, c = t / N;
-        T v{};
-        if (r == c) reinterpret_cast<double*>(&v)[0] = 1.0;
-        Vw[r + LD * c] = v;
-    }
-    __threadfence_block();
-    __syncthreads();
-    jacobi_sweeps<T, 16, 512>(Aw, LD, N, Vw, LD, N, 1e-15, max_sweeps, &s_rot);
-    __syncthreads();
     // de Rijk ordering at block level: the rotated columns leave sorted by norm (= eigenvalue of G), the
     // larger half to the block with the smaller tournament label -- without it the sweeps count doubles
-    if (tid < N) {
-        double v = 0;
-        for (int r = 0; r < N; ++r) v += abs2_t(Aw[r + LD * tid]);
-        lam[tid] = v;
-    }
-    __syncthreads();
     if (tid < N) {
         int rank = 0;
         const double mine = lam[tid];
@@ -855,12 +941,15 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
     const size_t lds = (size_t)2 * BJ_W * (BJ_W + 1) * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bj_pair_evd<T>),
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bj_pair_evd<T, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bj_pair_evd<T, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int opH = sizeof(T) == 16 ? 2 : 1;
-    static const int inner_sweeps = getenv("QIL_BJ_INNER") ? atoi(getenv("QIL_BJ_INNER")) : 1;   // tuning aid
+    static const int inner_sweeps = getenv("QIL_BJ_INNER") ? atoi(getenv("QIL_BJ_INNER")) : 1;   // tuning aids
+    static const bool two_sided = !(getenv("QIL_BJ_TWO_SIDED") && atoi(getenv("QIL_BJ_TWO_SIDED")) == 0);
     gemm_batch bg, bu;
     bg.count = np;
     bg.a_bs = bg.b_bs = (long long)BJ_W * ldx;
@@ -875,9 +964,14 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
         for (int r = 0; r < nr && status == QIL_OK; ++r) {
             status = gemm_dispatch<T>(ctx, opH, 0, BJ_W, BJ_W, rows, Xc, ldx, Xc, ldx, static_cast<T*>(gbuf), BJ_W, bg);
             if (status != QIL_OK) break;
-            hipLaunchKernelGGL(bj_pair_evd<T>, dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
-                               static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
-                               static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np);
+            if (two_sided)
+                hipLaunchKernelGGL((bj_pair_evd<T, true>), dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
+                                   static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
+                                   static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np);
+            else
+                hipLaunchKernelGGL((bj_pair_evd<T, false>), dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
+                                   static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
+                                   static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np);
             bu.cmap = static_cast<const int*>(cmapd) + (size_t)r * nb;
             status = gemm_dispatch<T>(ctx, 0, 0, rt, BJ_W, BJ_W, Xc, ldx, static_cast<const T*>(jbuf), BJ_W, Xn, ldx, bu);
             std::swap(Xc, Xn);
