@@ -395,8 +395,9 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
     // crossover between one-workgroup-per-query chains and the all-queries-together GEMM path (tuning aid:
     // QIL_COEFF_GEMM_MINCHI)
     // Measured on a 256 x 256 grid scan (65,536 queries): bond 504 chains 0.40 s vs GEMM 0.09 s; bond 23
-    // chains 4.9 ms vs GEMM 3.2 ms -- many queries favour the GEMM path at any bond dimension.
-    static const long long min_chi = getenv("QIL_COEFF_GEMM_MINCHI") ? atoll(getenv("QIL_COEFF_GEMM_MINCHI")) : 256;
+    // chains 4.9 ms vs GEMM 3.2 ms -- many queries favour the GEMM path at any bond dimension.  Few queries, 40
+    // complex sites: bond 64 chains 0.37 ms vs GEMM 0.55 ms, bond 128 1.07 vs 0.81 ms, bond 512 9.2 vs 2.1 ms.
+    static const long long min_chi = getenv("QIL_COEFF_GEMM_MINCHI") ? atoll(getenv("QIL_COEFF_GEMM_MINCHI")) : 128;
     if (nb >= 4 && (maxchi >= min_chi || (nb >= 1024 && maxchi >= 16))) {
         // Large bonds: all queries advance together, one f64-MFMA GEMM per site.  The site tensor is
         // read ONCE for the whole batch: T (nb x 2 chi_r) = V (nb x chi_l) * A_i (chi_l x 2 chi_r),
