@@ -9,4 +9,9 @@ run QIL_GEMM_CFG=1
 run QIL_APPLY_VARIANT=0
 run QIL_APPLY_VARIANT=2
 run QIL_RT_MIN=97
+run QIL_BJ_TWO_SIDED=0 QIL_BJ_INNER=2
+run QIL_SVD_A_LDS=0 QIL_JACOBI_EARLY=0
+run QIL_SVD_FUSED_GLOBAL=1
+run QIL_GEMM_XCD=0 QIL_GEMM_CFG=4
+run QIL_TSQR_MIN_ROWS=8192 QIL_TSQR_MIN_CHUNK=2048
 run QIL_SYSTEM_HIP=1
