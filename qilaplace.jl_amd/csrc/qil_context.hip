@@ -180,6 +180,19 @@ int qil_ctx_free(qil_context* ctx, void* p) {
     ctx->bytes_in_use -= bytes;
     ctx->free_blocks.emplace(bytes, p);
     ctx->bytes_cached += bytes;
+    // The cache is keyed by exact size: a long run over data-dependent shapes (truncated bonds) would pile up small
+    // blocks of ever new sizes.  Past kMaxCachedBlocks entries the SMALL ones (cheap to allocate again) go back to
+    // the driver; the large recurring ones (apply outputs) stay, they are what the cache is for.
+    constexpr size_t kMaxCachedBlocks = 8192, kSmall = 1u << 20;
+    if (ctx->free_blocks.size() > kMaxCachedBlocks) {
+        (void)hipStreamSynchronize(ctx->stream);
+        auto end = ctx->free_blocks.upper_bound(kSmall);
+        for (auto f = ctx->free_blocks.begin(); f != end; ++f) {
+            (void)hipFree(f->second);
+            ctx->bytes_cached -= f->first;
+        }
+        ctx->free_blocks.erase(ctx->free_blocks.begin(), end);
+    }
     return QIL_OK;
 }
 

@@ -1342,3 +1342,17 @@ def test_randomised_paired_pipeline_against_oracle(qil, seed):
         fixed_cfg[fixed_cfg == 2] = 0
         lazy = qil.apply_coefficient_batch(W, psi, fixed_cfg)
         assert rel(lazy, O.coefficient_batch(oout, fixed_cfg)) < 1e-12
+
+
+def test_pool_cache_stays_bounded_over_varied_shapes(qil):
+    """The exact-size block cache must not grow without bound when every call brings new tensor sizes: past 8192
+    cached blocks the small ones are returned to the driver."""
+    ctx = qil.default_context()
+    rng = np.random.default_rng(3)
+    before = ctx.mem_info()["pool_cached"]             # earlier tests may have left large recurring blocks cached
+    for it in range(4000):
+        m, n = int(rng.integers(2, 400)), int(rng.integers(2, 60))
+        qil.gemm(rng.standard_normal((m, 7)), rng.standard_normal((7, n)))
+    assert ctx.mem_info()["pool_cached"] - before < (256 << 20)
+    ctx.trim()
+    assert ctx.mem_info()["pool_cached"] == 0
