@@ -1004,8 +1004,10 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
 // Thin SVD A = U diag(S) Vh by one-sided Jacobi on the SHORT side.
 //   1. orientation: the work matrix has rows >= cols (A^H if m < n);
 //   2. tall-skinny (rows >= 8 cols): QR first, Jacobi on the cols x cols factor R, U = Q U_R;
-//   3. cols <= 128: the whole iteration is one launch (jacobi_fused); otherwise one launch per
-//      tournament round with one workgroup per column pair (jacobi_round).
+//   3. three regimes by column count: <= 96 columns with (at least) A resident in LDS -- the whole iteration is one
+//      launch of one workgroup (jacobi_fused); >= 512 columns -- QR, then GEMM-shaped block Jacobi sweeps on R^H
+//      (block_jacobi); otherwise one launch per tournament round with one workgroup per column pair (jacobi_round),
+//      which is also the fallback of the block path.
 template <class T>
 int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* U, long long ldu,
              double* S_host, T* Vh, long long ldvh) {
