@@ -352,12 +352,29 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None):
     (zt_transformer.jl:104 -> qil_mpo_compress) run on the device -- on the host that last step alone is the
     largest part of a build (1.4 s of 2.6 s at n = 24)."""
     from .ops import apply, mpo_compress
+    import threading
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
     n = _n_of(n_or_psi)
-    dts = build_dt_mpo_batch(n_or_psi, wrs, cutoff, maxdim, ctx)
     if n < 1:
         raise ValueError(f"build_zt_mpo: n must be >= 1. Found n={n}")
-    Q = PairedSiteMPO(zt_qft_chain_tensors(n, cutoff, maxdim), sites=dts[0].site_ids, ctx=dts[0].ctx)
+    # the host-side QFT half (numpy, GIL released inside LAPACK) is built while the GPU builds the DT halves
+    box = {}
+
+    def _host_half():
+        try:
+            box["Q"] = zt_qft_chain_tensors(n, cutoff, maxdim)
+        except Exception as e:                      # noqa: BLE001  (re-raised on the calling thread)
+            box["err"] = e
+
+    th = threading.Thread(target=_host_half)
+    th.start()
+    try:
+        dts = build_dt_mpo_batch(n_or_psi, wrs, cutoff, maxdim, ctx)
+    finally:
+        th.join()
+    if "err" in box:
+        raise box["err"]
+    Q = PairedSiteMPO(box["Q"], sites=dts[0].site_ids, ctx=dts[0].ctx)
     out = []
     for W_dt in dts:
         W = apply(W_dt, Q)
