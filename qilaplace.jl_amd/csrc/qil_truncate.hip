@@ -203,6 +203,23 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
     QIL_REQUIRE(m >= 1 && n >= 1, QIL_EEMPTY, "In `rsvd`, left or right index set is empty.");
     const size_t e = qil_elem_size(dt);
     const int64_t l = std::min(std::min(k + p, m), n);  // rsvd.jl:72
+    if (l == std::min(m, n)) {
+        // The sketch is as wide as the short side: Q spans the whole range of M and the procedure returns the exact
+        // truncated SVD (up to rounding) after 2 + 2q products and 1 + 2q QRs of matrices no larger than M itself.
+        // Take the SVD directly: Z = M^T = Uz Sz Vz^h  =>  U_M^T = Vz^h,  (S V_M^h)^T = Uz Sz.  Every deep split of
+        // the bisection encoder ends up here (SignalConverters.jl:161: m or n <= k + p).
+        void* Zc = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &Zc));
+        QIL_HIP(hipMemcpyAsync(Zc, Z, (size_t)(m * n) * e, hipMemcpyDeviceToDevice, ctx->stream));
+        int64_t r = 0;
+        void *UzS = nullptr, *Vzh = nullptr;
+        QIL_TRY(svd_trunc_dev(ctx, dt, n, m, Zc, n, cutoff, true, maxdim, mindim, 1, &r, &UzS, &Vzh, S_out));
+        qil_ctx_free(ctx, Zc);
+        *rank = r;
+        *left = Vzh;    // r x m, ld r
+        *right = UzS;   // n x (>= r) columns, ld n
+        return QIL_OK;
+    }
     void *Om = nullptr, *Y = nullptr, *Zq = nullptr, *Bt = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Om));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * l) * e, &Y));
