@@ -77,7 +77,46 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
 // Works on any chain: the physical block is 2 (MPS site A[a,s,b]) or 4 (MPO site W[a,s',s,b]) wide and sits
 // between the two bonds in memory, so "rows (a, phys) | cols b" and "rows a | cols (phys, b)" are the site
 // buffer as it lies in both cases.
-int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cutoff, int64_t maxdim) {
+// Exact gauge sweep by thin QR (no truncation): the first pass of zip_to_compress_mpo (dt_transformer.jl:190, :237
+// use `qr`, only the return pass uses `svd`).  Same site layouts as canonicalize_impl below; a site whose matrix is
+// wider than tall has no thin QR that shrinks nothing, so it takes the SVD route with cutoff 0.
+static int gauge_qr_site_right(qil_chain* psi, int64_t i, int64_t pd) {
+    qil_context* ctx = psi->ctx;
+    const int dt = psi->dtype;
+    const size_t e = qil_elem_size(dt);
+    const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1], cr2 = psi->dims[(size_t)i + 2];
+    void *Rf = nullptr, *next = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cr * cr) * e, &Rf));
+    QIL_TRY(qil_dev_qr_positive(ctx, dt, pd * cl, cr, psi->site[(size_t)i], pd * cl, Rf, cr));   // Q in place
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cr * pd * cr2) * e, &next));
+    QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, cr, pd * cr2, cr, Rf, cr, psi->site[(size_t)i + 1], cr, next, cr));
+    qil_ctx_free(ctx, Rf);
+    QIL_TRY(qil_chain_set_site(psi, i + 1, next, cr, cr2));
+    return QIL_OK;
+}
+
+static int gauge_qr_site_left(qil_chain* psi, int64_t i, int64_t pd) {
+    qil_context* ctx = psi->ctx;
+    const int dt = psi->dtype;
+    const size_t e = qil_elem_size(dt);
+    const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1], cl0 = psi->dims[(size_t)i - 1];
+    // A (cl x pd cr) = L Q with orthonormal rows of Q:  A^H = Qt Rt  =>  Q = Qt^H, L = Rt^H
+    void *Ah = nullptr, *Rt = nullptr, *prev = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(pd * cr * cl) * e, &Ah));
+    QIL_TRY(qil_dev_transpose(ctx, dt, 1, cl, pd * cr, psi->site[(size_t)i], cl, Ah, pd * cr));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl * cl) * e, &Rt));
+    QIL_TRY(qil_dev_qr_positive(ctx, dt, pd * cr, cl, Ah, pd * cr, Rt, cl));
+    QIL_TRY(qil_dev_transpose(ctx, dt, 1, pd * cr, cl, Ah, pd * cr, psi->site[(size_t)i], cl));
+    qil_ctx_free(ctx, Ah);
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl0 * pd * cl) * e, &prev));
+    QIL_TRY(qil_dev_gemm(ctx, dt, 0, 2, pd * cl0, cl, cl, psi->site[(size_t)i - 1], pd * cl0, Rt, cl, prev, pd * cl0));
+    qil_ctx_free(ctx, Rt);
+    QIL_TRY(qil_chain_set_site(psi, i - 1, prev, cl0, cl));
+    return QIL_OK;
+}
+
+int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cutoff, int64_t maxdim,
+                      bool gauge_qr = false) {
     const int64_t pd = psi->phys_rank == 1 ? 2 : 4;
     qil_context* ctx = psi->ctx;
     const int64_t N = psi->n();
@@ -89,6 +128,10 @@ int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cuto
         for (int64_t i = 0; i + 1 < c; ++i) {  // mps.jl:802-817
             const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
             const int64_t cr2 = psi->dims[(size_t)i + 2];
+            if (gauge_qr && pd * cl >= cr) {
+                QIL_TRY(gauge_qr_site_right(psi, i, pd));
+                continue;
+            }
             int64_t r = 0;
             void *U = nullptr, *SV = nullptr;
             // rows (alpha, s) | cols beta : the site buffer as it lies
@@ -107,6 +150,10 @@ int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cuto
         for (int64_t i = N - 1; i >= c; --i) {  // mps.jl:822-837
             const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
             const int64_t cl0 = psi->dims[(size_t)i - 1];
+            if (gauge_qr && pd * cr >= cl) {
+                QIL_TRY(gauge_qr_site_left(psi, i, pd));
+                continue;
+            }
             int64_t r = 0;
             void *US = nullptr, *Vh = nullptr;
             // rows alpha | cols (s, beta)
@@ -649,7 +696,8 @@ extern "C" int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_
     if (maxdim <= 0) maxdim = kNoCap;
     const int gauge = direction == 0 ? QIL_DIR_RIGHT : QIL_DIR_LEFT;
     const int trunc = direction == 0 ? QIL_DIR_LEFT : QIL_DIR_RIGHT;
-    QIL_TRY(canonicalize_impl(W, gauge, 0, 0.0, kNoCap));
+    static const bool qr_gauge = !(getenv("QIL_MPO_GAUGE_QR") && atoi(getenv("QIL_MPO_GAUGE_QR")) == 0);   // tuning aid
+    QIL_TRY(canonicalize_impl(W, gauge, 0, 0.0, kNoCap, qr_gauge));
     QIL_TRY(canonicalize_impl(W, trunc, 0, cutoff, maxdim));
     return QIL_OK;
 }
