@@ -129,6 +129,12 @@ __device__ __forceinline__ double rcp_refined(double x) {
 // sweep on a handful of 1e-15-level rotations and another one on finding nothing to do.  `big` reports whether this
 // pair was above that level.
 constexpr double kQuadraticOff = 1e-9;
+// Rank-deficient operands (every product bond before its truncation) leave columns that are pure rounding residue:
+// |a|^2 below 1e-30 |A|_F^2.  Such a column has no direction to converge to -- each rotation of the genuine columns
+// re-randomises it -- and keeps full sweeps going (builder slices: 14.7 -> 4.5 sweeps when it is left alone).  When the
+// caller truncates with a cutoff these columns are far below it (the threshold also stays 100x under the cutoff), so
+// pairs involving one are skipped; without a cutoff the threshold is 0 and nothing is skipped.
+constexpr double kNegligibleColumn = 1e-30;
 
 template <bool CX>
 __device__ __forceinline__ bool jacobi_rotation(double al, double be, double gr, double gi, double tol,
@@ -169,7 +175,7 @@ __device__ __forceinline__ bool jacobi_rotation(double al, double be, double gr,
 // trip of the rotation is an LDS access instead of an L2 one.
 template <class T, int G, int NT = 1024>
 __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ldv, int n, double tol,
-                                              int max_sweeps, int* s_rot) {
+                                              int max_sweeps, int* s_rot, double negligible = 0.0) {
     // a column pair is owned by a group of G lanes (16 = one DPP row, or the whole wave); NT = workgroup size
     const int tid = threadIdx.x, lane = tid & (G - 1), wave = tid / G;
     constexpr int NW = NT / G;
@@ -206,6 +212,7 @@ __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ld
                 be = group_sum<G>(be);
                 gr = group_sum<G>(gr);
                 if (sizeof(T) == 16) gi = group_sum<G>(gi);
+                if (al < negligible || be < negligible) continue;     // rounding residue: see kNegligibleColumn
                 double c, sn, pr, pi;
                 bool big;
                 if (!jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, tol, c, sn, pr, pi, big)) continue;

@@ -152,8 +152,10 @@ int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t 
                       void* At, int64_t ldt);
 // Thin SVD of A (m x n, lda) on the device: U (m x r0), S (r0, host), Vh (r0 x n), r0 = min(m,n).
 // A is destroyed.  Singular values sorted descending.
+// negligible_rel > 0: columns with |a|^2 < negligible_rel |A|_F^2 are left alone by the rotations (rounding residue
+// of a rank-deficient operand; callers that truncate pass a value far below their cutoff).
 int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* U,
-                int64_t ldu, double* S_host, void* Vh, int64_t ldvh);
+                int64_t ldu, double* S_host, void* Vh, int64_t ldvh, double negligible_rel = 0.0);
 // Thin QR with non-negative real diagonal of R: A (m x n, m >= n) -> Q (m x n) in place; R (n x n) optional.
 int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda,
                         void* R, int64_t ldr);

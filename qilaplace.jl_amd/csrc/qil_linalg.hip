@@ -383,7 +383,8 @@ template <class T>
 __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long lda, long long m,
                                                     T* __restrict__ V, long long ldv, int vrows, int n,
                                                     int npad, int round, double tol,
-                                                    int* __restrict__ rotated) {
+                                                    int* __restrict__ rotated,
+                                                    const double* __restrict__ negligible) {
     __shared__ double red[16];
     const int i = blockIdx.x;
     int p, q;
@@ -410,6 +411,10 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
         dot_parts(x, y, v[2], v[3]);
     }
     block_sum<4>(v, red);
+    if (negligible) {
+        const double ng = *negligible;
+        if (v[0] < ng || v[1] < ng) return;
+    }
     double c, s, pr, pi;
     bool big;
     if (!jacobi_rotation<sizeof(T) == 16>(v[0], v[1], v[2], v[3], tol, c, s, pr, pi, big)) return;
@@ -440,9 +445,10 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
 template <class T, int MODE>
 __global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long long lda, int m,
                                                      T* __restrict__ V, long long ldv, int n, double tol,
-                                                     int max_sweeps, double* __restrict__ norms) {
+                                                     int max_sweeps, double* __restrict__ norms, double negl_rel) {
     extern __shared__ __attribute__((aligned(16))) char jf_smem[];
     __shared__ int s_rot;
+    __shared__ double s_fro[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = 16;
     T* Aw = A;
@@ -466,11 +472,22 @@ __global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long lon
     }
     __threadfence_block();
     __syncthreads();
+    double negligible = 0.0;
+    if (negl_rel > 0.0) {
+        double f = 0;
+        for (int t = tid; t < m * n; t += 1024) f += abs2_t(Aw[(t % m) + (long long)la * (t / m)]);
+        f = wave_sum(f);
+        if (lane == 0) s_fro[wave] = f;
+        __syncthreads();
+        f = 0;
+        for (int w = 0; w < 16; ++w) f += s_fro[w];
+        negligible = negl_rel * f;
+    }
     // DPP lane-group exec masks must be uniform per group: the `continue`s above are per pair = per group
     if (m <= 128)
-        jacobi_sweeps<T, 16>(Aw, la, m, Vw, lv, n, tol, max_sweeps, &s_rot);
+        jacobi_sweeps<T, 16>(Aw, la, m, Vw, lv, n, tol, max_sweeps, &s_rot, negligible);
     else
-        jacobi_sweeps<T, 64>(Aw, la, m, Vw, lv, n, tol, max_sweeps, &s_rot);
+        jacobi_sweeps<T, 64>(Aw, la, m, Vw, lv, n, tol, max_sweeps, &s_rot, negligible);
     for (int j = wave; j < n; j += NW) {
         const T* a = Aw + la * j;
         double v = 0;
@@ -685,7 +702,8 @@ constexpr int BJ_W = 2 * BJ_B;
 template <class T, bool TWO_SIDED>
 __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* __restrict__ Jm, double tol,
                                                     int max_sweeps, int* __restrict__ flag,
-                                                    const int* __restrict__ big_second) {
+                                                    const int* __restrict__ big_second,
+                                                    const double* __restrict__ negligible) {
     constexpr int N = BJ_W, LD = N + 1;
     extern __shared__ __attribute__((aligned(16))) char bj_smem[];
     T* Aw = reinterpret_cast<T*>(bj_smem);
@@ -702,9 +720,10 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
     __syncthreads();
     int any = 0, work = 0;
     float worst = 0.f;
+    const double ng = negligible ? *negligible : 0.0;
     for (int t = tid; t < N * N; t += 512) {
         const int r = t % N, c = t / N;
-        if (r < c) {
+        if (r < c && !(d0[r] < ng || d0[c] < ng)) {
             const double g2 = abs2_t(Aw[r + LD * c]), dd = d0[r] * d0[c];
             if (g2 > tol * tol * dd) any = 1;                 // above the convergence threshold
             if (g2 > 1e-32 * dd) work = 1;                    // worth rotating at all
@@ -758,7 +777,7 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
                     const double gi = sizeof(T) == 16 ? reinterpret_cast<const double*>(&g)[1] : 0.0;
                     double c = 1.0, sn = 0.0, pr = 1.0, pi = 0.0;
                     bool big;
-                    if (!jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, 1e-15, c, sn, pr, pi, big)) {
+                    if (al < ng || be < ng || !jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, 1e-15, c, sn, pr, pi, big)) {
                         c = 1.0;
                         sn = 0.0;
                     }
@@ -891,7 +910,8 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
 // order (padding columns are entirely zero).
 template <class T>
 int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, long long ldw, double tol,
-                 int max_sweeps, void** xbuf, long long* ldx_out, long long* cols_pad_out, bool* converged) {
+                 int max_sweeps, void** xbuf, long long* ldx_out, long long* cols_pad_out, bool* converged,
+                 const double* negligible) {
     *converged = false;
     const long long cpad = (cols + BJ_W - 1) / BJ_W * BJ_W;
     const int nb = (int)(cpad / BJ_B), np = nb / 2;
@@ -967,11 +987,11 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
             if (two_sided)
                 hipLaunchKernelGGL((bj_pair_evd<T, true>), dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
                                    static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
-                                   static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np);
+                                   static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np, negligible);
             else
                 hipLaunchKernelGGL((bj_pair_evd<T, false>), dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
                                    static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
-                                   static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np);
+                                   static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np, negligible);
             bu.cmap = static_cast<const int*>(cmapd) + (size_t)r * nb;
             status = gemm_dispatch<T>(ctx, 0, 0, rt, BJ_W, BJ_W, Xc, ldx, static_cast<const T*>(jbuf), BJ_W, Xn, ldx, bu);
             std::swap(Xc, Xn);
@@ -1008,9 +1028,21 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
 //      launch of one workgroup (jacobi_fused); >= 512 columns -- QR, then GEMM-shaped block Jacobi sweeps on R^H
 //      (block_jacobi); otherwise one launch per tournament round with one workgroup per column pair (jacobi_round),
 //      which is also the fallback of the block path.
+// out[0] = rel * sum_j norms[j]^2  (the threshold below which a column counts as rounding residue)
+__global__ __launch_bounds__(256) void negligible_threshold(const double* __restrict__ norms, int n, double rel,
+                                                            double* __restrict__ out) {
+    __shared__ double red[4];
+    double v = 0;
+    for (int j = threadIdx.x; j < n; j += 256) v = fma(norms[j], norms[j], v);
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = rel * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 template <class T>
 int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* U, long long ldu,
-             double* S_host, T* Vh, long long ldvh) {
+             double* S_host, T* Vh, long long ldvh, double negl_rel) {
     const long long r0 = std::min(m, n);
     if (r0 == 0) return QIL_OK;
     const bool dbg = getenv("QIL_SVD_DEBUG") != nullptr;
@@ -1047,7 +1079,8 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     T* Q = nullptr;
     long long ldq = 0, qrows = 0;
     void *rbuf = nullptr, *rtbuf = nullptr;
-    if ((rows >= 8 * cols && rows >= 512) || rt) {
+    static const long long qr_ratio = getenv("QIL_SVD_QR_RATIO") ? atoll(getenv("QIL_SVD_QR_RATIO")) : 8;
+    if ((rows >= qr_ratio * cols && rows >= 512) || rt) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rbuf));
         QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols));
         Q = Wk;
@@ -1065,6 +1098,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     }
     lap("orientation + QR");
     void *vbuf = nullptr, *flag = nullptr, *nrm = nullptr, *permd = nullptr, *scd = nullptr, *xbuf = nullptr;
+    void* negl = nullptr;         // device scalar: squared norm below which a column is rounding residue (or null)
     if (!blocked) QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &vbuf));
     QIL_TRY(qil_ctx_alloc(ctx, 256, &flag));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)2 * (cols + BJ_W) * sizeof(double), &nrm));
@@ -1089,29 +1123,37 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         if (lds_av <= 150 * 1024) {
             if (!attr_set[1]) {
                 QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_fused<T, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
                 attr_set[1] = true;
             }
             hipLaunchKernelGGL((jacobi_fused<T, 1>), dim3(1), dim3(1024), lds_av, ctx->stream, Wk, ldw, (int)rows, V, cols,
-                               ncol, tol, 40, (double*)nrm);
+                               ncol, tol, 40, (double*)nrm, negl_rel);
         } else if (a_in_lds && rows <= 128 && lds_a <= 150 * 1024) {   // one DPP row per pair only up to 128 rows
             if (!attr_set[2]) {
                 QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_fused<T, 2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
                 attr_set[2] = true;
             }
             hipLaunchKernelGGL((jacobi_fused<T, 2>), dim3(1), dim3(1024), lds_a, ctx->stream, Wk, ldw, (int)rows, V, cols,
-                               ncol, tol, 40, (double*)nrm);
+                               ncol, tol, 40, (double*)nrm, negl_rel);
         } else {
             hipLaunchKernelGGL((jacobi_fused<T, 0>), dim3(1), dim3(1024), 0, ctx->stream, Wk, ldw, (int)rows, V, cols, ncol,
-                               tol, 40, (double*)nrm);
+                               tol, 40, (double*)nrm, negl_rel);
         }
     } else {
         bool bj_done = false;
+        if (negl_rel > 0.0) {
+            QIL_TRY(qil_ctx_alloc(ctx, 256, &negl));
+            hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)cols), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
+                               (double*)nrm);
+            hipLaunchKernelGGL(negligible_threshold, dim3(1), dim3(256), 0, ctx->stream, (const double*)nrm, (int)cols,
+                               negl_rel, (double*)negl);
+        }
         if (blocked) {
             // GEMM-shaped block sweeps; the scalar tournament below only runs if they hit their sweep limit
             long long ldx = 0, cpad = 0;
-            QIL_TRY(block_jacobi<T>(ctx, rows, cols, Wk, ldw, tol, 20, &xbuf, &ldx, &cpad, &bj_done));
+            QIL_TRY(block_jacobi<T>(ctx, rows, cols, Wk, ldw, tol, 20, &xbuf, &ldx, &cpad, &bj_done,
+                                    (const double*)negl));
             Wk = static_cast<T*>(xbuf);
             ldw = ldx;
             V = Wk + rows;
@@ -1127,7 +1169,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
             QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
             for (int round = 0; round < npad - 1; ++round)
                 hipLaunchKernelGGL(jacobi_round<T>, dim3(npad / 2), dim3(256), 0, ctx->stream, Wk, ldw, rows, V,
-                                   ldv, (int)cols, nn, npad, round, tol, (int*)flag);
+                                   ldv, (int)cols, nn, npad, round, tol, (int*)flag, (const double*)negl);
             int hv[2] = {0, 0};
             QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             QIL_HIP(hipStreamSynchronize(ctx->stream));
@@ -1209,6 +1251,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     if (lbuf) qil_ctx_free(ctx, lbuf);
     if (vbuf) qil_ctx_free(ctx, vbuf);
     if (xbuf) qil_ctx_free(ctx, xbuf);
+    if (negl) qil_ctx_free(ctx, negl);
     qil_ctx_free(ctx, flag);
     qil_ctx_free(ctx, nrm);
     qil_ctx_free(ctx, permd);
@@ -1568,9 +1611,12 @@ int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t 
 }
 
 int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* U,
-                int64_t ldu, double* S_host, void* Vh, int64_t ldvh) {
-    if (dtype == QIL_C64) return svd_impl<c64>(ctx, m, n, (c64*)A, lda, (c64*)U, ldu, S_host, (c64*)Vh, ldvh);
-    return svd_impl<double>(ctx, m, n, (double*)A, lda, (double*)U, ldu, S_host, (double*)Vh, ldvh);
+                int64_t ldu, double* S_host, void* Vh, int64_t ldvh, double negligible_rel) {
+    static const bool skip = !(getenv("QIL_SVD_NEGLIGIBLE") && atoi(getenv("QIL_SVD_NEGLIGIBLE")) == 0);   // tuning aid
+    if (!skip) negligible_rel = 0.0;
+    if (dtype == QIL_C64)
+        return svd_impl<c64>(ctx, m, n, (c64*)A, lda, (c64*)U, ldu, S_host, (c64*)Vh, ldvh, negligible_rel);
+    return svd_impl<double>(ctx, m, n, (double*)A, lda, (double*)U, ldu, S_host, (double*)Vh, ldvh, negligible_rel);
 }
 
 int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* R,

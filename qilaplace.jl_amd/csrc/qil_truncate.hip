@@ -54,7 +54,9 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * r0) * e, &U));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r0 * n) * e, &Vh));
     std::vector<double> S((size_t)r0);
-    QIL_TRY(qil_dev_svd(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0));
+    // with a truncating cutoff, columns 100x below it (and never above 1e-30 |A|_F^2) are not worth rotating
+    const double negl_rel = use_cutoff && cutoff > 0 ? std::min(1e-30, 1e-2 * cutoff) : 0.0;
+    QIL_TRY(qil_dev_svd(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0, negl_rel));
     const int64_t r = qil_truncation_rank(S.data(), r0, cutoff, use_cutoff, maxdim, mindim);
     if (absorb == 1) QIL_TRY(qil_dev_scale(ctx, dtype, 1, m, r, U, m, S.data()));
     if (absorb == 2) QIL_TRY(qil_dev_scale(ctx, dtype, 0, r, n, Vh, r0, S.data()));
