@@ -149,12 +149,24 @@ __global__ __launch_bounds__(256) void bgs_fused(double* __restrict__ A, double*
         if (lane == 0) red[wave] = v;
         // first projection's dot products share the barrier with the norm
         for (int pass = 0; pass < 2 && j > 0; ++pass) {
-            for (int i = wave; i < j; i += 4) {
-                const double* qi = Aw + la * i;
-                double g = 0;
-                for (int r = lane; r < m; r += 64) g = fma(qi[r], y[r], g);
-                g = wave_sum(g);
-                if (lane == 0) c[i] = g;
+            if (m <= 256) {
+                // short columns: one 16-lane DPP row per previous column (16 dot products in flight, 4-step reductions)
+                const int l16 = tid & 15;
+                for (int i = tid >> 4; i < j; i += 16) {
+                    const double* qi = Aw + la * i;
+                    double g = 0;
+                    for (int r = l16; r < m; r += 16) g = fma(qi[r], y[r], g);
+                    g = row16_sum(g);
+                    if (l16 == 0) c[i] = g;
+                }
+            } else {
+                for (int i = wave; i < j; i += 4) {
+                    const double* qi = Aw + la * i;
+                    double g = 0;
+                    for (int r = lane; r < m; r += 64) g = fma(qi[r], y[r], g);
+                    g = wave_sum(g);
+                    if (lane == 0) c[i] = g;
+                }
             }
             __syncthreads();
             double w = 0;
