@@ -569,8 +569,11 @@ __global__ void conj_transpose(const T* __restrict__ A, long long lda, long long
 // R diagonal: A = Q R still holds and Q^H Q is the projector on the numerical range.
 // Chunk mode (chunk_rows > 0, first level of the tall-skinny tree below): workgroup c factors rows
 // [c*chunk_rows, ...) on its own and writes its n x n triangle to rows [c*n, (c+1)*n) of a stacked R.
-template <class T>
-__global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long lda, long long mtot, int n,
+// LDS = true: the workgroup's rows x n slice is staged in LDS (odd leading dimension) for the whole factorisation and
+// written back at the end -- every phase of every column is a dependent round trip to wherever the slice lives, and
+// a 512 x 55 sketch out of L2 took 22 us per column (1.2 ms per QR, 3/4 of an n = 24 RSVD encode).
+template <class T, bool LDS>
+__global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long ldg, long long mtot, int n,
                                                  T* __restrict__ R, long long ldr,
                                                  const double* __restrict__ ref_norm, long long chunk_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -580,12 +583,19 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long ld
     int m = (int)mtot;
     if (chunk_rows > 0) {
         const long long r0 = blockIdx.x * chunk_rows;
-        A += r0;
+        Ag += r0;
         m = (int)min(chunk_rows, mtot - r0);
         if (R) R += (long long)blockIdx.x * n;
     }
     constexpr int NW = 16, CH = 16;
     constexpr int NC = sizeof(T) == 16 ? 2 : 1;
+    T* A = Ag;
+    long long lda = ldg;
+    if (LDS) {
+        A = c + (n + (n & 1));
+        lda = m | 1;
+        for (int t = tid; t < m * n; t += 1024) A[(t % m) + lda * (t / m)] = Ag[(t % m) + ldg * (t / m)];
+    }
     if (R)
         for (int t = tid; t < n * n; t += 1024) R[(t % n) + ldr * (t / n)] = T{};
     __syncthreads();
@@ -673,6 +683,32 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ A, long long ld
         __threadfence_block();
         __syncthreads();
     }
+    if (LDS)
+        for (int t = tid; t < m * n; t += 1024) Ag[(t % m) + ldg * (t / m)] = A[(t % m) + lda * (t / m)];
+}
+
+// launches gs_fused with the slice in LDS whenever rows_per_workgroup x n fits
+template <class T>
+int gs_fused_launch(qil_context* ctx, unsigned nwg, T* A, long long lda, long long mtot, int n, T* R, long long ldr,
+                    const double* ref_norm, long long chunk_rows) {
+    const long long rows = chunk_rows > 0 ? std::min(chunk_rows, mtot) : mtot;
+    const size_t lds = ((size_t)(n + (n & 1)) + (size_t)(rows | 1) * n) * sizeof(T);
+    static const bool use_lds = !(getenv("QIL_QR_LDS") && atoi(getenv("QIL_QR_LDS")) == 0);   // tuning aid
+    if (use_lds && lds <= 150 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_fused<T, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL((gs_fused<T, true>), dim3(nwg), dim3(1024), lds, ctx->stream, A, lda, mtot, n, R, ldr, ref_norm,
+                           chunk_rows);
+    } else {
+        hipLaunchKernelGGL((gs_fused<T, false>), dim3(nwg), dim3(1024), (size_t)n * sizeof(T), ctx->stream, A, lda, mtot, n,
+                           R, ldr, ref_norm, chunk_rows);
+    }
+    QIL_HIP(hipGetLastError());
+    return QIL_OK;
 }
 
 template <class T>
@@ -1365,10 +1401,8 @@ int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, 
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nch * b * b) * sizeof(T), &rs));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(b * b) * sizeof(T), &r2));
     T* Rs = static_cast<T*>(rs);
-    hipLaunchKernelGGL(gs_fused<T>, dim3((unsigned)nch), dim3(1024), (size_t)b * sizeof(T), ctx->stream, P, lda, m,
-                       b, Rs, nch * b, ref_norm, chunk);
-    hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)b * sizeof(T), ctx->stream, Rs, nch * b, nch * b,
-                       b, static_cast<T*>(r2), (long long)b, ref_norm, 0LL);
+    QIL_TRY(gs_fused_launch<T>(ctx, (unsigned)nch, P, lda, m, b, Rs, nch * b, ref_norm, chunk));
+    QIL_TRY(gs_fused_launch<T>(ctx, 1u, Rs, nch * b, nch * b, b, static_cast<T*>(r2), (long long)b, ref_norm, 0LL));
     hipLaunchKernelGGL((tsqr_apply_q2<T, 16>), dim3((unsigned)std::min<long long>((chunk + 255) / 256, 64), (unsigned)nch),
                        dim3(256), 0, ctx->stream, P, lda, m, b, (const T*)Rs, nch * b, chunk);
     QIL_HIP(hipGetLastError());
@@ -1388,7 +1422,9 @@ int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, 
 template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
     static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 2048;   // tuning aid
-    if (n <= 16 || m * n <= (1LL << 15)) {
+    // one launch for the whole factorisation: single panels, and anything whose slice fits one CU's LDS
+    const bool fits_lds = ((size_t)(n + (n & 1)) + (size_t)(m | 1) * n) * sizeof(T) <= 150 * 1024;
+    if (n <= 16 || fits_lds) {
         if (m >= TALL && n <= 16) {
             void* nb0 = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nb0));
@@ -1397,10 +1433,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
             qil_ctx_free(ctx, nb0);
             return QIL_OK;
         }
-        hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)n * sizeof(T), ctx->stream, A, lda, m,
-                           (int)n, R, ldr, (const double*)nullptr, 0LL);
-        QIL_HIP(hipGetLastError());
-        return QIL_OK;
+        return gs_fused_launch<T>(ctx, 1u, A, lda, m, (int)n, R, ldr, (const double*)nullptr, 0LL);
     }
     constexpr int PB = 16;
     if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
@@ -1431,8 +1464,8 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
         if (m >= TALL)
             QIL_TRY(tsqr_panel<T>(ctx, m, b, P, lda, R ? Rp : (T*)nullptr, (long long)PB, (const double*)nbuf + j0));
         else
-            hipLaunchKernelGGL(gs_fused<T>, dim3(1), dim3(1024), (size_t)b * sizeof(T), ctx->stream, P, lda, m, b,
-                               R ? Rp : (T*)nullptr, (long long)PB, (const double*)nbuf + j0, 0LL);
+            QIL_TRY(gs_fused_launch<T>(ctx, 1u, P, lda, m, b, R ? Rp : (T*)nullptr, (long long)PB,
+                                       (const double*)nbuf + j0, 0LL));
         if (R)
             QIL_HIP(hipMemcpy2DAsync(R + j0 + ldr * j0, (size_t)ldr * sizeof(T), Rp, (size_t)PB * sizeof(T),
                                      (size_t)b * sizeof(T), (size_t)b, hipMemcpyDeviceToDevice, ctx->stream));
