@@ -591,8 +591,9 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long l
     constexpr int NC = sizeof(T) == 16 ? 2 : 1;
     T* A = Ag;
     long long lda = ldg;
+    T* csum = c + (n + (n & 1));                           // first-pass projections (LDS mode only)
     if (LDS) {
-        A = c + (n + (n & 1));
+        A = csum + (n + (n & 1));
         lda = m | 1;
         for (int t = tid; t < m * n; t += 1024) A[(t % m) + lda * (t / m)] = Ag[(t % m) + ldg * (t / m)];
     }
@@ -616,7 +617,52 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long l
             nrm0 = sqrt(t0);
             __syncthreads();
         }
-        for (int pass = 0; pass < 2 && j > 0; ++pass) {
+        for (int pass = 0; pass < 2 && j > 0 && LDS; ++pass) {
+            // slice in LDS: one previous column per lane group (a 16-lane DPP row for short columns, a wave otherwise),
+            // every dot product a short independent chain; R is written once, after the second pass
+            if (m <= 256) {
+                const int l16 = tid & 15;
+                for (int i = tid >> 4; i < j; i += 64) {
+                    const T* qi = A + lda * i;
+                    double a0 = 0, a1 = 0;
+                    for (int r = l16; r < m; r += 16) dot_parts(qi[r], y[r], a0, a1);
+                    a0 = row16_sum(a0);
+                    if (NC == 2) a1 = row16_sum(a1);
+                    if (l16 == 0) {
+                        T out{};
+                        reinterpret_cast<double*>(&out)[0] = a0;
+                        if (NC == 2) reinterpret_cast<double*>(&out)[1] = a1;
+                        c[i] = out;
+                    }
+                }
+            } else {
+                for (int i = wave; i < j; i += NW) {
+                    const T* qi = A + lda * i;
+                    double a0 = 0, a1 = 0;
+                    for (int r = lane; r < m; r += 64) dot_parts(qi[r], y[r], a0, a1);
+                    a0 = wave_sum(a0);
+                    if (NC == 2) a1 = wave_sum(a1);
+                    if (lane == 0) {
+                        T out{};
+                        reinterpret_cast<double*>(&out)[0] = a0;
+                        if (NC == 2) reinterpret_cast<double*>(&out)[1] = a1;
+                        c[i] = out;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int r = tid; r < m; r += 1024) {
+                T acc = y[r];
+                for (int i = 0; i < j; ++i) acc = sub_t(acc, fma_t(A[r + lda * i], c[i], T{}));
+                y[r] = acc;
+            }
+            for (int i = tid; i < j; i += 1024) {
+                if (pass == 0) csum[i] = c[i];
+                else if (R) R[i + ldr * j] = add_t(csum[i], c[i]);
+            }
+            __syncthreads();
+        }
+        for (int pass = 0; pass < 2 && j > 0 && !LDS; ++pass) {
             for (int i0 = 0; i0 < j; i0 += CH) {
                 const int nc = min(CH, j - i0);
                 double acc[CH][2];
@@ -692,7 +738,7 @@ template <class T>
 int gs_fused_launch(qil_context* ctx, unsigned nwg, T* A, long long lda, long long mtot, int n, T* R, long long ldr,
                     const double* ref_norm, long long chunk_rows) {
     const long long rows = chunk_rows > 0 ? std::min(chunk_rows, mtot) : mtot;
-    const size_t lds = ((size_t)(n + (n & 1)) + (size_t)(rows | 1) * n) * sizeof(T);
+    const size_t lds = ((size_t)2 * (n + (n & 1)) + (size_t)(rows | 1) * n) * sizeof(T);
     static const bool use_lds = !(getenv("QIL_QR_LDS") && atoi(getenv("QIL_QR_LDS")) == 0);   // tuning aid
     if (use_lds && lds <= 150 * 1024) {
         static bool attr = false;
@@ -1423,7 +1469,7 @@ template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
     static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 2048;   // tuning aid
     // one launch for the whole factorisation: single panels, and anything whose slice fits one CU's LDS
-    const bool fits_lds = ((size_t)(n + (n & 1)) + (size_t)(m | 1) * n) * sizeof(T) <= 150 * 1024;
+    const bool fits_lds = ((size_t)2 * (n + (n & 1)) + (size_t)(m | 1) * n) * sizeof(T) <= 150 * 1024;
     if (n <= 16 || fits_lds) {
         if (m >= TALL && n <= 16) {
             void* nb0 = nullptr;
