@@ -652,9 +652,20 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long l
             }
             __syncthreads();
             for (int r = tid; r < m; r += 1024) {
-                T acc = y[r];
-                for (int i = 0; i < j; ++i) acc = sub_t(acc, fma_t(A[r + lda * i], c[i], T{}));
-                y[r] = acc;
+                // four independent chains, loads of a group issued together (a rolled single chain waits out one LDS
+                // round trip per previous column)
+                T s0{}, s1{}, s2{}, s3{};
+                int i = 0;
+                for (; i + 4 <= j; i += 4) {
+                    const T a0 = A[r + lda * i], a1 = A[r + lda * (i + 1)], a2 = A[r + lda * (i + 2)],
+                            a3 = A[r + lda * (i + 3)];
+                    s0 = fma_t(a0, c[i], s0);
+                    s1 = fma_t(a1, c[i + 1], s1);
+                    s2 = fma_t(a2, c[i + 2], s2);
+                    s3 = fma_t(a3, c[i + 3], s3);
+                }
+                for (; i < j; ++i) s0 = fma_t(A[r + lda * i], c[i], s0);
+                y[r] = sub_t(y[r], add_t(add_t(s0, s1), add_t(s2, s3)));
             }
             for (int i = tid; i < j; i += 1024) {
                 if (pass == 0) csum[i] = c[i];
