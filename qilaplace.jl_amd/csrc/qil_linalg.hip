@@ -439,6 +439,143 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
 }
 
 
+// One OUTER round of a block tournament for the mid-size regime (97...511 columns), where one launch per scalar
+// round costs ~3.9 us for ~1 us of work (every column arrives from another XCD's L2).  Blocks of BB columns are paired
+// round-robin; a workgroup stages its 2 BB columns of A and of V in LDS, orthogonalises every CROSS pair of the two
+// blocks (BB inner rounds of BB disjoint pairs, one wave per pair) -- or, in the first outer round of a sweep, every
+// pair among the 2 BB columns, which also covers the pairs inside each block once per sweep -- and writes the columns
+// back.  A sweep is nb - 1 launches instead of n - 1.
+template <class T, int BB>
+__global__ __launch_bounds__(64 * BB) void jacobi_block_round(T* __restrict__ A, long long lda, int m,
+                                                              T* __restrict__ V, long long ldv, int vrows, int n, int nb,
+                                                              int round, int all_pairs, double tol,
+                                                              int* __restrict__ rotated,
+                                                              const double* __restrict__ negligible) {
+    constexpr int W = 2 * BB, NT = 64 * BB;
+    extern __shared__ __attribute__((aligned(16))) char jb_smem[];
+    const int la = m | 1, lv = vrows | 1;
+    T* As = reinterpret_cast<T*>(jb_smem);
+    T* Vs = As + (size_t)la * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int P, Q;
+    {
+        const int i = blockIdx.x;
+        if (i == 0) {
+            P = nb - 1;
+            Q = round;
+        } else {
+            P = (round + i) % (nb - 1);
+            Q = (round + nb - 1 - i) % (nb - 1);
+        }
+        if (P > Q) {
+            const int t = P;
+            P = Q;
+            Q = t;
+        }
+    }
+    auto gcol = [&](int k) { return (k < BB ? P * BB + k : Q * BB + (k - BB)); };
+    if (P * BB >= n) return;                               // both blocks are padding
+    // staging: eight independent loads in flight per thread (a rolled copy loop waits out one L2 / fabric round trip
+    // per element, which costs more than the rotations)
+    auto stage = [&](const T* __restrict__ G, long long ldg, int rws, T* __restrict__ S, int lds_) {
+        const int total = W * rws;
+        for (int base = tid; base < total; base += 8 * NT) {
+            T tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * NT;
+                tmp[u] = T{};
+                if (idx < total) {
+                    const int k = idx / rws, r = idx - k * rws, g = gcol(k);
+                    if (g < n) tmp[u] = G[r + ldg * g];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * NT;
+                if (idx < total) {
+                    const int k = idx / rws, r = idx - k * rws;
+                    S[r + (size_t)lds_ * k] = tmp[u];
+                }
+            }
+        }
+    };
+    stage(A, lda, m, As, la);
+    stage(V, ldv, vrows, Vs, lv);
+    __syncthreads();
+    const double ng = negligible ? *negligible : 0.0;
+    int flags = 0;
+    const int nin = all_pairs ? W - 1 : BB;
+    for (int t = 0; t < nin; ++t) {
+        int p, q;
+        if (all_pairs) {
+            if (wave == 0) {
+                p = W - 1;
+                q = t;
+            } else {
+                p = (t + wave) % (W - 1);
+                q = (t + W - 1 - wave) % (W - 1);
+            }
+            if (p > q) {
+                const int t2 = p;
+                p = q;
+                q = t2;
+            }
+        } else {
+            p = wave;
+            q = BB + (wave + t) % BB;
+        }
+        if (gcol(p) < n && gcol(q) < n) {
+            T* ap = As + (size_t)la * p;
+            T* aq = As + (size_t)la * q;
+            double al = 0, be = 0, gr = 0, gi = 0;
+            for (int r = lane; r < m; r += 64) {
+                const T x = ap[r], y = aq[r];
+                al += abs2_t(x);
+                be += abs2_t(y);
+                dot_parts(x, y, gr, gi);
+            }
+            al = wave_sum(al);
+            be = wave_sum(be);
+            gr = wave_sum(gr);
+            if (sizeof(T) == 16) gi = wave_sum(gi);
+            double c, sn, pr, pi;
+            bool big;
+            if (!(al < ng || be < ng) && jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, tol, c, sn, pr, pi, big)) {
+                flags |= big ? 3 : 1;
+                for (int r = lane; r < m; r += 64) {
+                    T x = ap[r], y = aq[r];
+                    rotate_pair(x, y, c, sn, pr, pi);
+                    ap[r] = x;
+                    aq[r] = y;
+                }
+                T* vp = Vs + (size_t)lv * p;
+                T* vq = Vs + (size_t)lv * q;
+                for (int r = lane; r < vrows; r += 64) {
+                    T x = vp[r], y = vq[r];
+                    rotate_pair(x, y, c, sn, pr, pi);
+                    vp[r] = x;
+                    vq[r] = y;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && flags) {        // plain stores of the same value from every rotating wave
+        rotated[0] = 1;
+        if (flags & 2) rotated[1] = 1;
+    }
+    auto unstage = [&](T* __restrict__ G, long long ldg, int rws, const T* __restrict__ S, int lds_) {
+        const int total = W * rws;
+        for (int idx = tid; idx < total; idx += NT) {
+            const int k = idx / rws, r = idx - k * rws, g = gcol(k);
+            if (g < n) G[r + ldg * g] = S[r + (size_t)lds_ * k];
+        }
+    };
+    unstage(A, lda, m, As, la);
+    unstage(V, ldv, vrows, Vs, lv);
+}
+
 // MODE 1: A and V staged in LDS for the whole iteration; MODE 2: only A in LDS, V in global memory (complex operands of
 // 2 chi x chi sites with chi ~ 64: A fits the CU's LDS, A and V together do not) -- the dot products and the rotation
 // of A, which every round's critical path waits for, still run out of LDS; MODE 0: both in global memory.
@@ -1166,7 +1303,9 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     // (the classical preconditioning of one-sided Jacobi); then R^H = L S V^H gives Wk = (Q V) S L^H.
     static const long long bj_min = getenv("QIL_BJ_MIN") ? atoll(getenv("QIL_BJ_MIN")) : 512;   // tuning aids
     static const bool bj_rt = !(getenv("QIL_BJ_RT") && atoi(getenv("QIL_BJ_RT")) == 0);
-    static const long long rt_min = getenv("QIL_RT_MIN") ? atoll(getenv("QIL_RT_MIN")) : (1LL << 40);
+    // mid-size operands too: neutral on random matrices, but graded / low-rank spectra -- what truncation sees after an
+    // apply -- need 2-4x fewer sweeps (512 x 256 graded: 36 -> 9 ms including the QR)
+    static const long long rt_min = getenv("QIL_RT_MIN") ? atoll(getenv("QIL_RT_MIN")) : 97;
     const bool blocked = cols >= bj_min;
     const bool rt = (blocked && bj_rt) || cols >= rt_min;
     T* Q = nullptr;
@@ -1258,9 +1397,45 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
                                dim3(256), 0, ctx->stream, V, cols, (int)cols);
         }
         const int nn = (int)nj, npad = nn + (nn & 1);
+        // in-LDS block rounds when 2 BB columns of A and V fit one CU's LDS (not after the GEMM-shaped block sweeps:
+        // their fallback keeps the scalar rounds)
+        static const bool block_rounds = !(getenv("QIL_SVD_BLOCK_ROUNDS") && atoi(getenv("QIL_SVD_BLOCK_ROUNDS")) == 0);
+        int bb = 0;
+        if (block_rounds && !blocked && rows <= (1 << 20)) {
+            const size_t per_col = (size_t)((rows | 1) + (cols | 1)) * sizeof(T);
+            if (16 * per_col <= 150 * 1024) bb = 8;
+            else if (8 * per_col <= 150 * 1024) bb = 4;
+        }
+        const int nblk = bb ? (int)(((cols + bb - 1) / bb + 1) / 2 * 2) : 0;
+        if (bb) {
+            static bool attr8 = false, attr4 = false;
+            if (bb == 8 && !attr8) {
+                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round<T, 8>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                attr8 = true;
+            }
+            if (bb == 4 && !attr4) {
+                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round<T, 4>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                attr4 = true;
+            }
+        }
         for (int sweep = 0; sweep < 40 && nn > 1 && !bj_done; ++sweep) {
             QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
-            for (int round = 0; round < npad - 1; ++round)
+            if (bb) {
+                const size_t lds = (size_t)2 * bb * ((rows | 1) + (cols | 1)) * sizeof(T);
+                for (int round = 0; round < nblk - 1; ++round) {
+                    if (bb == 8)
+                        hipLaunchKernelGGL((jacobi_block_round<T, 8>), dim3(nblk / 2), dim3(512), lds, ctx->stream, Wk, ldw,
+                                           (int)rows, V, ldv, (int)cols, nn, nblk, round, round == 0 ? 1 : 0, tol,
+                                           (int*)flag, (const double*)negl);
+                    else
+                        hipLaunchKernelGGL((jacobi_block_round<T, 4>), dim3(nblk / 2), dim3(256), lds, ctx->stream, Wk, ldw,
+                                           (int)rows, V, ldv, (int)cols, nn, nblk, round, round == 0 ? 1 : 0, tol,
+                                           (int*)flag, (const double*)negl);
+                }
+            }
+            for (int round = 0; round < npad - 1 && !bb; ++round)
                 hipLaunchKernelGGL(jacobi_round<T>, dim3(npad / 2), dim3(256), 0, ctx->stream, Wk, ldw, rows, V,
                                    ldv, (int)cols, nn, npad, round, tol, (int*)flag, (const double*)negl);
             int hv[2] = {0, 0};
