@@ -1403,7 +1403,8 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         int bb = 0;
         if (block_rounds && !blocked && rows <= (1 << 20)) {
             const size_t per_col = (size_t)((rows | 1) + (cols | 1)) * sizeof(T);
-            if (16 * per_col <= 150 * 1024) bb = 8;
+            static const int bb_max = getenv("QIL_SVD_BB") ? atoi(getenv("QIL_SVD_BB")) : 8;   // tuning aid
+            if (bb_max >= 8 && 16 * per_col <= 150 * 1024) bb = 8;
             else if (8 * per_col <= 150 * 1024) bb = 4;
         }
         const int nblk = bb ? (int)(((cols + bb - 1) / bb + 1) / 2 * 2) : 0;
