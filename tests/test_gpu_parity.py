@@ -831,6 +831,47 @@ def test_svd_block_jacobi_path(qil, m, n, cplx, kind):
     assert np.abs(Vh[live] @ Vh[live].conj().T - np.eye(live.sum())).max() < 1e-11
 
 
+@pytest.mark.parametrize("m,n,cplx,kind", [(450, 450, 0, "graded"), (640, 330, 1, "graded"), (1000, 500, 0, "rank40"),
+                                            (300, 480, 1, "rank40"), (400, 200, 0, "dup"), (620, 310, 1, "rand"),
+                                            (260, 130, 0, "zero_cols")])
+@pytest.mark.parametrize("cutoff", [None, 1e-20])
+def test_svd_mid_regime_block_rounds(qil, m, n, cplx, kind, cutoff):
+    """97...511 columns on the short side: QR, then in-LDS block rounds on R^H (2 x 8 columns per workgroup, 2 x 4 for
+    the wide complex operands), with and without a truncating cutoff (the cutoff switches on the rule that leaves
+    rounding-residue columns of rank-deficient operands alone).  Contract as for every svd call site (mps.jl:929,946;
+    dt_transformer.jl:213,261): A = U S Vh to rounding, LAPACK's singular values, isometric factors on the live part."""
+    rng = np.random.default_rng(7 * m + n)
+    r0 = min(m, n)
+    A = rng.standard_normal((m, n))
+    if cplx:
+        A = A + 1j * rng.standard_normal((m, n))
+    if kind == "graded":
+        U0, _ = np.linalg.qr(A) if m >= n else np.linalg.qr(A.conj().T)
+        V0, _ = np.linalg.qr(rng.standard_normal((r0, r0)) + (1j * rng.standard_normal((r0, r0)) if cplx else 0))
+        A = (U0[:, :r0] * np.logspace(0, -13, r0)) @ V0.conj().T
+        A = A if m >= n else A.conj().T
+    elif kind == "rank40":
+        A = A[:, :40] @ (rng.standard_normal((40, n)) + (1j * rng.standard_normal((40, n)) if cplx else 0))
+    elif kind == "dup":
+        A[:, 50:100] = A[:, 0:50]
+    elif kind == "zero_cols":
+        A[:, 10:60] = 0.0
+    assert A.shape == (m, n)
+    U, S, Vh = qil.svd_trunc(A, cutoff=cutoff)
+    Sref = np.linalg.svd(A, compute_uv=False)
+    k = len(S)
+    assert np.all(np.diff(S) <= 0) and S.min() >= 0
+    if cutoff is None:
+        assert k == r0
+    else:                                                   # ITensors rule on the reference spectrum (oracle pin)
+        assert abs(k - O.truncation_rank(Sref, cutoff=cutoff)) <= (0 if kind in ("rand", "graded") else 2)
+    assert np.abs((U * S) @ Vh - A).max() < 1e-12 * np.abs(A).max() + 2 * (Sref[k] if k < r0 else 0.0)
+    assert np.abs(S - Sref[:k]).max() < 1e-12 * Sref[0]
+    live = S > 1e-10 * S[0]
+    assert np.abs(U[:, live].conj().T @ U[:, live] - np.eye(live.sum())).max() < 1e-11
+    assert np.abs(Vh[live] @ Vh[live].conj().T - np.eye(live.sum())).max() < 1e-11
+
+
 @pytest.mark.parametrize("wdt,adt", [(np.complex128, np.float64), (np.complex128, np.complex128),
                                      (np.float64, np.float64), (np.float64, np.complex128)])
 def test_lazy_coefficient_gemm_form(qil, wdt, adt):
