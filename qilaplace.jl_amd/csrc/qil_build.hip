@@ -204,7 +204,6 @@ __global__ __launch_bounds__(256) void bgs_fused(double* __restrict__ A, double*
 // One-sided Jacobi on every slice: the columns of A (m x n, n <= m) are rotated in place until mutually
 // orthogonal; norms (n) receives the column norms = singular values.  No V accumulation: the callers
 // recover the other factor with one small GEMM.  A lives in LDS for the whole iteration when it fits.
-__device__ unsigned long long g_dbg_sweeps = 0, g_dbg_calls = 0, g_dbg_rounds = 0;
 template <class T, int G, int NT>
 __device__ __forceinline__ void jacobi_sweeps_nov(T* A, int lda, int m, int n, double tol, int max_sweeps,
                                                   int* s_rot, double negligible) {
@@ -257,10 +256,8 @@ __device__ __forceinline__ void jacobi_sweeps_nov(T* A, int lda, int m, int n, d
         }
         const int any = *s_rot;
         __syncthreads();
-        if (tid == 0) { atomicAdd(&g_dbg_sweeps, 1ull); atomicAdd(&g_dbg_rounds, (unsigned long long)(npad - 1)); }
         if (!(any & 2)) break;
     }
-    if (tid == 0) atomicAdd(&g_dbg_calls, 1ull);
 }
 
 template <bool LDS, int NT>
@@ -812,12 +809,5 @@ extern "C" int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, c
     }
     QIL_HIP(hipStreamSynchronize(ctx->stream));
     for (auto& s : M) bfree(ctx, s);
-    if (getenv("QIL_BUILD_DEBUG")) {
-        unsigned long long a = 0, b = 0, c = 0;
-        hipMemcpyFromSymbol(&a, HIP_SYMBOL(g_dbg_sweeps), 8);
-        hipMemcpyFromSymbol(&b, HIP_SYMBOL(g_dbg_calls), 8);
-        hipMemcpyFromSymbol(&c, HIP_SYMBOL(g_dbg_rounds), 8);
-        fprintf(stderr, "[qil build] jacobi slices %llu sweeps %llu rounds %llu\n", b, a, c);
-    }
     return QIL_OK;
 }
