@@ -1668,18 +1668,19 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
         }
         return gs_fused_launch<T>(ctx, 1u, A, lda, m, (int)n, R, ldr, (const double*)nullptr, 0LL);
     }
-    constexpr int PB = 16;
+    // panel width: 32 columns while a rows x 32 panel still fits one CU's LDS (half the launches), else 16
+    static const int pb_max = getenv("QIL_QR_PANEL") ? atoi(getenv("QIL_QR_PANEL")) : 32;   // tuning aid
+    const bool wide = pb_max >= 32 && m < TALL && ((size_t)64 + (size_t)(m | 1) * 32) * sizeof(T) <= 150 * 1024;
+    const int PB = wide ? 32 : 16;
     if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
-    void *cbuf = nullptr, *dbuf = nullptr, *rpan = nullptr, *nbuf = nullptr;
+    void *cbuf = nullptr, *dbuf = nullptr, *nbuf = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nbuf));
     // original column norms, measured before any projection (reference for the dependence test)
     QIL_TRY(col_norms_any<T>(ctx, A, lda, m, n, (double*)nbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * PB) * sizeof(T), &cbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * PB) * sizeof(T), &dbuf));
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(PB * PB) * sizeof(T), &rpan));
     T* C = static_cast<T*>(cbuf);
     T* D = static_cast<T*>(dbuf);
-    T* Rp = static_cast<T*>(rpan);
     const int opH = sizeof(T) == 16 ? 2 : 1;
     for (long long j0 = 0; j0 < n; j0 += PB) {
         const int b = (int)std::min<long long>(PB, n - j0);
@@ -1693,20 +1694,16 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
                 hipLaunchKernelGGL(add_block<T>, dim3(8), dim3(256), 0, ctx->stream, R + ldr * j0, ldr, (const T*)C,
                                    n, (int)j0, b);
         }
-        // intra-panel CGS2 (one launch); its b x b triangular factor goes to R[j0:, j0:]
+        // intra-panel CGS2 (one launch); its b x b triangular factor goes straight to R[j0:, j0:]
+        T* Rjj = R ? R + j0 + ldr * j0 : (T*)nullptr;
         if (m >= TALL)
-            QIL_TRY(tsqr_panel<T>(ctx, m, b, P, lda, R ? Rp : (T*)nullptr, (long long)PB, (const double*)nbuf + j0));
+            QIL_TRY(tsqr_panel<T>(ctx, m, b, P, lda, Rjj, ldr, (const double*)nbuf + j0));
         else
-            QIL_TRY(gs_fused_launch<T>(ctx, 1u, P, lda, m, b, R ? Rp : (T*)nullptr, (long long)PB,
-                                       (const double*)nbuf + j0, 0LL));
-        if (R)
-            QIL_HIP(hipMemcpy2DAsync(R + j0 + ldr * j0, (size_t)ldr * sizeof(T), Rp, (size_t)PB * sizeof(T),
-                                     (size_t)b * sizeof(T), (size_t)b, hipMemcpyDeviceToDevice, ctx->stream));
+            QIL_TRY(gs_fused_launch<T>(ctx, 1u, P, lda, m, b, Rjj, ldr, (const double*)nbuf + j0, 0LL));
     }
     QIL_HIP(hipGetLastError());
     qil_ctx_free(ctx, cbuf);
     qil_ctx_free(ctx, dbuf);
-    qil_ctx_free(ctx, rpan);
     qil_ctx_free(ctx, nbuf);
     return QIL_OK;
 }
