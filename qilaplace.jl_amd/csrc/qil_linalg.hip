@@ -1251,13 +1251,6 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
     return status;
 }
 
-// Thin SVD A = U diag(S) Vh by one-sided Jacobi on the SHORT side.
-//   1. orientation: the work matrix has rows >= cols (A^H if m < n);
-//   2. tall-skinny (rows >= 8 cols): QR first, Jacobi on the cols x cols factor R, U = Q U_R;
-//   3. three regimes by column count: <= 96 columns with (at least) A resident in LDS -- the whole iteration is one
-//      launch of one workgroup (jacobi_fused); >= 512 columns -- QR, then GEMM-shaped block Jacobi sweeps on R^H
-//      (block_jacobi); otherwise one launch per tournament round with one workgroup per column pair (jacobi_round),
-//      which is also the fallback of the block path.
 // out[0] = rel * sum_j norms[j]^2  (the threshold below which a column counts as rounding residue)
 __global__ __launch_bounds__(256) void negligible_threshold(const double* __restrict__ norms, int n, double rel,
                                                             double* __restrict__ out) {
@@ -1270,6 +1263,13 @@ __global__ __launch_bounds__(256) void negligible_threshold(const double* __rest
     if (threadIdx.x == 0) out[0] = rel * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// Thin SVD A = U diag(S) Vh by one-sided Jacobi on the SHORT side.
+//   1. orientation: the work matrix has rows >= cols (A^H if m < n);
+//   2. tall-skinny (rows >= 8 cols): QR first, Jacobi on the cols x cols factor R, U = Q U_R;
+//   3. three regimes by column count: <= 96 columns with (at least) A resident in LDS -- the whole iteration is one
+//      launch of one workgroup (jacobi_fused); >= 640 columns -- QR, then GEMM-shaped block Jacobi sweeps on R^H
+//      (block_jacobi); in between QR, then in-LDS block rounds on R^H (jacobi_block_round); one launch per scalar
+//      tournament round (jacobi_round) remains for operands too tall for LDS and as the fallback of the block path.
 template <class T>
 int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* U, long long ldu,
              double* S_host, T* Vh, long long ldvh, double negl_rel) {
@@ -1301,7 +1301,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     // tall-skinny: Wk = Q R, rotate R instead.  Large column counts (block path): always, and rotate R^H --
     // the rows of a triangular factor are far closer to orthogonal than its columns, which saves sweeps
     // (the classical preconditioning of one-sided Jacobi); then R^H = L S V^H gives Wk = (Q V) S L^H.
-    static const long long bj_min = getenv("QIL_BJ_MIN") ? atoll(getenv("QIL_BJ_MIN")) : 512;   // tuning aids
+    static const long long bj_min = getenv("QIL_BJ_MIN") ? atoll(getenv("QIL_BJ_MIN")) : 640;   // tuning aids (crossover with the in-LDS block rounds: 600-700 columns)
     static const bool bj_rt = !(getenv("QIL_BJ_RT") && atoi(getenv("QIL_BJ_RT")) == 0);
     // mid-size operands too: neutral on random matrices, but graded / low-rank spectra -- what truncation sees after an
     // apply -- need 2-4x fewer sweeps (512 x 256 graded: 36 -> 9 ms including the QR)
