@@ -439,6 +439,87 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
 }
 
 
+// One column pair of an in-LDS block round, handled by one wave.  KM > 0: at most KM elements per lane (m, vrows <= 64 KM);
+// all loads of a phase are issued together and the pair is rotated from the registers it was read into for the dot
+// products -- with one wave per pair and eight waves per CU the phases are latency chains, and a rolled loop pays one
+// LDS round trip per element (1.6 us per inner round).  KM = 0: generic loops.
+template <class T, int KM>
+__device__ __forceinline__ int block_pair_rotate(T* __restrict__ ap, T* __restrict__ aq, int m, T* __restrict__ vp,
+                                                 T* __restrict__ vq, int vrows, int lane, double tol, double ng) {
+    double al = 0, be = 0, gr = 0, gi = 0;
+    constexpr int KA = KM > 0 ? KM : 1;
+    T xs[KA], ys[KA];
+    if (KM > 0) {
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            const int r = lane + 64 * k;
+            xs[k] = r < m ? ap[r] : T{};
+            ys[k] = r < m ? aq[r] : T{};
+        }
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            al += abs2_t(xs[k]);
+            be += abs2_t(ys[k]);
+            dot_parts(xs[k], ys[k], gr, gi);
+        }
+    } else {
+        for (int r = lane; r < m; r += 64) {
+            const T x = ap[r], y = aq[r];
+            al += abs2_t(x);
+            be += abs2_t(y);
+            dot_parts(x, y, gr, gi);
+        }
+    }
+    al = wave_sum(al);
+    be = wave_sum(be);
+    gr = wave_sum(gr);
+    if (sizeof(T) == 16) gi = wave_sum(gi);
+    double c, sn, pr, pi;
+    bool big;
+    if (al < ng || be < ng || !jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, tol, c, sn, pr, pi, big)) return 0;
+    if (KM > 0) {
+        T us[KA], ws[KA];
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {       // V loads go out before the A rotation's arithmetic
+            const int r = lane + 64 * k;
+            us[k] = r < vrows ? vp[r] : T{};
+            ws[k] = r < vrows ? vq[r] : T{};
+        }
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            const int r = lane + 64 * k;
+            rotate_pair(xs[k], ys[k], c, sn, pr, pi);
+            if (r < m) {
+                ap[r] = xs[k];
+                aq[r] = ys[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            const int r = lane + 64 * k;
+            rotate_pair(us[k], ws[k], c, sn, pr, pi);
+            if (r < vrows) {
+                vp[r] = us[k];
+                vq[r] = ws[k];
+            }
+        }
+    } else {
+        for (int r = lane; r < m; r += 64) {
+            T x = ap[r], y = aq[r];
+            rotate_pair(x, y, c, sn, pr, pi);
+            ap[r] = x;
+            aq[r] = y;
+        }
+        for (int r = lane; r < vrows; r += 64) {
+            T x = vp[r], y = vq[r];
+            rotate_pair(x, y, c, sn, pr, pi);
+            vp[r] = x;
+            vq[r] = y;
+        }
+    }
+    return big ? 3 : 1;
+}
+
 // One OUTER round of a block tournament for the mid-size regime (97...511 columns), where one launch per scalar
 // round costs ~3.9 us for ~1 us of work (every column arrives from another XCD's L2).  Blocks of BB columns are paired
 // round-robin; a workgroup stages its 2 BB columns of A and of V in LDS, orthogonalises every CROSS pair of the two
@@ -528,36 +609,12 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round(T* __restrict__ A,
         if (gcol(p) < n && gcol(q) < n) {
             T* ap = As + (size_t)la * p;
             T* aq = As + (size_t)la * q;
-            double al = 0, be = 0, gr = 0, gi = 0;
-            for (int r = lane; r < m; r += 64) {
-                const T x = ap[r], y = aq[r];
-                al += abs2_t(x);
-                be += abs2_t(y);
-                dot_parts(x, y, gr, gi);
-            }
-            al = wave_sum(al);
-            be = wave_sum(be);
-            gr = wave_sum(gr);
-            if (sizeof(T) == 16) gi = wave_sum(gi);
-            double c, sn, pr, pi;
-            bool big;
-            if (!(al < ng || be < ng) && jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, tol, c, sn, pr, pi, big)) {
-                flags |= big ? 3 : 1;
-                for (int r = lane; r < m; r += 64) {
-                    T x = ap[r], y = aq[r];
-                    rotate_pair(x, y, c, sn, pr, pi);
-                    ap[r] = x;
-                    aq[r] = y;
-                }
-                T* vp = Vs + (size_t)lv * p;
-                T* vq = Vs + (size_t)lv * q;
-                for (int r = lane; r < vrows; r += 64) {
-                    T x = vp[r], y = vq[r];
-                    rotate_pair(x, y, c, sn, pr, pi);
-                    vp[r] = x;
-                    vq[r] = y;
-                }
-            }
+            T* vp = Vs + (size_t)lv * p;
+            T* vq = Vs + (size_t)lv * q;
+            const int mx = max(m, vrows);
+            if (mx <= 256) flags |= block_pair_rotate<T, 4>(ap, aq, m, vp, vq, vrows, lane, tol, ng);
+            else if (mx <= 512) flags |= block_pair_rotate<T, 8>(ap, aq, m, vp, vq, vrows, lane, tol, ng);
+            else flags |= block_pair_rotate<T, 0>(ap, aq, m, vp, vq, vrows, lane, tol, ng);
         }
         __syncthreads();
     }
