@@ -831,6 +831,24 @@ def test_svd_block_jacobi_path(qil, m, n, cplx, kind):
     assert np.abs(Vh[live] @ Vh[live].conj().T - np.eye(live.sum())).max() < 1e-11
 
 
+@pytest.mark.parametrize("m,n,cplx", [(900, 700, 0), (700, 680, 1)])
+def test_svd_block_jacobi_path_with_cutoff_on_low_rank(qil, m, n, cplx):
+    """>= 640 columns, rank-deficient operand, truncating cutoff: the pair solver leaves rounding-residue columns
+    alone (their Gram diagonals are below 1e-30 |A|_F^2); kept rank, singular values and factors as LAPACK's."""
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, 60)) @ rng.standard_normal((60, n))
+    if cplx:
+        A = A + 1j * (rng.standard_normal((m, 60)) @ rng.standard_normal((60, n)))
+    U, S, Vh = qil.svd_trunc(A, cutoff=1e-22)
+    Sref = np.linalg.svd(A, compute_uv=False)
+    k = O.truncation_rank(Sref, cutoff=1e-22)
+    assert len(S) == k == (120 if cplx else 60)
+    assert np.abs(S - Sref[:k]).max() < 1e-12 * Sref[0]
+    assert np.abs((U * S) @ Vh - A).max() < 1e-11 * np.abs(A).max()
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() < 1e-11
+    assert np.abs(Vh @ Vh.conj().T - np.eye(k)).max() < 1e-11
+
+
 @pytest.mark.parametrize("m,n,cplx,kind", [(450, 450, 0, "graded"), (640, 330, 1, "graded"), (1000, 500, 0, "rank40"),
                                             (300, 480, 1, "rank40"), (400, 200, 0, "dup"), (620, 310, 1, "rand"),
                                             (260, 130, 0, "zero_cols")])
