@@ -1714,8 +1714,13 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 2048;   // tuning aid
     // one launch for the whole factorisation: single panels, and anything whose slice fits one CU's LDS
     const bool fits_lds = ((size_t)2 * (n + (n & 1)) + (size_t)(m | 1) * n) * sizeof(T) <= 150 * 1024;
+    // panels go through the row-chunk tree from TALL rows on, and already from 1024 rows when a rows x 16 panel does
+    // not fit LDS (complex panels above ~580 rows): its 512-row chunks do, and a single workgroup factoring such a
+    // panel out of L2 takes ~290 us instead of three short launches
+    const bool panel16_fits = ((size_t)32 + (size_t)(m | 1) * 16) * sizeof(T) <= 150 * 1024;
+    const bool tree = m >= TALL || (!panel16_fits && m >= 1024);
     if (n <= 16 || fits_lds) {
-        if (m >= TALL && n <= 16) {
+        if (tree && n <= 16) {
             void* nb0 = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nb0));
             QIL_TRY(col_norms_any<T>(ctx, A, lda, m, n, (double*)nb0));
@@ -1727,7 +1732,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     }
     // panel width: 32 columns while a rows x 32 panel still fits one CU's LDS (half the launches), else 16
     static const int pb_max = getenv("QIL_QR_PANEL") ? atoi(getenv("QIL_QR_PANEL")) : 32;   // tuning aid
-    const bool wide = pb_max >= 32 && m < TALL && ((size_t)64 + (size_t)(m | 1) * 32) * sizeof(T) <= 150 * 1024;
+    const bool wide = pb_max >= 32 && !tree && ((size_t)64 + (size_t)(m | 1) * 32) * sizeof(T) <= 150 * 1024;
     const int PB = wide ? 32 : 16;
     if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
     void *cbuf = nullptr, *dbuf = nullptr, *nbuf = nullptr;
@@ -1753,7 +1758,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
         }
         // intra-panel CGS2 (one launch); its b x b triangular factor goes straight to R[j0:, j0:]
         T* Rjj = R ? R + j0 + ldr * j0 : (T*)nullptr;
-        if (m >= TALL)
+        if (tree)
             QIL_TRY(tsqr_panel<T>(ctx, m, b, P, lda, Rjj, ldr, (const double*)nbuf + j0));
         else
             QIL_TRY(gs_fused_launch<T>(ctx, 1u, P, lda, m, b, Rjj, ldr, (const double*)nbuf + j0, 0LL));
