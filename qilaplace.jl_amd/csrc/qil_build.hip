@@ -171,8 +171,19 @@ __global__ __launch_bounds__(256) void bgs_fused(double* __restrict__ A, double*
             __syncthreads();
             double w = 0;
             for (int r = tid; r < m; r += 256) {
-                double acc = y[r];
-                for (int i = 0; i < j; ++i) acc = fma(-Aw[r + la * i], c[i], acc);
+                // four independent chains, the loads of a group issued together
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                int i = 0;
+                for (; i + 4 <= j; i += 4) {
+                    const double a0 = Aw[r + la * i], a1 = Aw[r + la * (i + 1)], a2 = Aw[r + la * (i + 2)],
+                                 a3 = Aw[r + la * (i + 3)];
+                    s0 = fma(a0, c[i], s0);
+                    s1 = fma(a1, c[i + 1], s1);
+                    s2 = fma(a2, c[i + 2], s2);
+                    s3 = fma(a3, c[i + 3], s3);
+                }
+                for (; i < j; ++i) s0 = fma(Aw[r + la * i], c[i], s0);
+                const double acc = y[r] - ((s0 + s1) + (s2 + s3));
                 y[r] = acc;
                 w = fma(acc, acc, w);
             }
@@ -371,6 +382,28 @@ struct Builder {
     int B;
     double cutoff;
     long long maxdim;
+    // pinned host staging for the per-step singular values (down) and truncation decisions (up): two slots used
+    // alternately, so a step's upload needs no second stream synchronisation (the NEXT step's download sync covers it)
+    // and the device never idles while the host enqueues the following step
+    char* pin = nullptr;
+    size_t pin_slot_bytes = 0;
+    int pin_next = 0;
+
+    ~Builder() {
+        if (pin) (void)hipHostFree(pin);
+    }
+    int pinned_slot(size_t bytes, char** out) {
+        if (bytes > pin_slot_bytes) {
+            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            if (pin) QIL_HIP(hipHostFree(pin));
+            pin = nullptr;
+            pin_slot_bytes = std::max<size_t>(2 * bytes, 1 << 16);
+            QIL_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin), 2 * pin_slot_bytes, hipHostMallocDefault));
+        }
+        *out = pin + (size_t)pin_next * pin_slot_bytes;
+        pin_next ^= 1;
+        return QIL_OK;
+    }
 
     int upload(const std::vector<double>& h, void** dev) {
         QIL_TRY(qil_ctx_alloc(ctx, h.size() * sizeof(double), dev));
@@ -559,31 +592,37 @@ struct Builder {
                                    (double*)nrm, rows, cols, 1e-15);
             }
             QIL_HIP(hipGetLastError());
-            std::vector<double> sig((size_t)B * cols);
-            QIL_HIP(hipMemcpyAsync(sig.data(), nrm, sig.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            // slot layout: sig (B cols doubles, down) | inv (B cols doubles) | perm (B cols ints) | rank (B ints)  (up)
+            const size_t nsig = (size_t)B * cols;
+            const size_t up_bytes = nsig * sizeof(double) + nsig * sizeof(int) + (size_t)B * sizeof(int);
+            char* slot = nullptr;
+            QIL_TRY(pinned_slot(nsig * sizeof(double) + up_bytes, &slot));
+            double* sig = reinterpret_cast<double*>(slot);
+            double* inv = sig + nsig;
+            int* perm = reinterpret_cast<int*>(inv + nsig);
+            int* rank = perm + nsig;
+            QIL_HIP(hipMemcpyAsync(sig, nrm, nsig * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             QIL_HIP(hipStreamSynchronize(ctx->stream));
-            std::vector<int> perm((size_t)B * cols), rank((size_t)B);
-            std::vector<double> inv((size_t)B * cols), S((size_t)cols);
+            std::vector<double> S((size_t)cols);
             int rmax = 1;
             for (int b = 0; b < B; ++b) {
-                int* p = perm.data() + (size_t)b * cols;
-                const double* sg = sig.data() + (size_t)b * cols;
+                int* p = perm + (size_t)b * cols;
+                const double* sg = sig + (size_t)b * cols;
                 std::iota(p, p + cols, 0);
                 std::stable_sort(p, p + cols, [&](int x, int y) { return sg[x] > sg[y]; });
                 for (int j = 0; j < cols; ++j) {
                     S[(size_t)j] = sg[p[j]];
                     inv[(size_t)b * cols + j] = S[(size_t)j] > 0 ? 1.0 / S[(size_t)j] : 0.0;
                 }
-                rank[(size_t)b] = (int)qil_truncation_rank(S.data(), cols, cutoff, true, maxdim, 1);
-                rmax = std::max(rmax, rank[(size_t)b]);
+                rank[b] = (int)qil_truncation_rank(S.data(), cols, cutoff, true, maxdim, 1);
+                rmax = std::max(rmax, rank[b]);
             }
-            void *dperm = nullptr, *drank = nullptr, *dinv = nullptr;
-            QIL_TRY(qil_ctx_alloc(ctx, perm.size() * sizeof(int), &dperm));
-            QIL_TRY(qil_ctx_alloc(ctx, rank.size() * sizeof(int), &drank));
-            QIL_TRY(qil_ctx_alloc(ctx, inv.size() * sizeof(double), &dinv));
-            QIL_HIP(hipMemcpyAsync(dperm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            QIL_HIP(hipMemcpyAsync(drank, rank.data(), rank.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            QIL_HIP(hipMemcpyAsync(dinv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            void* dpack = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, up_bytes, &dpack));
+            QIL_HIP(hipMemcpyAsync(dpack, inv, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+            const double* dinv = static_cast<const double*>(dpack);
+            const int* dperm = reinterpret_cast<const int*>(dinv + nsig);
+            const int* drank = dperm + nsig;
             void *Vh = nullptr, *US = nullptr, *nl = nullptr;   // Vh: rmax x w ; US: d x rmax
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * rmax * w * sizeof(double), &Vh));
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * d * rmax * sizeof(double), &US));
@@ -608,12 +647,9 @@ struct Builder {
             hipLaunchKernelGGL(bgemm, dim3(nblk((long long)lf.dl * 4 * rmax), B), dim3(256), 0, ctx->stream,
                                (const double*)lf.p, (const double*)US, (double*)nl, lf.dl * 4, rmax, d);
             QIL_HIP(hipGetLastError());
-            QIL_HIP(hipStreamSynchronize(ctx->stream));   // perm/rank/inv are host vectors
             qil_ctx_free(ctx, Wk);
             qil_ctx_free(ctx, nrm);
-            qil_ctx_free(ctx, dperm);
-            qil_ctx_free(ctx, drank);
-            qil_ctx_free(ctx, dinv);
+            qil_ctx_free(ctx, dpack);
             qil_ctx_free(ctx, US);
             bfree(ctx, lf);
             bfree(ctx, rt);
