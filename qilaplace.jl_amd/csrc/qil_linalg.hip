@@ -1528,8 +1528,25 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         S_host[j] = s;
         inv[(size_t)j] = s > 0 ? 1.0 / s : 0.0;
     }
-    QIL_HIP(hipMemcpyAsync(permd, perm.data(), (size_t)cols * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipMemcpyAsync(scd, inv.data(), (size_t)cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // permutation + reciprocal singular values go up through the context's event-guarded pinned ring when they fit a
+    // slot: no stream synchronisation at the end of the call, so the device does not idle while the host enqueues
+    // whatever follows (chains of small SVDs are bound by exactly that)
+    const size_t up_bytes = (size_t)cols * (sizeof(double) + sizeof(int));
+    int ring_slot = -1;
+    if (up_bytes <= qil_context::kDescSlotBytes) {
+        void *hp = nullptr, *dp = nullptr;
+        QIL_TRY(qil_ctx_desc_acquire(ctx, up_bytes, &hp, &dp, &ring_slot));
+        memcpy(hp, inv.data(), (size_t)cols * sizeof(double));
+        memcpy(static_cast<char*>(hp) + (size_t)cols * sizeof(double), perm.data(), (size_t)cols * sizeof(int));
+        QIL_HIP(hipMemcpyAsync(dp, hp, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+        qil_ctx_free(ctx, scd);
+        qil_ctx_free(ctx, permd);
+        scd = dp;
+        permd = static_cast<char*>(dp) + (size_t)cols * sizeof(double);
+    } else {
+        QIL_HIP(hipMemcpyAsync(permd, perm.data(), (size_t)cols * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        QIL_HIP(hipMemcpyAsync(scd, inv.data(), (size_t)cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
     // Work problem: Wk[:, perm] = Fw diag(S), Fw orthonormal columns, and Fv = V[:, perm]:  Wk = Fw S Fv^H.
     //   plain:        oriented A = Wk            = (Fw)   S (Fv)^H
     //   QR:           oriented A = Q Wk          = (Q Fw) S (Fv)^H
@@ -1568,8 +1585,13 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
             gather(ls, Vh, ldvh, 1);
     }
     QIL_HIP(hipGetLastError());
-    // perm/inv are host vectors read by async copies: finish before they go out of scope
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    if (ring_slot >= 0) {
+        QIL_TRY(qil_ctx_desc_commit(ctx, ring_slot));
+        scd = permd = nullptr;                                   // ring memory, not pool blocks
+    } else {
+        // perm/inv are host vectors read by async copies: finish before they go out of scope
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+    }
     lap("factors out");
     if (tbuf) qil_ctx_free(ctx, tbuf);
     if (rbuf) qil_ctx_free(ctx, rbuf);
@@ -1580,8 +1602,8 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     if (negl) qil_ctx_free(ctx, negl);
     qil_ctx_free(ctx, flag);
     qil_ctx_free(ctx, nrm);
-    qil_ctx_free(ctx, permd);
-    qil_ctx_free(ctx, scd);
+    if (permd) qil_ctx_free(ctx, permd);
+    if (scd) qil_ctx_free(ctx, scd);
     return QIL_OK;
 }
 
@@ -1982,9 +2004,17 @@ int qil_dev_scale(qil_context* ctx, int dtype, int side, int64_t m, int64_t n, v
     if (m == 0 || n == 0) return QIL_OK;
     const int64_t len = side ? n : m;
     void* sd = nullptr;
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)len * sizeof(double), &sd));
-    QIL_HIP(hipMemcpyAsync(sd, s_host, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));  // s_host is caller memory
+    int ring_slot = -1;
+    if ((size_t)len * sizeof(double) <= qil_context::kDescSlotBytes) {   // pinned ring: no synchronisation
+        void* hp = nullptr;
+        QIL_TRY(qil_ctx_desc_acquire(ctx, (size_t)len * sizeof(double), &hp, &sd, &ring_slot));
+        memcpy(hp, s_host, (size_t)len * sizeof(double));
+        QIL_HIP(hipMemcpyAsync(sd, hp, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)len * sizeof(double), &sd));
+        QIL_HIP(hipMemcpyAsync(sd, s_host, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        QIL_HIP(hipStreamSynchronize(ctx->stream));  // s_host is caller memory
+    }
     const unsigned g = (unsigned)std::min<long long>((m * n + 255) / 256, 65536);
     if (dtype == QIL_C64)
         hipLaunchKernelGGL(scale_kernel<c64>, dim3(g), dim3(256), 0, ctx->stream, (c64*)A, lda, m, n,
@@ -1993,6 +2023,7 @@ int qil_dev_scale(qil_context* ctx, int dtype, int side, int64_t m, int64_t n, v
         hipLaunchKernelGGL(scale_kernel<double>, dim3(g), dim3(256), 0, ctx->stream, (double*)A, lda, m, n,
                            (const double*)sd, side);
     QIL_HIP(hipGetLastError());
+    if (ring_slot >= 0) return qil_ctx_desc_commit(ctx, ring_slot);
     qil_ctx_free(ctx, sd);
     return QIL_OK;
 }
