@@ -1511,9 +1511,20 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     }
     lap("scalar sweeps");
     std::vector<double> sig((size_t)nj * 2, 1.0);
-    QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)nj * (blocked && nj > 96 ? 2 : 1) * sizeof(double),
-                           hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        const size_t down = (size_t)nj * (blocked && nj > 96 ? 2 : 1) * sizeof(double);
+        if (down <= qil_context::kDescSlotBytes) {      // through pinned memory: a pageable target is staged twice
+            void *hp = nullptr, *dp = nullptr;
+            int slot = -1;
+            QIL_TRY(qil_ctx_desc_acquire(ctx, down, &hp, &dp, &slot));
+            QIL_HIP(hipMemcpyAsync(hp, nrm, down, hipMemcpyDeviceToHost, ctx->stream));
+            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            memcpy(sig.data(), hp, down);
+        } else {
+            QIL_HIP(hipMemcpyAsync(sig.data(), nrm, down, hipMemcpyDeviceToHost, ctx->stream));
+            QIL_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
     std::vector<int> perm((size_t)nj);
     std::iota(perm.begin(), perm.end(), 0);
     const double* vn = sig.data() + nj;
