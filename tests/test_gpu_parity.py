@@ -954,6 +954,17 @@ def test_build_zt_mpo_batch_device_assisted(qil, pins):
     for W, wr in zip(Ws, wrs):
         host = qil.build_zt_mpo(psi, wr, cutoff=1e-14, maxdim=1000)
         assert rel(qil.coefficient_batch(W * psi, bits), qil.coefficient_batch(host * psi, bits)) < 1e-9
+    # several values: the per-value product + compression chains run on worker contexts (threads); same MPOs
+    # as the single-context path, bit for bit, in the caller's context
+    wrs = [0.25, 1.0, 2 * np.pi, 9.0, 15.5]
+    seq = qil.build_zt_mpo_batch(psi, wrs, workers=1)
+    par = qil.build_zt_mpo_batch(psi, wrs, workers=3)
+    assert len(par) == len(seq) == len(wrs)
+    for Ws_, Wp in zip(seq, par):
+        assert Wp.ctx is psi.ctx and Wp.bond_dims == Ws_.bond_dims
+        for ts, tp in zip(Ws_.to_host(), Wp.to_host()):
+            assert np.array_equal(ts, tp)
+        assert rel(qil.coefficient_batch(Wp * psi, bits), qil.coefficient_batch(Ws_ * psi, bits)) == 0.0
 
 
 def test_failed_calls_leave_no_device_memory_behind(qil):
