@@ -330,6 +330,7 @@ def build_dt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None):
 
 
 _ZT_Q_CACHE = {}
+_WORKER_CTX = {}          # (device, worker index) -> Context of build_zt_mpo_batch's worker threads
 
 
 @_single_thread_blas
@@ -395,9 +396,11 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, worke
     errors = []
 
     def _worker(k):
-        wctx = None
         try:
-            wctx = Context(home.device)
+            # worker contexts persist across calls: a fresh pool pays one hipMalloc per distinct block size
+            wctx = _WORKER_CTX.get((home.device, k))
+            if wctx is None:
+                wctx = _WORKER_CTX[(home.device, k)] = Context(home.device)
             Qk = PairedSiteMPO(box["Q"], sites=ids, ctx=wctx)
             for j in range(k, len(dts), nw):
                 Wd = PairedSiteMPO(dt_host[j], sites=ids, ctx=wctx)
@@ -407,9 +410,6 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, worke
             del Qk
         except Exception as e:                      # noqa: BLE001  (re-raised on the calling thread)
             errors.append(e)
-        finally:
-            if wctx is not None:
-                wctx.close()
 
     threads = [threading.Thread(target=_worker, args=(k,)) for k in range(nw)]
     for t in threads:

@@ -9,7 +9,7 @@ nv = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 wrs = np.linspace(0.25, 16.0, nv)
 ctx = qil.default_context()
 qil.build_zt_mpo_batch(n, wrs[:2])
-for workers in (1, 4, 8, 16):
+for workers in (1, 8, 8, 16, 16):
     t0 = time.perf_counter(); Ws = qil.build_zt_mpo_batch(n, wrs, workers=workers); ctx.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"case": "zt_sigma_batch_build", "n": n, "values": nv, "workers": workers, "seconds": round(dt, 4),
