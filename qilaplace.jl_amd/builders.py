@@ -277,19 +277,31 @@ def build_qft_mpo(n_or_psi, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
     return SingleSiteMPO(qft_mpo_tensors(n, cutoff, maxdim), sites=sites, ctx=ctx)
 
 
-def build_dt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None):
-    """build_dt_mpo(n, wr, ...; cutoff, maxdim) / build_dt_mpo(psi::ZTMPS, wr; ...)."""
+_DEVICE_BUILD_MIN_N = 8      # from here on the device-assisted builders are faster than the host chain
+
+
+def build_dt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None, device=None):
+    """build_dt_mpo(n, wr, ...; cutoff, maxdim) / build_dt_mpo(psi::ZTMPS, wr; ...).  `device`: build on the GPU
+    (qil_build_dt_mpo_batch with one value; default from n = 8) or with the host chain (`dt_mpo_tensors`)."""
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
+    n = _n_of(n_or_psi)
+    if device or (device is None and n >= _DEVICE_BUILD_MIN_N):
+        return build_dt_mpo_batch(n_or_psi, [wr], cutoff, maxdim, ctx)[0]
     sites = psi.site_ids if psi is not None else None
-    return PairedSiteMPO(dt_mpo_tensors(_n_of(n_or_psi), wr, cutoff, maxdim), sites=sites,
+    return PairedSiteMPO(dt_mpo_tensors(n, wr, cutoff, maxdim), sites=sites,
                          ctx=ctx or (psi.ctx if psi is not None else None))
 
 
-def build_zt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None):
-    """build_zt_mpo(n, wr, ...; cutoff, maxdim) / build_zt_mpo(psi::ZTMPS, wr; ...)."""
+def build_zt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None, device=None):
+    """build_zt_mpo(n, wr, ...; cutoff, maxdim) / build_zt_mpo(psi::ZTMPS, wr; ...).  `device`: DT half, MPO x MPO
+    product and final compression on the GPU (build_zt_mpo_batch with one value; default from n = 8: 0.55 s instead
+    of 2.6 s at n = 24) or everything with the host chain (`zt_mpo_tensors`)."""
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
+    n = _n_of(n_or_psi)
+    if device or (device is None and n >= _DEVICE_BUILD_MIN_N):
+        return build_zt_mpo_batch(n_or_psi, [wr], cutoff, maxdim, ctx)[0]
     sites = psi.site_ids if psi is not None else None
-    return PairedSiteMPO(zt_mpo_tensors(_n_of(n_or_psi), wr, cutoff, maxdim), sites=sites,
+    return PairedSiteMPO(zt_mpo_tensors(n, wr, cutoff, maxdim), sites=sites,
                          ctx=ctx or (psi.ctx if psi is not None else None))
 
 

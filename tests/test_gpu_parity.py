@@ -952,7 +952,7 @@ def test_build_zt_mpo_batch_device_assisted(qil, pins):
     bits = rng.integers(0, 2, size=(128, 2 * n))
     Ws = qil.build_zt_mpo_batch(psi, wrs, cutoff=1e-14, maxdim=1000)
     for W, wr in zip(Ws, wrs):
-        host = qil.build_zt_mpo(psi, wr, cutoff=1e-14, maxdim=1000)
+        host = qil.build_zt_mpo(psi, wr, cutoff=1e-14, maxdim=1000, device=False)
         assert rel(qil.coefficient_batch(W * psi, bits), qil.coefficient_batch(host * psi, bits)) < 1e-9
     # several values: the per-value product + compression chains run on worker contexts (threads); same MPOs
     # as the single-context path, bit for bit, in the caller's context
