@@ -831,6 +831,55 @@ def test_svd_block_jacobi_path(qil, m, n, cplx, kind):
     assert np.abs(Vh[live] @ Vh[live].conj().T - np.eye(live.sum())).max() < 1e-11
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_svd_shape_fuzz_across_regime_boundaries(qil, seed):
+    """Random shapes around every dispatch boundary of the Jacobi SVD (96/97 and 639/640 columns on the short side,
+    rows = 8 x columns, the LDS-fit limits of the fused and block-round kernels), both dtypes, random / graded /
+    low-rank / zero operands, with and without a truncating cutoff: LAPACK's singular values, A = U S Vh, isometric
+    factors on the live part, the ITensors rank on the reference spectrum."""
+    rng = np.random.default_rng(1000 + seed)
+    shorts = [1, 2, 15, 16, 17, 63, 64, 65, 95, 96, 97, 98, 128, 135, 136, 144, 255, 256, 257, 300, 511, 512, 639, 640, 641]
+    for _ in range(8):
+        k = int(rng.choice(shorts))
+        ratio = float(rng.choice([1.0, 1.0, 1.3, 2.0, 4.0, 7.9, 8.0, 8.5, 20.0]))
+        long_ = max(k, min(int(round(k * ratio)) + int(rng.integers(0, 3)), 6000))
+        m, n = (long_, k) if rng.random() < 0.5 else (k, long_)
+        cplx = bool(rng.integers(0, 2))
+        kind = str(rng.choice(["rand", "rand", "graded", "lowrank", "zero"]))
+        cutoff = None if rng.random() < 0.5 else float(10.0 ** -int(rng.integers(10, 25)))
+        A = rng.standard_normal((m, n)) + (1j * rng.standard_normal((m, n)) if cplx else 0)
+        r0 = min(m, n)
+        if kind == "graded" and r0 > 1:
+            U0, _ = np.linalg.qr(A if m >= n else A.conj().T)
+            V0, _ = np.linalg.qr(rng.standard_normal((r0, r0)) + (1j * rng.standard_normal((r0, r0)) if cplx else 0))
+            B = (U0[:, :r0] * np.logspace(0, -14, r0)) @ V0.conj().T
+            A = B if m >= n else B.conj().T
+        elif kind == "lowrank":
+            r = max(1, r0 // 5)
+            A = A[:, :r] @ (rng.standard_normal((r, n)) + (1j * rng.standard_normal((r, n)) if cplx else 0))
+        elif kind == "zero":
+            A = np.zeros_like(A)
+        tag = (seed, m, n, cplx, kind, cutoff)
+        U, S, Vh = qil.svd_trunc(A, cutoff=cutoff)
+        Sref = np.linalg.svd(A, compute_uv=False)
+        kk = len(S)
+        scale = max(Sref[0], 1e-300)
+        assert np.all(np.diff(S) <= 0) and (S >= 0).all(), tag
+        if kind == "zero":
+            assert kk >= 1 and not S.any(), tag                # an all-zero spectrum keeps mindim = 1 (or everything)
+        elif cutoff is None:
+            assert kk == r0, tag
+        else:
+            assert abs(kk - O.truncation_rank(Sref, cutoff=cutoff)) <= (1 if kind == "rand" else 3), tag
+        assert np.abs(S - Sref[:kk]).max() <= 2e-12 * scale, tag
+        tail = Sref[kk] if kk < r0 else 0.0
+        assert np.abs((U * S) @ Vh - A).max() <= 2e-12 * scale + 2 * tail, tag
+        live = S > 1e-9 * scale
+        if live.any():
+            assert np.abs(U[:, live].conj().T @ U[:, live] - np.eye(live.sum())).max() < 1e-10, tag
+            assert np.abs(Vh[live] @ Vh[live].conj().T - np.eye(live.sum())).max() < 1e-10, tag
+
+
 @pytest.mark.parametrize("m,n,cplx", [(900, 700, 0), (700, 680, 1)])
 def test_svd_block_jacobi_path_with_cutoff_on_low_rank(qil, m, n, cplx):
     """>= 640 columns, rank-deficient operand, truncating cutoff: the pair solver leaves rounding-residue columns
