@@ -1320,6 +1320,25 @@ __global__ __launch_bounds__(256) void negligible_threshold(const double* __rest
     if (threadIdx.x == 0) out[0] = rel * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// out[0] = max over i != j of |G[i, j]| (as the bit pattern of a non-negative double: atomicMax on the integer view)
+template <class T>
+__global__ __launch_bounds__(256) void offdiag_max(const T* __restrict__ G, long long ldg, long long n,
+                                                   unsigned long long* __restrict__ out) {
+    double v = 0;
+    for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n * n; t += (long long)gridDim.x * 256) {
+        const long long i = t % n, j = t / n;
+        if (i != j) v = fmax(v, sqrt(abs2_t(G[i + ldg * j])));
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
+}
+
 // Thin SVD A = U diag(S) Vh by one-sided Jacobi on the SHORT side.
 //   1. orientation: the work matrix has rows >= cols (A^H if m < n);
 //   2. tall-skinny (rows >= 8 cols): QR first, Jacobi on the cols x cols factor R, U = Q U_R;
@@ -1372,6 +1391,39 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     if ((rows >= qr_ratio * cols && rows >= 512) || rt) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rbuf));
         QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols));
+        // CGS2 keeps Q orthonormal only while the operand is numerically of full rank ("twice is enough" needs
+        // kappa * eps < 1).  Operands that are not -- product bonds before their truncation, spectra graded down to
+        // 1e-14 -- leave late columns whose residual is rounding noise with O(1) overlaps, and the singular values of R
+        // are then not those of the operand.  Q^H Q is measured (one small GEMM), and if it is not the identity to
+        // 1e-10, Q is factored once more: Q = Q2 R2 is a well-conditioned problem (columns lying in the span of earlier
+        // ones come out as zero columns), and R <- R2 R.
+        static const bool reorth = !(getenv("QIL_SVD_REORTH") && atoi(getenv("QIL_SVD_REORTH")) == 0);   // tuning aid
+        if (reorth && cols >= 2) {
+            void *gbuf = nullptr, *mx = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &gbuf));
+            QIL_TRY(qil_ctx_alloc(ctx, 256, &mx));
+            for (int pass = 0; pass < 3; ++pass) {
+                QIL_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned long long), ctx->stream));
+                QIL_TRY(gemm_dispatch<T>(ctx, sizeof(T) == 16 ? 2 : 1, 0, cols, cols, rows, Wk, ldw, Wk, ldw,
+                                         static_cast<T*>(gbuf), cols));
+                hipLaunchKernelGGL(offdiag_max<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 1024)),
+                                   dim3(256), 0, ctx->stream, (const T*)gbuf, cols, cols, (unsigned long long*)mx);
+                double worst = 0;
+                QIL_HIP(hipMemcpyAsync(&worst, mx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                QIL_HIP(hipStreamSynchronize(ctx->stream));
+                if (dbg) fprintf(stderr, "[svd] QR first: max |Q^H Q - I| off-diagonal %.3g\n", worst);
+                if (!(worst > 1e-11) || pass == 2) break;
+                void* rnew = nullptr;
+                QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rnew));
+                QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(gbuf), cols));           // Q <- Q2, gbuf = R2
+                QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, cols, cols, cols, static_cast<const T*>(gbuf), cols,
+                                         static_cast<const T*>(rbuf), cols, static_cast<T*>(rnew), cols));
+                qil_ctx_free(ctx, rbuf);
+                rbuf = rnew;
+            }
+            qil_ctx_free(ctx, gbuf);
+            qil_ctx_free(ctx, mx);
+        }
         Q = Wk;
         ldq = ldw;
         qrows = rows;
