@@ -157,8 +157,10 @@ int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t 
 int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* U,
                 int64_t ldu, double* S_host, void* Vh, int64_t ldvh, double negligible_rel = 0.0);
 // Thin QR with non-negative real diagonal of R: A (m x n, m >= n) -> Q (m x n) in place; R (n x n) optional.
+// orthonormal = true: Q^H Q is measured afterwards and Q re-factored while it is not the identity (numerically
+// rank-deficient operands; one small GEMM and one stream synchronisation when nothing needs doing).
 int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda,
-                        void* R, int64_t ldr);
+                        void* R, int64_t ldr, bool orthonormal = false);
 // ITensors truncation rule (host): number of singular values kept.
 int64_t qil_truncation_rank(const double* S, int64_t n, double cutoff, bool use_cutoff, int64_t maxdim,
                             int64_t mindim);

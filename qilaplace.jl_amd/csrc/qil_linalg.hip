@@ -1339,6 +1339,45 @@ __global__ __launch_bounds__(256) void offdiag_max(const T* __restrict__ G, long
     if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
 }
 
+// CGS2 keeps Q orthonormal only while the operand is numerically of full rank ("twice is enough" needs
+// kappa * eps < 1).  Operands that are not -- product bonds before their truncation, sketches wider than the rank,
+// spectra graded down to 1e-14 -- leave late columns whose residual is rounding noise with O(1) overlaps, and the
+// singular values of R are then not those of the operand.  Q^H Q is measured (one small GEMM + a max-reduction), and
+// while it is not the identity to 1e-11, Q is factored once more: Q = Q2 R2 is a well-conditioned problem (columns
+// lying in the span of earlier ones come out as zero columns), and R <- R2 R.  At most two extra factorisations.
+template <class T>
+int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long long ldq, T* R, long long ldr, bool dbg) {
+    static const bool reorth = !(getenv("QIL_SVD_REORTH") && atoi(getenv("QIL_SVD_REORTH")) == 0);   // tuning aid
+    if (!reorth || n < 2) return QIL_OK;
+    void *gbuf = nullptr, *mx = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * sizeof(T), &gbuf));
+    QIL_TRY(qil_ctx_alloc(ctx, 256, &mx));
+    for (int pass = 0; pass < 3; ++pass) {
+        QIL_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned long long), ctx->stream));
+        QIL_TRY(gemm_dispatch<T>(ctx, sizeof(T) == 16 ? 2 : 1, 0, n, n, m, Q, ldq, Q, ldq, static_cast<T*>(gbuf), n));
+        hipLaunchKernelGGL(offdiag_max<T>, dim3((unsigned)std::min<long long>((n * n + 255) / 256, 1024)), dim3(256), 0,
+                           ctx->stream, (const T*)gbuf, n, n, (unsigned long long*)mx);
+        double worst = 0;
+        QIL_HIP(hipMemcpyAsync(&worst, mx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        if (dbg) fprintf(stderr, "[qr] max |Q^H Q - I| off-diagonal %.3g\n", worst);
+        if (!(worst > 1e-11) || pass == 2) break;
+        QIL_TRY(qr_impl<T>(ctx, m, n, Q, ldq, static_cast<T*>(gbuf), n));                  // Q <- Q2, gbuf = R2
+        if (R) {
+            void* rnew = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * sizeof(T), &rnew));
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, n, n, n, static_cast<const T*>(gbuf), n, (const T*)R, ldr,
+                                     static_cast<T*>(rnew), n));
+            QIL_HIP(hipMemcpy2DAsync(R, (size_t)ldr * sizeof(T), rnew, (size_t)n * sizeof(T), (size_t)n * sizeof(T),
+                                     (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+            qil_ctx_free(ctx, rnew);
+        }
+    }
+    qil_ctx_free(ctx, gbuf);
+    qil_ctx_free(ctx, mx);
+    return QIL_OK;
+}
+
 // Thin SVD A = U diag(S) Vh by one-sided Jacobi on the SHORT side.
 //   1. orientation: the work matrix has rows >= cols (A^H if m < n);
 //   2. tall-skinny (rows >= 8 cols): QR first, Jacobi on the cols x cols factor R, U = Q U_R;
@@ -1391,39 +1430,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     if ((rows >= qr_ratio * cols && rows >= 512) || rt) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rbuf));
         QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols));
-        // CGS2 keeps Q orthonormal only while the operand is numerically of full rank ("twice is enough" needs
-        // kappa * eps < 1).  Operands that are not -- product bonds before their truncation, spectra graded down to
-        // 1e-14 -- leave late columns whose residual is rounding noise with O(1) overlaps, and the singular values of R
-        // are then not those of the operand.  Q^H Q is measured (one small GEMM), and if it is not the identity to
-        // 1e-10, Q is factored once more: Q = Q2 R2 is a well-conditioned problem (columns lying in the span of earlier
-        // ones come out as zero columns), and R <- R2 R.
-        static const bool reorth = !(getenv("QIL_SVD_REORTH") && atoi(getenv("QIL_SVD_REORTH")) == 0);   // tuning aid
-        if (reorth && cols >= 2) {
-            void *gbuf = nullptr, *mx = nullptr;
-            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &gbuf));
-            QIL_TRY(qil_ctx_alloc(ctx, 256, &mx));
-            for (int pass = 0; pass < 3; ++pass) {
-                QIL_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned long long), ctx->stream));
-                QIL_TRY(gemm_dispatch<T>(ctx, sizeof(T) == 16 ? 2 : 1, 0, cols, cols, rows, Wk, ldw, Wk, ldw,
-                                         static_cast<T*>(gbuf), cols));
-                hipLaunchKernelGGL(offdiag_max<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 1024)),
-                                   dim3(256), 0, ctx->stream, (const T*)gbuf, cols, cols, (unsigned long long*)mx);
-                double worst = 0;
-                QIL_HIP(hipMemcpyAsync(&worst, mx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-                QIL_HIP(hipStreamSynchronize(ctx->stream));
-                if (dbg) fprintf(stderr, "[svd] QR first: max |Q^H Q - I| off-diagonal %.3g\n", worst);
-                if (!(worst > 1e-11) || pass == 2) break;
-                void* rnew = nullptr;
-                QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rnew));
-                QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(gbuf), cols));           // Q <- Q2, gbuf = R2
-                QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, cols, cols, cols, static_cast<const T*>(gbuf), cols,
-                                         static_cast<const T*>(rbuf), cols, static_cast<T*>(rnew), cols));
-                qil_ctx_free(ctx, rbuf);
-                rbuf = rnew;
-            }
-            qil_ctx_free(ctx, gbuf);
-            qil_ctx_free(ctx, mx);
-        }
+        QIL_TRY(qr_reorthogonalise<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols, dbg));
         Q = Wk;
         ldq = ldw;
         qrows = rows;
@@ -1938,7 +1945,7 @@ extern "C" int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * e, &dR));
     QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, ctx->stream));
     QIL_HIP(hipStreamSynchronize(ctx->stream));
-    QIL_TRY(qil_dev_qr_positive(ctx, dtype, m, n, dA, m, dR, n));
+    QIL_TRY(qil_dev_qr_positive(ctx, dtype, m, n, dA, m, dR, n, true));
     QIL_HIP(hipMemcpyAsync(Q, dA, (size_t)(m * n) * e, hipMemcpyDeviceToHost, ctx->stream));
     QIL_HIP(hipMemcpyAsync(R, dR, (size_t)(n * n) * e, hipMemcpyDeviceToHost, ctx->stream));
     QIL_HIP(hipStreamSynchronize(ctx->stream));
@@ -2030,10 +2037,14 @@ int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int6
 }
 
 int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* R,
-                        int64_t ldr) {
+                        int64_t ldr, bool orthonormal) {
     QIL_REQUIRE(m >= n, QIL_EINVAL_ARG, "qr: needs m >= n (got %lld x %lld)", (long long)m, (long long)n);
-    if (dtype == QIL_C64) return qr_impl<c64>(ctx, m, n, (c64*)A, lda, (c64*)R, ldr);
-    return qr_impl<double>(ctx, m, n, (double*)A, lda, (double*)R, ldr);
+    if (dtype == QIL_C64) {
+        QIL_TRY(qr_impl<c64>(ctx, m, n, (c64*)A, lda, (c64*)R, ldr));
+        return orthonormal ? qr_reorthogonalise<c64>(ctx, m, n, (c64*)A, lda, (c64*)R, ldr, false) : QIL_OK;
+    }
+    QIL_TRY(qr_impl<double>(ctx, m, n, (double*)A, lda, (double*)R, ldr));
+    return orthonormal ? qr_reorthogonalise<double>(ctx, m, n, (double*)A, lda, (double*)R, ldr, false) : QIL_OK;
 }
 
 int64_t qil_truncation_rank(const double* S, int64_t n, double cutoff, bool use_cutoff, int64_t maxdim,

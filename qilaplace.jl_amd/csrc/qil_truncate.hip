@@ -89,7 +89,7 @@ static int gauge_qr_site_right(qil_chain* psi, int64_t i, int64_t pd) {
     const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1], cr2 = psi->dims[(size_t)i + 2];
     void *Rf = nullptr, *next = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cr * cr) * e, &Rf));
-    QIL_TRY(qil_dev_qr_positive(ctx, dt, pd * cl, cr, psi->site[(size_t)i], pd * cl, Rf, cr));   // Q in place
+    QIL_TRY(qil_dev_qr_positive(ctx, dt, pd * cl, cr, psi->site[(size_t)i], pd * cl, Rf, cr, true));   // Q in place
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cr * pd * cr2) * e, &next));
     QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, cr, pd * cr2, cr, Rf, cr, psi->site[(size_t)i + 1], cr, next, cr));
     qil_ctx_free(ctx, Rf);
@@ -107,7 +107,7 @@ static int gauge_qr_site_left(qil_chain* psi, int64_t i, int64_t pd) {
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(pd * cr * cl) * e, &Ah));
     QIL_TRY(qil_dev_transpose(ctx, dt, 1, cl, pd * cr, psi->site[(size_t)i], cl, Ah, pd * cr));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl * cl) * e, &Rt));
-    QIL_TRY(qil_dev_qr_positive(ctx, dt, pd * cr, cl, Ah, pd * cr, Rt, cl));
+    QIL_TRY(qil_dev_qr_positive(ctx, dt, pd * cr, cl, Ah, pd * cr, Rt, cl, true));
     QIL_TRY(qil_dev_transpose(ctx, dt, 1, pd * cr, cl, Ah, pd * cr, psi->site[(size_t)i], cl));
     qil_ctx_free(ctx, Ah);
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl0 * pd * cl) * e, &prev));
@@ -274,13 +274,15 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * l) * e, &Y));
     QIL_TRY(qil_dev_fill_normal(ctx, dt, Om, n * l, seed, 1.0));                        // rsvd.jl:74-76
     QIL_TRY(qil_dev_gemm(ctx, dt, 1, 0, m, l, n, Z, n, Om, n, Y, m));                   // Y = M Omega (:79)
-    QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0));                      // Q (:83)
+    // the basis that B = Q^H M and U = Q Uhat are built from (the last QR) must be orthonormal even when the sketch is
+    // wider than the rank of M; the power iteration's intermediate bases only stabilise it
+    QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0, q == 0));              // Q (:83)
     if (q > 0) QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Zq));
     for (int it = 0; it < q; ++it) {                                                    // :86-95
         QIL_TRY(qil_dev_gemm(ctx, dt, 3, 0, n, l, m, Z, n, Y, m, Zq, n));               // M^H Q = conj(Z) Q
         QIL_TRY(qil_dev_qr_positive(ctx, dt, n, l, Zq, n, nullptr, 0));
         QIL_TRY(qil_dev_gemm(ctx, dt, 1, 0, m, l, n, Z, n, Zq, n, Y, m));               // M Qz
-        QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0));
+        QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0, it + 1 == q));
     }
     qil_ctx_free(ctx, Om);
     if (Zq) qil_ctx_free(ctx, Zq);

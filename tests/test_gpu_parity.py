@@ -831,6 +831,30 @@ def test_svd_block_jacobi_path(qil, m, n, cplx, kind):
     assert np.abs(Vh[live] @ Vh[live].conj().T - np.eye(live.sum())).max() < 1e-11
 
 
+@pytest.mark.parametrize("m,n,cplx,kind", [(6000, 300, 0, "lowrank"), (2561, 640, 1, "graded"), (2056, 257, 0, "graded"),
+                                            (900, 300, 1, "lowrank")])
+def test_qr_stays_orthonormal_on_numerically_rank_deficient_tall_operands(qil, m, n, cplx, kind):
+    """qr(...; positive=true) (rsvd.jl:83) on operands with kappa * eps >= 1: CGS2 alone leaves noise columns with
+    O(1) overlaps; the factor is measured and re-factored until Q^H Q is a projector to rounding."""
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n)) + (1j * rng.standard_normal((m, n)) if cplx else 0)
+    if kind == "graded":
+        U0, _ = np.linalg.qr(A)
+        V0, _ = np.linalg.qr(rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0))
+        A = (U0 * np.logspace(0, -14, n)) @ V0.conj().T
+    else:
+        A = A[:, :n // 5] @ (rng.standard_normal((n // 5, n)) + (1j * rng.standard_normal((n // 5, n)) if cplx else 0))
+    Q, R = qil.qr_positive(A)
+    assert np.abs(Q @ R - A).max() < 1e-11 * np.abs(A).max()
+    G = Q.conj().T @ Q
+    d = np.real(np.diag(G))
+    assert np.all((np.abs(d - 1) < 1e-12) | (d == 0))
+    assert np.abs(G - np.diag(d)).max() < 1e-11
+    assert np.abs(np.tril(R, -1)).max() < 1e-13 * np.abs(R).max() and np.real(np.diag(R)).min() >= 0
+    if kind == "lowrank":
+        assert (d > 0.5).sum() <= n // 5 + 2
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_svd_shape_fuzz_across_regime_boundaries(qil, seed):
     """Random shapes around every dispatch boundary of the Jacobi SVD (96/97 and 639/640 columns on the short side,
