@@ -1346,8 +1346,10 @@ __global__ __launch_bounds__(256) void offdiag_max(const T* __restrict__ G, long
 // while it is not the identity to 1e-11, Q is factored once more: Q = Q2 R2 is a well-conditioned problem (columns
 // lying in the span of earlier ones come out as zero columns), and R <- R2 R.  At most two extra factorisations.
 template <class T>
-int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long long ldq, T* R, long long ldr, bool dbg) {
+int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long long ldq, T* R, long long ldr, bool dbg,
+                       bool* orthonormal = nullptr) {
     static const bool reorth = !(getenv("QIL_SVD_REORTH") && atoi(getenv("QIL_SVD_REORTH")) == 0);   // tuning aid
+    if (orthonormal) *orthonormal = true;
     if (!reorth || n < 2) return QIL_OK;
     void *gbuf = nullptr, *mx = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * sizeof(T), &gbuf));
@@ -1361,6 +1363,7 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
         QIL_HIP(hipMemcpyAsync(&worst, mx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         QIL_HIP(hipStreamSynchronize(ctx->stream));
         if (dbg) fprintf(stderr, "[qr] max |Q^H Q - I| off-diagonal %.3g\n", worst);
+        if (orthonormal) *orthonormal = !(worst > 1e-9);
         if (!(worst > 1e-11) || pass == 2) break;
         QIL_TRY(qr_impl<T>(ctx, m, n, Q, ldq, static_cast<T*>(gbuf), n));                  // Q <- Q2, gbuf = R2
         if (R) {
@@ -1422,21 +1425,36 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     // apply -- need 2-4x fewer sweeps (512 x 256 graded: 36 -> 9 ms including the QR)
     static const long long rt_min = getenv("QIL_RT_MIN") ? atoll(getenv("QIL_RT_MIN")) : 97;
     const bool blocked = cols >= bj_min;
-    const bool rt = (blocked && bj_rt) || cols >= rt_min;
+    bool rt = (blocked && bj_rt) || cols >= rt_min;
     T* Q = nullptr;
     long long ldq = 0, qrows = 0;
-    void *rbuf = nullptr, *rtbuf = nullptr;
+    void *rbuf = nullptr, *rtbuf = nullptr, *abuf = nullptr;
     static const long long qr_ratio = getenv("QIL_SVD_QR_RATIO") ? atoll(getenv("QIL_SVD_QR_RATIO")) : 8;
     if ((rows >= qr_ratio * cols && rows >= 512) || rt) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rbuf));
         QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols));
-        QIL_TRY(qr_reorthogonalise<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols, dbg));
+        bool q_ok = true;
+        QIL_TRY(qr_reorthogonalise<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols, dbg, &q_ok));
+        if (!q_ok) {
+            // the re-factorisations did not reach an orthonormal basis (spectra graded to rounding level on very tall
+            // operands): Q R still reproduces the operand to rounding, so it is rebuilt and rotated as it is --
+            // slower (rows stay long), but one-sided Jacobi needs no conditioning assumption
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(rows * cols) * sizeof(T), &abuf));
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, rows, cols, cols, Wk, ldw, static_cast<const T*>(rbuf), cols,
+                                     static_cast<T*>(abuf), rows));
+            Wk = static_cast<T*>(abuf);
+            ldw = rows;
+            qil_ctx_free(ctx, rbuf);
+            rbuf = nullptr;
+            rt = false;
+        } else {
         Q = Wk;
         ldq = ldw;
         qrows = rows;
         Wk = static_cast<T*>(rbuf);
         ldw = cols;
         rows = cols;
+        }
         if (rt) {
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rtbuf));
             hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
@@ -1666,6 +1684,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     if (tbuf) qil_ctx_free(ctx, tbuf);
     if (rbuf) qil_ctx_free(ctx, rbuf);
     if (rtbuf) qil_ctx_free(ctx, rtbuf);
+    if (abuf) qil_ctx_free(ctx, abuf);
     if (lbuf) qil_ctx_free(ctx, lbuf);
     if (vbuf) qil_ctx_free(ctx, vbuf);
     if (xbuf) qil_ctx_free(ctx, xbuf);

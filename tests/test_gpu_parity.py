@@ -855,7 +855,7 @@ def test_qr_stays_orthonormal_on_numerically_rank_deficient_tall_operands(qil, m
         assert (d > 0.5).sum() <= n // 5 + 2
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 23, 26, 39, 145])
 def test_svd_shape_fuzz_across_regime_boundaries(qil, seed):
     """Random shapes around every dispatch boundary of the Jacobi SVD (96/97 and 639/640 columns on the short side,
     rows = 8 x columns, the LDS-fit limits of the fused and block-round kernels), both dtypes, random / graded /
