@@ -15,6 +15,7 @@ run QIL_SVD_BB=4
 run QIL_QR_LDS=0
 run QIL_SVD_NEGLIGIBLE=0 QIL_MPO_GAUGE_QR=0
 run QIL_SVD_QR_RATIO=2
+run QIL_QR_PANEL=16
 run QIL_BJ_TWO_SIDED=0 QIL_BJ_INNER=2
 run QIL_SVD_A_LDS=0 QIL_JACOBI_EARLY=0
 run QIL_SVD_FUSED_GLOBAL=1
