@@ -202,7 +202,9 @@ int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_t maxdim);
  * (apply.jl:75-122 followed by mps.jl:913-973) without materialising the (D chi)^2 product: a zip-up sweep
  * with intermediate bond cap zip_maxdim (<= 0: 2 maxdim) followed by the exact-gauge compress!.  Same error
  * codes as qil_apply / qil_compress.  Not a reference entry point (the reference's apply ignores its
- * cutoff/maxdim kwargs); qil_apply keeps that behaviour.                                                  */
+ * cutoff/maxdim kwargs); qil_apply keeps that behaviour.  Accuracy: as for every zip-up, the intermediate
+ * truncations are near-optimal for decaying spectra (transform MPOs on encoded signals) and can lose more
+ * than the exact route on flat-spectrum operands; qil_apply + qil_compress is the exact route.            */
 int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
                        int64_t zip_maxdim, qil_mps** out);
 

@@ -290,7 +290,9 @@ def mpo_compress(W, direction="down", cutoff=1e-14, maxdim=None):
 def apply_compress(W, psi, maxdim=None, tol=1e-12, sweeps=1, zip_maxdim=None):
     """compress(apply(W, psi), maxdim, tol, sweeps) fused: a zip-up sweep that never writes the (D chi)^2
     product tensors, then the exact-gauge compress.  (The reference's `apply` ignores cutoff/maxdim, and so
-    does `apply` here; this is the explicit truncating variant.)"""
+    does `apply` here; this is the explicit truncating variant.)  As for every zip-up, the intermediate
+    truncations are near-optimal for decaying spectra and can lose more than `compress(apply(W, psi))` -- the
+    exact route -- on flat-spectrum (random) operands; `zip_maxdim` buys head-room."""
     if W.paired != psi.paired:
         raise TypeError("apply: PairedSiteMPO acts on ZTMPS, SingleSiteMPO on SignalMPS")
     h = C.c_void_p()
