@@ -1103,30 +1103,52 @@ def test_failed_calls_leave_no_device_memory_behind(qil):
         del res
 
 
+class _DeviceSignal:
+    """A 1-D device array for the tests, without any framework: the samples are parked in the first site buffer of
+    a two-site chain (HBM owned by the library) and exposed through __cuda_array_interface__."""
+
+    def __init__(self, qil, x):
+        x = np.asarray(x)
+        n = x.size
+        site0 = np.ascontiguousarray(x.reshape(n // 2, 2).T[None, :, :])        # memory order (s fastest) = x
+        site1 = np.zeros((n // 2, 2, 1), dtype=x.dtype)
+        self._owner = qil.SignalMPS([site0, site1])
+        self.__cuda_array_interface__ = {"data": (self._owner.site_device_ptr(0), False), "shape": (n,),
+                                         "typestr": x.dtype.str, "version": 2}
+
+
 def test_signal_encoders_take_device_resident_signals(qil):
-    """The samples may already be in HBM (torch tensor / anything with __cuda_array_interface__): same MPS as
-    from the host copy, no PCIe trip.  SignalConverters.jl:228-233, 247-283."""
+    """The samples may already be in HBM (anything with __cuda_array_interface__, e.g. a torch CUDA tensor): same
+    MPS as from the host copy, no PCIe trip.  SignalConverters.jl:228-233, 247-283.  (A torch tensor is used as the
+    producer only when QIL_TEST_TORCH=1: the first `import torch` on a fresh box takes minutes.)"""
     import os
-    if os.environ.get("QIL_SYSTEM_HIP") == "1":
-        pytest.skip("opted out of sharing torch's HIP runtime: torch cannot see the GPU in this process")
-    torch = pytest.importorskip("torch")
     rng = np.random.default_rng(31)
     n = 12
     x = np.sin(0.01 * np.arange(2 ** n)) * np.exp(-1e-3 * np.arange(2 ** n)) + 1e-3 * rng.standard_normal(2 ** n)
-    xd = torch.from_numpy(x).cuda()
-    a = qil.signal_mps(x, method="svd", cutoff=1e-12)
-    b = qil.signal_mps(xd, method="svd", cutoff=1e-12)
-    assert a.bond_dims == b.bond_dims and abs(a.amplitude - b.amplitude) < 1e-12 * a.amplitude
-    assert np.abs(qil.mps_to_vector(b) - x).max() < 1e-5 * np.abs(x).max()
     z = x * np.exp(0.3j * np.arange(2 ** n))
-    zd = torch.from_numpy(z).cuda()
-    c = qil.signal_ztmps(zd, method="rsvd", k=24, p=6, q=1, cutoff=1e-12, maxdim=32)
-    d = qil.signal_ztmps(z, method="rsvd", k=24, p=6, q=1, cutoff=1e-12, maxdim=32)
-    assert c.bonds_main == d.bonds_main and c.bonds_copy == d.bonds_copy
+    producers = [lambda v: _DeviceSignal(qil, v)]
+    if os.environ.get("QIL_TEST_TORCH") == "1" and os.environ.get("QIL_SYSTEM_HIP") != "1":
+        torch = pytest.importorskip("torch")
+        producers.append(lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda())
+    for dev in producers:
+        xd = dev(x)
+        a = qil.signal_mps(x, method="svd", cutoff=1e-12)
+        b = qil.signal_mps(xd, method="svd", cutoff=1e-12)
+        assert a.bond_dims == b.bond_dims and abs(a.amplitude - b.amplitude) < 1e-12 * a.amplitude
+        assert np.abs(qil.mps_to_vector(b) - x).max() < 1e-5 * np.abs(x).max()
+        zd = dev(z)
+        c = qil.signal_ztmps(zd, method="rsvd", k=24, p=6, q=1, cutoff=1e-12, maxdim=32)
+        d = qil.signal_ztmps(z, method="rsvd", k=24, p=6, q=1, cutoff=1e-12, maxdim=32)
+        assert c.bonds_main == d.bonds_main and c.bonds_copy == d.bonds_copy
+
+    class _Bad:
+        def __init__(self, shape, typestr):
+            self.__cuda_array_interface__ = {"data": (xd.__cuda_array_interface__["data"][0], False), "shape": shape,
+                                             "typestr": typestr, "version": 2}
     with pytest.raises(ValueError):
-        qil.signal_mps(torch.zeros(8, 2, dtype=torch.float64).cuda())
+        qil.signal_mps(_Bad((8, 2), "<f8"))                      # not 1-D
     with pytest.raises(ValueError):
-        qil.signal_mps(torch.zeros(8, dtype=torch.float32).cuda())
+        qil.signal_mps(_Bad((8,), "<f4"))                        # not float64 / complex128
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
