@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round(T* __restrict__ A,
                                                               int round, int all_pairs, double tol,
                                                               int* __restrict__ rotated,
                                                               const double* __restrict__ negligible) {
-    constexpr int W = 2 * BB, NT = 64 * BB;
+    constexpr int W = 2 * BB;
     extern __shared__ __attribute__((aligned(16))) char jb_smem[];
     const int la = m | 1, lv = vrows | 1;
     T* As = reinterpret_cast<T*>(jb_smem);
@@ -556,27 +556,30 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round(T* __restrict__ A,
     }
     auto gcol = [&](int k) { return (k < BB ? P * BB + k : Q * BB + (k - BB)); };
     if (P * BB >= n) return;                               // both blocks are padding
-    // staging: eight independent loads in flight per thread (a rolled copy loop waits out one L2 / fabric round trip
-    // per element, which costs more than the rotations)
+    // staging: every wave owns two of the 2 BB columns (NT / 64 = BB waves), lanes stride the rows -- coalesced, no
+    // index division, eight independent loads in flight per thread (a rolled copy loop waits out one L2 / fabric round
+    // trip per element, which costs more than the rotations)
+    const int kc0 = wave, kc1 = wave + BB;
+    const int gc0 = gcol(kc0), gc1 = gcol(kc1);
     auto stage = [&](const T* __restrict__ G, long long ldg, int rws, T* __restrict__ S, int lds_) {
-        const int total = W * rws;
-        for (int base = tid; base < total; base += 8 * NT) {
-            T tmp[8];
+        const T* s0 = G + ldg * gc0;
+        const T* s1 = G + ldg * gc1;
+        T* d0 = S + (size_t)lds_ * kc0;
+        T* d1 = S + (size_t)lds_ * kc1;
+        for (int r0 = lane; r0 < rws; r0 += 256) {
+            T t0[4], t1[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * NT;
-                tmp[u] = T{};
-                if (idx < total) {
-                    const int k = idx / rws, r = idx - k * rws, g = gcol(k);
-                    if (g < n) tmp[u] = G[r + ldg * g];
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 64 * u;
+                t0[u] = (gc0 < n && r < rws) ? s0[r] : T{};
+                t1[u] = (gc1 < n && r < rws) ? s1[r] : T{};
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * NT;
-                if (idx < total) {
-                    const int k = idx / rws, r = idx - k * rws;
-                    S[r + (size_t)lds_ * k] = tmp[u];
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 64 * u;
+                if (r < rws) {
+                    d0[r] = t0[u];
+                    d1[r] = t1[u];
                 }
             }
         }
@@ -623,10 +626,15 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round(T* __restrict__ A,
         if (flags & 2) rotated[1] = 1;
     }
     auto unstage = [&](T* __restrict__ G, long long ldg, int rws, const T* __restrict__ S, int lds_) {
-        const int total = W * rws;
-        for (int idx = tid; idx < total; idx += NT) {
-            const int k = idx / rws, r = idx - k * rws, g = gcol(k);
-            if (g < n) G[r + ldg * g] = S[r + (size_t)lds_ * k];
+        if (gc0 < n) {
+            T* d = G + ldg * gc0;
+            const T* sp = S + (size_t)lds_ * kc0;
+            for (int r = lane; r < rws; r += 64) d[r] = sp[r];
+        }
+        if (gc1 < n) {
+            T* d = G + ldg * gc1;
+            const T* sp = S + (size_t)lds_ * kc1;
+            for (int r = lane; r < rws; r += 64) d[r] = sp[r];
         }
     };
     unstage(A, lda, m, As, la);
