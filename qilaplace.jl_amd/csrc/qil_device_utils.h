@@ -190,8 +190,11 @@ __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ld
                     p = npad - 1;
                     q = round;
                 } else {
-                    p = (round + i) % (npad - 1);
-                    q = (round + npad - 1 - i) % (npad - 1);
+                    // both sums lie in [0, 2 (npad - 1)): one conditional subtraction, not a runtime modulo
+                    p = round + i;
+                    q = round + npad - 1 - i;
+                    if (p >= npad - 1) p -= npad - 1;
+                    if (q >= npad - 1) q -= npad - 1;
                 }
                 if (p >= n || q >= n) continue;
                 if (p > q) {
