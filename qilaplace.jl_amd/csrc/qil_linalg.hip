@@ -797,7 +797,19 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long l
     if (LDS) {
         A = csum + (n + (n & 1));
         lda = m | 1;
-        for (int t = tid; t < m * n; t += 1024) A[(t % m) + lda * (t / m)] = Ag[(t % m) + ldg * (t / m)];
+        // one wave per column, lanes stride the rows (coalesced, no index division), four loads in flight per lane
+        for (int k = wave; k < n; k += NW) {
+            const T* src = Ag + ldg * k;
+            T* dst = A + lda * k;
+            for (int r0 = lane; r0 < m; r0 += 256) {
+                T t4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t4[u] = r0 + 64 * u < m ? src[r0 + 64 * u] : T{};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (r0 + 64 * u < m) dst[r0 + 64 * u] = t4[u];
+            }
+        }
     }
     if (R)
         for (int t = tid; t < n * n; t += 1024) R[(t % n) + ldr * (t / n)] = T{};
@@ -943,7 +955,11 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long l
         __syncthreads();
     }
     if (LDS)
-        for (int t = tid; t < m * n; t += 1024) Ag[(t % m) + ldg * (t / m)] = A[(t % m) + lda * (t / m)];
+        for (int k = wave; k < n; k += NW) {
+            T* dst = Ag + ldg * k;
+            const T* src = A + lda * k;
+            for (int r = lane; r < m; r += 64) dst[r] = src[r];
+        }
 }
 
 // launches gs_fused with the slice in LDS whenever rows_per_workgroup x n fits
