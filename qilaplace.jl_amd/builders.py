@@ -343,6 +343,7 @@ def build_dt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None):
 
 _ZT_Q_CACHE = {}
 _WORKER_CTX = {}          # (device, worker index) -> Context of build_zt_mpo_batch's worker threads
+_WORKER_LOCK = __import__("threading").Lock()
 
 
 @_single_thread_blas
@@ -423,11 +424,12 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, worke
         except Exception as e:                      # noqa: BLE001  (re-raised on the calling thread)
             errors.append(e)
 
-    threads = [threading.Thread(target=_worker, args=(k,)) for k in range(nw)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    with _WORKER_LOCK:                                   # the persistent worker contexts serve one batch at a time
+        threads = [threading.Thread(target=_worker, args=(k,)) for k in range(nw)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     if errors:
         raise errors[0]
     return [PairedSiteMPO(r, sites=ids, ctx=home) for r in results]
