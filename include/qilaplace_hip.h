@@ -232,11 +232,15 @@ int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n, int dty
 
 /* ------------------------------------------------------------------ transform producers (P2) */
 /* build_dt_mpo(n, wr; cutoff=1e-14, maxdim=1000) src/transforms/dt_transformer.jl:312-407 for a BATCH of
- * damping values wr[0..nb): all chains are built together on the device (one workgroup per damping value
- * per step).  out[nb] receives PairedSiteMPO handles (f64, 2n tensors, site ids 1..2n); the batch shares one
- * bond profile (each MPO is zero-padded to the batch maximum -- same operator).  maxdim <= 0: no cap.      */
+ * damping values wr[0..nb): ONE kernel launch, one workgroup per damping value runs that value's whole chain of
+ * zip_to_combine / zip_to_compress steps (:20-288) with the tensors being factorised resident in LDS.
+ * out[nb] receives PairedSiteMPO handles (f64, 2n tensors), each with its own bond dimensions -- those of a
+ * single build_dt_mpo call.  site_ids: the 2n labels of the operand the MPOs will act on (build_dt_mpo(psi::ZTMPS,
+ * ...) builds on psi's own sites, dt_transformer.jl:409-412); NULL => 1..2n.  maxdim <= 0: no cap.
+ * Bonds beyond the in-LDS capacity (truncated bond > 20; never at the reference's cutoffs) take a launch-per-step
+ * route that pads every MPO of the batch to a common bond profile with zero components (same operators).      */
 int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff,
-                           int64_t maxdim, qil_mpo** out);
+                           int64_t maxdim, const int64_t* site_ids, qil_mpo** out);
 
 /* C (m x n) = opA(A) * opB(B) on host operands, column-major; op: 0 = N, 1 = T, 2 = H, 3 = conj.
  * The f64-MFMA GEMM every contraction of the truncation/encode path goes through (the `*` of

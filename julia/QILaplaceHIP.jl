@@ -39,9 +39,13 @@ mutable struct Context
     function Context(device::Integer=0)
         r = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:qil_context_create, LIB), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, r))
-        finalizer(c -> ccall((:qil_context_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), new(r[]))
+        # No finalizer: handles (DeviceMPS / DeviceMPO) carry their own finalizers and finalizer order at exit is
+        # unspecified -- a context must outlive its handles.  The library also orphans live handles when a context is
+        # destroyed explicitly (destroy! below), so either order is safe.
+        new(r[])
     end
 end
+destroy!(c::Context) = (ccall((:qil_context_destroy, LIB), Cint, (Ptr{Cvoid},), c.h); c.h = C_NULL; nothing)
 const DEFAULT_CTX = Ref{Union{Nothing,Context}}(nothing)
 ctx() = something(DEFAULT_CTX[], (DEFAULT_CTX[] = Context(0)))
 
@@ -281,9 +285,10 @@ function build_dt_mpo_batch(psi::DeviceMPS, wrs::AbstractVector{<:Real}; cutoff:
     n = length(psi.sites) ÷ 2
     w = Vector{Float64}(wrs)
     hs = Vector{Ptr{Cvoid}}(undef, length(w))
+    _site_labels(p) = Int64.(hash.(p.sites) .% typemax(Int64))          # same labels as to_device
     check(ccall((:qil_build_dt_mpo_batch, LIB), Cint,
-                (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Cdouble, Int64, Ptr{Ptr{Cvoid}}),
-                ctx().h, n, length(w), w, cutoff, maxdim, hs))
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Cdouble, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
+                ctx().h, n, length(w), w, cutoff, maxdim, _site_labels(psi), hs))
     return [finalizer(_free!, DeviceMPO(h, copy(psi.sites), true)) for h in hs]
 end
 

@@ -325,9 +325,9 @@ def dt_mpo_tensors_many(n, wrs, cutoff=1e-14, maxdim=1000, workers=8):
 
 
 def build_dt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None):
-    """All damping values of a sweep built TOGETHER on the GPU (qil_build_dt_mpo_batch): one launch per
-    step with one workgroup per damping value, instead of one host chain per value.  Returns a list of
-    PairedSiteMPO handles sharing one (zero-padded) bond profile."""
+    """All damping values of a sweep built TOGETHER on the GPU (qil_build_dt_mpo_batch): ONE kernel launch, one
+    workgroup per damping value running that value's whole chain in LDS.  Returns a list of PairedSiteMPO handles,
+    each with the bond dimensions of a single build_dt_mpo call, labelled with psi's site ids when psi is given."""
     import ctypes as C
     from . import _lib as L
     from .containers import default_context
@@ -336,8 +336,11 @@ def build_dt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None):
     n = _n_of(n_or_psi)
     w = np.ascontiguousarray(np.asarray(list(wrs), dtype=np.float64))
     outs = (C.c_void_p * len(w))()
+    ids = None
+    if psi is not None:                      # build_dt_mpo(psi::ZTMPS, ...) builds on psi's own sites (:409-412)
+        ids = (C.c_int64 * (2 * n))(*[int(i) for i in psi.site_ids])
     L.check(L.lib.qil_build_dt_mpo_batch(ctx.handle, int(n), len(w), w.ctypes.data_as(C.POINTER(C.c_double)),
-                                         float(cutoff), -1 if maxdim is None else int(maxdim), outs))
+                                         float(cutoff), -1 if maxdim is None else int(maxdim), ids, outs))
     return [PairedSiteMPO(ctx=ctx, _handle=C.c_void_p(h)) for h in outs]
 
 

@@ -411,6 +411,17 @@ extern "C" int qil_apply_mpo_mpo(const qil_mpo* W1, const qil_mpo* W2, qil_mpo**
     const qil_mpo* base = n1 >= n2 ? W1 : W2;
     const int64_t base_start = n1 >= n2 ? start1 : start2;
     const int64_t nb = base->n();
+    // The shorter operand must lie entirely inside the window: otherwise its bond at the window edge would
+    // dangle (the reference leaves that index on the edge tensor and its SingleSiteMPO constructor throws,
+    // mpo.jl check_singlesitempo) -- and the fused edge bond would not match the copied base neighbour.
+    {
+        const qil_mpo* other = n1 >= n2 ? W2 : W1;
+        const int64_t other_start = n1 >= n2 ? start2 : start1;
+        QIL_REQUIRE(other_start == 0 && match == other->n(), QIL_EINVAL_SITES,
+                    "apply: MPOs overlap only partially (sites %lld..%lld of the shorter operand's %lld): its "
+                    "bond at the window edge would be left dangling",
+                    (long long)other_start + 1, (long long)(other_start + match), (long long)other->n());
+    }
     std::vector<int64_t> dims(base->dims);
     for (int64_t i = 0; i <= match; ++i) {
         // bond to the left of window site i (i == match: right of the last window site)

@@ -212,68 +212,6 @@ __global__ __launch_bounds__(256) void bgs_fused(double* __restrict__ A, double*
         for (int t = tid; t < m * n; t += 256) a0[t] = Aw[(t % m) + la * (t / m)];
 }
 
-// One-sided Jacobi on every slice: the columns of A (m x n, n <= m) are rotated in place until mutually
-// orthogonal; norms (n) receives the column norms = singular values.  No V accumulation: the callers
-// recover the other factor with one small GEMM.  A lives in LDS for the whole iteration when it fits.
-template <class T, int G, int NT>
-__device__ __forceinline__ void jacobi_sweeps_nov(T* A, int lda, int m, int n, double tol, int max_sweeps,
-                                                  int* s_rot, double negligible) {
-    const int tid = threadIdx.x, lane = tid & (G - 1), grp = tid / G;
-    constexpr int NW = NT / G;
-    const int npad = n + (n & 1);
-    for (int sweep = 0; sweep < max_sweeps && n > 1; ++sweep) {
-        if (tid == 0) *s_rot = 0;
-        __syncthreads();
-        for (int round = 0; round < npad - 1; ++round) {
-            for (int i = grp; i < npad / 2; i += NW) {
-                int p, q;
-                if (i == 0) {
-                    p = npad - 1;
-                    q = round;
-                } else {
-                    // both sums lie in [0, 2 (npad - 1)): one conditional subtraction, not a runtime modulo
-                    p = round + i;
-                    q = round + npad - 1 - i;
-                    if (p >= npad - 1) p -= npad - 1;
-                    if (q >= npad - 1) q -= npad - 1;
-                }
-                if (p >= n || q >= n) continue;
-                T* ap = A + lda * p;
-                T* aq = A + lda * q;
-                double al = 0, be = 0, gr = 0, gi = 0;
-                for (int r = lane; r < m; r += G) {
-                    const T x = ap[r], y = aq[r];
-                    al += abs2_t(x);
-                    be += abs2_t(y);
-                    dot_parts(x, y, gr, gi);
-                }
-                al = group_sum<G>(al);
-                be = group_sum<G>(be);
-                gr = group_sum<G>(gr);
-                // a column below 1e-15 of the slice's Frobenius norm is rounding residue of a rank-deficient
-                // slice: it has no direction to converge to and would keep the sweeps going (6 instead of 8.5
-                // sweeps on the builder's slices); its norm is far below any truncation cutoff
-                if (al < negligible || be < negligible) continue;
-                double c, sn, pr, pi_unused;
-                bool big;
-                if (!jacobi_rotation<false>(al, be, gr, 0.0, tol, c, sn, pr, pi_unused, big)) continue;
-                if (lane == 0) atomicOr(s_rot, big ? 3 : 1);
-                for (int r = lane; r < m; r += G) {
-                    T x = ap[r], y = aq[r];
-                    rotate_pair(x, y, c, sn, pr, 0.0);
-                    ap[r] = x;
-                    aq[r] = y;
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-        const int any = *s_rot;
-        __syncthreads();
-        if (!(any & 2)) break;
-    }
-}
-
 template <bool LDS, int NT>
 __global__ __launch_bounds__(NT) void bjacobi(double* __restrict__ A, double* __restrict__ norms, int m, int n,
                                               double tol) {
@@ -778,13 +716,24 @@ void dt_copy_site(int n, int k, double w, int site, int* dl, int* dr, std::vecto
 
 }  // namespace
 
+int qil_build_dt_persistent(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff, int64_t maxdim,
+                            const int64_t* site_ids, qil_mpo** out, int* fallback);
+
 extern "C" int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff,
-                                      int64_t maxdim, qil_mpo** out) {
+                                      int64_t maxdim, const int64_t* site_ids, qil_mpo** out) {
     QIL_REQUIRE(ctx && wrs && out, QIL_EINVAL_ARG, "build_dt_mpo: null argument");
     QIL_REQUIRE(n >= 1, QIL_EINVAL_ARG, "build_dt_mpo: n must be >= 1. Found n=%lld", (long long)n);
     QIL_REQUIRE(nb >= 1 && nb <= 4096, QIL_EINVAL_ARG, "build_dt_mpo: batch of %lld damping values", (long long)nb);
     QIL_TRY(qil_ctx_activate(ctx));
     qil_call_scope call_scope(ctx);
+    // default route: the persistent kernel (one launch, one workgroup per damping value, true bond dimensions per
+    // value); the launch-per-step route below serves bonds beyond its in-LDS capacity and QIL_DT_BUILDER=launches
+    const char* mode = getenv("QIL_DT_BUILDER");
+    if (!(mode && strcmp(mode, "launches") == 0)) {
+        int fallback = 0;
+        QIL_TRY(qil_build_dt_persistent(ctx, n, nb, wrs, cutoff, maxdim, site_ids, out, &fallback));
+        if (!fallback) return QIL_OK;
+    }
     Builder bd{ctx, (int)nb, cutoff, maxdim <= 0 ? INT64_MAX : maxdim};
     const int B = (int)nb;
     std::vector<BSite> M;
@@ -836,7 +785,7 @@ extern "C" int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, c
     for (int i = 0; i + 1 < L; ++i) bonds[(size_t)i] = M[(size_t)i].dr;
     for (int b = 0; b < B; ++b) {
         qil_mpo* W = nullptr;
-        st = qil_mpo_alloc(ctx, L, QIL_F64, 1, bonds.data(), nullptr, &W);
+        st = qil_mpo_alloc(ctx, L, QIL_F64, 1, bonds.data(), site_ids, &W);
         if (st != QIL_OK) return fail(st);
         for (int i = 0; i < L; ++i) {
             const size_t bytes = (size_t)M[(size_t)i].elems() * sizeof(double);

@@ -86,8 +86,13 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
     if (!ctx) return QIL_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (qil_chain* c : ctx->chains) {                    // handles the caller has not destroyed yet: orphan them
+        c->ctx = nullptr;
+        for (void*& p : c->site) p = nullptr;
+    }
+    ctx->chains.clear();
     for (auto& kv : ctx->free_blocks) hipFree(kv.second);
-    for (auto& kv : ctx->live_blocks) hipFree(kv.first);  // handles the caller never destroyed
+    for (auto& kv : ctx->live_blocks) hipFree(kv.first);  // ... their blocks go with the pool
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->dev_scratch) hipFree(ctx->dev_scratch);
     if (ctx->desc_host) hipHostFree(ctx->desc_host);
@@ -352,7 +357,7 @@ int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int pa
     QIL_REQUIRE(!paired || n % 2 == 0, QIL_EINVAL_LENGTH,
                 "paired chains need an even number of tensors (got %lld)", (long long)n);
     QIL_REQUIRE(n == 1 || bond_dims, QIL_EINVAL_ARG, "null bond_dims");
-    c->ctx = ctx;
+    qil_chain_bind(c, ctx);
     c->dtype = dtype;
     c->paired = paired ? 1 : 0;
     c->phys_rank = phys_rank;
@@ -375,6 +380,11 @@ int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int pa
         mark_owned(ctx, c->site[(size_t)i]);
     }
     return QIL_OK;
+}
+
+void qil_chain_bind(qil_chain* c, qil_context* ctx) {
+    c->ctx = ctx;
+    if (ctx) ctx->chains.insert(c);
 }
 
 int qil_chain_release(qil_chain* c) {

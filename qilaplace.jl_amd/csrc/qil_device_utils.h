@@ -245,4 +245,67 @@ __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ld
 }
 
 
+// One-sided Jacobi on every slice: the columns of A (m x n, n <= m) are rotated in place until mutually
+// orthogonal; norms (n) receives the column norms = singular values.  No V accumulation: the callers
+// recover the other factor with one small GEMM.  A lives in LDS for the whole iteration when it fits.
+template <class T, int G, int NT>
+__device__ __forceinline__ void jacobi_sweeps_nov(T* A, int lda, int m, int n, double tol, int max_sweeps,
+                                                  int* s_rot, double negligible) {
+    const int tid = threadIdx.x, lane = tid & (G - 1), grp = tid / G;
+    constexpr int NW = NT / G;
+    const int npad = n + (n & 1);
+    for (int sweep = 0; sweep < max_sweeps && n > 1; ++sweep) {
+        if (tid == 0) *s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < npad - 1; ++round) {
+            for (int i = grp; i < npad / 2; i += NW) {
+                int p, q;
+                if (i == 0) {
+                    p = npad - 1;
+                    q = round;
+                } else {
+                    // both sums lie in [0, 2 (npad - 1)): one conditional subtraction, not a runtime modulo
+                    p = round + i;
+                    q = round + npad - 1 - i;
+                    if (p >= npad - 1) p -= npad - 1;
+                    if (q >= npad - 1) q -= npad - 1;
+                }
+                if (p >= n || q >= n) continue;
+                T* ap = A + lda * p;
+                T* aq = A + lda * q;
+                double al = 0, be = 0, gr = 0, gi = 0;
+                for (int r = lane; r < m; r += G) {
+                    const T x = ap[r], y = aq[r];
+                    al += abs2_t(x);
+                    be += abs2_t(y);
+                    dot_parts(x, y, gr, gi);
+                }
+                al = group_sum<G>(al);
+                be = group_sum<G>(be);
+                gr = group_sum<G>(gr);
+                // a column below 1e-15 of the slice's Frobenius norm is rounding residue of a rank-deficient
+                // slice: it has no direction to converge to and would keep the sweeps going (6 instead of 8.5
+                // sweeps on the builder's slices); its norm is far below any truncation cutoff
+                if (al < negligible || be < negligible) continue;
+                double c, sn, pr, pi_unused;
+                bool big;
+                if (!jacobi_rotation<false>(al, be, gr, 0.0, tol, c, sn, pr, pi_unused, big)) continue;
+                if (lane == 0) atomicOr(s_rot, big ? 3 : 1);
+                for (int r = lane; r < m; r += G) {
+                    T x = ap[r], y = aq[r];
+                    rotate_pair(x, y, c, sn, pr, 0.0);
+                    ap[r] = x;
+                    aq[r] = y;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        const int any = *s_rot;
+        __syncthreads();
+        if (!(any & 2)) break;
+    }
+}
+
+
 }  // namespace qil_dev

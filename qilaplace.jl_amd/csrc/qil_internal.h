@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,9 @@ struct qil_context {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     std::vector<hipEvent_t> event_pool;
     int num_cus = 256;
+    // live chain handles: orphaned (ctx = nullptr, site pointers dropped) when the context is destroyed first,
+    // so a handle released after its context touches nothing
+    std::set<struct qil_chain*> chains;
 };
 
 int qil_ctx_activate(qil_context* ctx);  // hipSetDevice
@@ -99,6 +103,12 @@ struct qil_chain {
     std::vector<int64_t> site_ids;   // n labels
     std::vector<void*> site;         // device pointers, one allocation per site
     double amplitude = 1.0;
+    qil_chain() = default;
+    qil_chain(const qil_chain&) = delete;
+    qil_chain& operator=(const qil_chain&) = delete;
+    ~qil_chain() {
+        if (ctx) ctx->chains.erase(this);
+    }
     int64_t n() const { return (int64_t)site.size(); }
     int64_t site_elems(int64_t i) const {
         return dims[i] * (phys_rank == 1 ? 2 : 4) * dims[i + 1];
@@ -111,6 +121,8 @@ struct qil_mpo : qil_chain {};
 int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int paired, int phys_rank,
                     const int64_t* bond_dims, const int64_t* site_ids);
 int qil_chain_release(qil_chain* c);
+// tie a handle to its context (registers it for orphaning on context destruction)
+void qil_chain_bind(qil_chain* c, qil_context* ctx);
 // replace site i's buffer (takes ownership of `p`), updating the bond dims
 int qil_chain_set_site(qil_chain* c, int64_t i, void* p, int64_t dl, int64_t dr);
 // attach a pool block to an EMPTY site slot of a chain under construction (ownership moves to the chain)

@@ -456,7 +456,7 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
         return s;
     }
     qil_mps* psi = new qil_mps();
-    psi->ctx = ctx;
+    qil_chain_bind(psi, ctx);
     psi->dtype = dtype;
     psi->paired = 0;
     psi->phys_rank = 1;
@@ -594,7 +594,7 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
         return st;
     }
     qil_mps* res = new qil_mps();
-    res->ctx = ctx;
+    qil_chain_bind(res, ctx);
     res->dtype = odt;
     res->paired = psi->paired;
     res->phys_rank = 1;
@@ -796,7 +796,7 @@ extern "C" int qil_signal_ztmps(qil_context* ctx, const void* x, int64_t len, in
     const int64_t n = sig->n();
     const size_t e = qil_elem_size(dtype);
     qil_mps* zt = new qil_mps();
-    zt->ctx = ctx;
+    qil_chain_bind(zt, ctx);
     zt->dtype = dtype;
     zt->paired = 1;
     zt->phys_rank = 1;

@@ -141,6 +141,13 @@ def test_mpo_mpo_composition(qil):                                # test_apply.j
             assert rel(g.site(i), r.data[i]) < 1e-14
     with pytest.raises(ValueError, match="No matching sites"):
         qil.apply(qil.SingleSiteMPO.identity(2, sites=[7, 8]), qil.SingleSiteMPO(wl, sites=[1, 2, 3, 4]))
+    # partial overlap: the shorter operand sticks out of the window, its edge bond would dangle (the reference's
+    # SingleSiteMPO constructor throws on the result, apply.jl:198 -> mpo.jl check) -- refused, nothing written
+    wa, wb = random_mpo_data([3, 3], rng), random_mpo_data([3, 3], rng)
+    for sa, sb in (([1, 2, 3], [2, 3, 4]), ([2, 3, 4], [1, 2, 3]), ([1, 2, 3, 4], [3, 4, 5])):
+        A = qil.SingleSiteMPO(wl if len(sa) == 4 else wa, sites=sa)
+        with pytest.raises(ValueError, match="partially"):
+            qil.apply(A, qil.SingleSiteMPO(wb, sites=sb))
 
 
 # ---------------------------------------------------------------- read-out (C1, C2, K3)
