@@ -172,6 +172,12 @@ int qil_coefficient_marginal_batch(const qil_mps* psi, int64_t nb, const uint8_t
  * qil_coefficient_batch(qil_apply(W, psi))).                                      */
 int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi, int64_t nb,
                                 const uint8_t* bits, double* out);
+/* The body of a damping sweep: for each of the nw operators (the reference's loop `W = build_dt_mpo(psi, wr);
+ * out = W * psi; coefficient(out, ...)`, docs/src/tutorials/dt.jl:150-197, zt.jl:300-348) the product W_j psi is
+ * materialised by the apply kernel (apply.jl:75-122) and read out at the same nb configurations (mps.jl:669-693).
+ * out: host, nw x nb complex doubles, operator-major.  One upload, one download, one synchronisation for the batch.  */
+int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw, const qil_mps* psi, int64_t nb,
+                                const uint8_t* bits, double* out);
 /* mps_to_vector(psi; reverse) src/mps.jl:716-743: 2^n values of psi's dtype, times amplitude. */
 int qil_mps_to_vector(const qil_mps* psi, int reverse, void* host_out);
 /* Dense read-out of a sub-lattice of configurations: spec[i] = 0 / 1 fixes site i's bit, 2 sums the site

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "qil_coefficient_batch": [_vp, _i64, _pu8, _pdbl],
     "qil_coefficient_marginal_batch": [_vp, _i64, _pu8, _pdbl],
     "qil_apply_coefficient_batch": [_vp, _vp, _i64, _pu8, _pdbl],
+    "qil_apply_coefficient_sweep": [_pvp, _i64, _vp, _i64, _pu8, _pdbl],
     "qil_mps_to_vector": [_vp, _int, _vp],
     "qil_mps_block": [_vp, _pu8, _int, _vp],
     "qil_norm": [_vp, _pdbl],

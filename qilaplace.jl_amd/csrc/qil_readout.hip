@@ -375,12 +375,10 @@ extern "C" int qil_coefficient_marginal_batch(const qil_mps* psi, int64_t nb, co
     return coefficient_impl(psi, nb, bits, out, 2);
 }
 
-static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out, int max_bit) {
-    QIL_REQUIRE(psi && (nb == 0 || (bits && out)), QIL_EINVAL_ARG, "coefficient: null argument");
-    if (nb == 0) return QIL_OK;
+// Enqueue the read-out of nb configurations (device bits) of psi into dout (nb complex, device); no
+// synchronisation, every temporary goes back to the pool in stream order.
+static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* dbits, void* dout) {
     qil_context* ctx = psi->ctx;
-    QIL_TRY(qil_ctx_activate(ctx));
-    qil_call_scope call_scope(ctx);
     const int64_t n = psi->n();
     std::vector<ChainSite> tab((size_t)n);
     long long maxchi = 1;
@@ -389,8 +387,6 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
                                    (int)psi->dims[(size_t)i + 1], 1, 1};
         maxchi = std::max<long long>(maxchi, psi->dims[(size_t)i + 1]);
     }
-    uint8_t* dbits = nullptr;
-    QIL_TRY(upload_bits(ctx, nb, n, bits, &dbits, max_bit));
     const size_t esz = qil_elem_size(psi->dtype);
     // crossover between one-workgroup-per-query chains and the all-queries-together GEMM path (tuning aid:
     // QIL_COEFF_GEMM_MINCHI)
@@ -402,11 +398,10 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
         // Large bonds: all queries advance together, one f64-MFMA GEMM per site.  The site tensor is
         // read ONCE for the whole batch: T (nb x 2 chi_r) = V (nb x chi_l) * A_i (chi_l x 2 chi_r),
         // then each query keeps the column block of its own bit.
-        void *V = nullptr, *Vn = nullptr, *Tm = nullptr, *dout2 = nullptr;
+        void *V = nullptr, *Vn = nullptr, *Tm = nullptr;
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nb * maxchi) * esz, &V));
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nb * maxchi) * esz, &Vn));
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * nb * maxchi) * esz, &Tm));
-        QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout2));
         const bool cx = psi->dtype == QIL_C64;
         const unsigned g1 = (unsigned)std::min<long long>((nb + 255) / 256, 4096);
         if (cx) hipLaunchKernelGGL(fill_ones<c64>, dim3(g1), dim3(256), 0, ctx->stream, (c64*)V, (long long)nb);
@@ -424,23 +419,18 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
             std::swap(V, Vn);
         }
         if (cx) hipLaunchKernelGGL(finish_coeff<c64>, dim3(g1), dim3(256), 0, ctx->stream, (const c64*)V,
-                                   (long long)nb, psi->amplitude, (c64*)dout2);
+                                   (long long)nb, psi->amplitude, (c64*)dout);
         else hipLaunchKernelGGL(finish_coeff<double>, dim3(g1), dim3(256), 0, ctx->stream, (const double*)V,
-                                (long long)nb, psi->amplitude, (c64*)dout2);
+                                (long long)nb, psi->amplitude, (c64*)dout);
         QIL_HIP(hipGetLastError());
-        QIL_HIP(hipMemcpyAsync(out, dout2, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream));
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
         qil_ctx_free(ctx, V);
         qil_ctx_free(ctx, Vn);
         qil_ctx_free(ctx, Tm);
-        qil_ctx_free(ctx, dout2);
-        qil_ctx_free(ctx, dbits);
         return QIL_OK;
     }
-    void *scratch = nullptr, *dout = nullptr, *pin = nullptr, *dtab = nullptr;
+    void *scratch = nullptr, *pin = nullptr, *dtab = nullptr;
     int slot = 0;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * nb * maxchi) * esz, &scratch));
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout));
     QIL_TRY(qil_ctx_desc_acquire(ctx, tab.size() * sizeof(ChainSite), &pin, &dtab, &slot));
     memcpy(pin, tab.data(), tab.size() * sizeof(ChainSite));
     QIL_HIP(hipMemcpyAsync(dtab, pin, tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, ctx->stream));
@@ -454,9 +444,54 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
                            psi->amplitude);
     QIL_HIP(hipGetLastError());
     QIL_TRY(qil_ctx_desc_commit(ctx, slot));
+    qil_ctx_free(ctx, scratch);
+    return QIL_OK;
+}
+
+static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits, double* out, int max_bit) {
+    QIL_REQUIRE(psi && (nb == 0 || (bits && out)), QIL_EINVAL_ARG, "coefficient: null argument");
+    if (nb == 0) return QIL_OK;
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
+    uint8_t* dbits = nullptr;
+    QIL_TRY(upload_bits(ctx, nb, psi->n(), bits, &dbits, max_bit));
+    void* dout = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout));
+    QIL_TRY(coefficient_enqueue(psi, nb, dbits, dout));
     QIL_HIP(hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream));
     QIL_HIP(hipStreamSynchronize(ctx->stream));
-    qil_ctx_free(ctx, scratch);
+    qil_ctx_free(ctx, dout);
+    qil_ctx_free(ctx, dbits);
+    return QIL_OK;
+}
+
+// The body of a damping sweep (BASELINE.json configs[3]; the reference loops `W = build_dt_mpo(psi, wr); out = W * psi;
+// coefficient(out, ...)` per damping value, docs/src/tutorials/dt.jl:150-197, zt.jl:300-348): for every operator of the
+// batch the product W_j psi is materialised by the apply kernel and read out at the same nb configurations.  One bit
+// upload, one download and ONE host synchronisation for the whole batch; each product's blocks return to the pool in
+// stream order and serve the next one.
+extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw, const qil_mps* psi, int64_t nb,
+                                           const uint8_t* bits, double* out) {
+    QIL_REQUIRE(Ws && psi && (nb == 0 || (bits && out)), QIL_EINVAL_ARG, "apply_coefficient_sweep: null argument");
+    if (nw == 0 || nb == 0) return QIL_OK;
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
+    uint8_t* dbits = nullptr;
+    QIL_TRY(upload_bits(ctx, nb, psi->n(), bits, &dbits, 1));
+    void* dout = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nw * nb) * 16, &dout));
+    for (int64_t j = 0; j < nw; ++j) {
+        QIL_REQUIRE(Ws[j], QIL_EINVAL_ARG, "apply_coefficient_sweep: null operator %lld", (long long)j);
+        qil_mps* prod = nullptr;
+        QIL_TRY(qil_apply(Ws[j], psi, &prod));
+        int st = coefficient_enqueue(prod, nb, dbits, static_cast<char*>(dout) + (size_t)(j * nb) * 16);
+        qil_mps_destroy(prod);
+        QIL_TRY(st);
+    }
+    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)(nw * nb) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
     qil_ctx_free(ctx, dout);
     qil_ctx_free(ctx, dbits);
     return QIL_OK;

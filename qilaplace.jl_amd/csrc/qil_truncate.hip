@@ -117,6 +117,31 @@ static int gauge_qr_site_left(qil_chain* psi, int64_t i, int64_t pd) {
     return QIL_OK;
 }
 
+// One step of the right-to-left gauge sweep (mps.jl:822-837): site i becomes a right isometry (rows alpha | cols
+// (phys, beta)), its left factor is multiplied into site i-1.  gauge_qr: exact thin QR where the site is wide enough,
+// truncated SVD otherwise (and always when gauge_qr is off).
+static int gauge_site_left(qil_chain* psi, int64_t i, double cutoff, int64_t maxdim, bool gauge_qr) {
+    const int64_t pd = psi->phys_rank == 1 ? 2 : 4;
+    qil_context* ctx = psi->ctx;
+    const int dt = psi->dtype;
+    const size_t e = qil_elem_size(dt);
+    const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
+    const int64_t cl0 = psi->dims[(size_t)i - 1];
+    if (gauge_qr && pd * cr >= cl) return gauge_qr_site_left(psi, i, pd);
+    int64_t r = 0;
+    void *US = nullptr, *Vh = nullptr;
+    // rows alpha | cols (s, beta)
+    QIL_TRY(svd_trunc_dev(ctx, dt, cl, pd * cr, psi->site[(size_t)i], cl, cutoff, true, maxdim, 1, 1, &r, &US, &Vh,
+                          nullptr));
+    void* prev = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl0 * pd * r) * e, &prev));
+    QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, pd * cl0, r, cl, psi->site[(size_t)i - 1], pd * cl0, US, cl, prev, pd * cl0));
+    qil_ctx_free(ctx, US);
+    QIL_TRY(qil_chain_set_site(psi, i, Vh, r, cr));
+    QIL_TRY(qil_chain_set_site(psi, i - 1, prev, cl0, r));
+    return QIL_OK;
+}
+
 int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cutoff, int64_t maxdim,
                       bool gauge_qr = false) {
     const int64_t pd = psi->phys_rank == 1 ? 2 : 4;
@@ -149,26 +174,7 @@ int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cuto
     } else if (direction == QIL_DIR_LEFT) {
         const int64_t c = center == 0 ? 1 : center;
         QIL_REQUIRE(c >= 1 && c <= N, QIL_EDOMAIN, "Center out of range [1,%lld]", (long long)N);
-        for (int64_t i = N - 1; i >= c; --i) {  // mps.jl:822-837
-            const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
-            const int64_t cl0 = psi->dims[(size_t)i - 1];
-            if (gauge_qr && pd * cr >= cl) {
-                QIL_TRY(gauge_qr_site_left(psi, i, pd));
-                continue;
-            }
-            int64_t r = 0;
-            void *US = nullptr, *Vh = nullptr;
-            // rows alpha | cols (s, beta)
-            QIL_TRY(svd_trunc_dev(ctx, dt, cl, pd * cr, psi->site[(size_t)i], cl, cutoff, true, maxdim, 1, 1, &r,
-                                  &US, &Vh, nullptr));
-            void* prev = nullptr;
-            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cl0 * pd * r) * e, &prev));
-            QIL_TRY(qil_dev_gemm(ctx, dt, 0, 0, pd * cl0, r, cl, psi->site[(size_t)i - 1], pd * cl0, US, cl, prev,
-                                 pd * cl0));
-            qil_ctx_free(ctx, US);
-            QIL_TRY(qil_chain_set_site(psi, i, Vh, r, cr));
-            QIL_TRY(qil_chain_set_site(psi, i - 1, prev, cl0, r));
-        }
+        for (int64_t i = N - 1; i >= c; --i) QIL_TRY(gauge_site_left(psi, i, cutoff, maxdim, gauge_qr));  // mps.jl:822-837
     } else {
         return qil_fail(QIL_EINVAL_ARG, "Direction must be :right or :left");
     }
@@ -540,6 +546,36 @@ int zip_theta(qil_context* ctx, const void* Rm, const void* W, const void* A, in
     return QIL_OK;
 }
 
+// Z[(alpha, a), (s, r')] = sum_{s', b} Y[alpha, s', b, r'] W[a, s', s, b]     (right environment of the fit sweep)
+//   Y index (alpha + cl s') + 2 cl (b + Dr r'),  W index a + Dl (s' + 2 (s + 2 b)),  Z index (alpha + cl a) + cl Dl (s + 2 r')
+template <class T>
+__global__ void fit_env_stage(const T* __restrict__ Y, const T* __restrict__ W, T* __restrict__ Z, int cl, int Dl,
+                              int Dr, int rp) {
+    const long long total = (long long)cl * Dl * 2 * rp;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        long long u = t;
+        const int alpha = (int)(u % cl);
+        u /= cl;
+        const int a = (int)(u % Dl);
+        u /= Dl;
+        const int s_ = (int)(u & 1);
+        const int r = (int)(u >> 1);
+        T acc{};
+        for (int sp = 0; sp < 2; ++sp) {
+            const T* yp = Y + (alpha + (long long)cl * sp) + 2LL * cl * Dr * r;        // + 2 cl b
+            const T* wp = W + a + (long long)Dl * (sp + 2 * s_);                       // + 4 Dl b
+            for (int b = 0; b < Dr; ++b) acc = zadd(acc, zmul(yp[2LL * cl * b], wp[4LL * Dl * b]));
+        }
+        Z[t] = acc;
+    }
+}
+
+__global__ void widen_f64(const double* __restrict__ in, c64* __restrict__ out, long long n) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+        out[t] = c64{in[t], 0.0};
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- exported
@@ -555,14 +591,23 @@ extern "C" int qil_canonicalize(qil_mps* psi, int direction, int64_t center, dou
 
 extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps);
 
-// Fused apply-and-truncate ("zip-up"): compress!(apply(W, psi); maxdim, tol, sweeps) WITHOUT
-// ever writing the (D chi)^2 product tensors.  psi is brought to right-canonical gauge (a copy), then one
-// left-to-right sweep carries a remainder R[r, alpha, a] and per site forms only
-//     theta[(r, s), (beta, b)] = sum R[r, alpha, a] W[a, s', s, b] A[alpha, s', beta]      (2 r x D chi)
-// whose truncated SVD gives the output site (U) and the next remainder (S V^h).  The intermediate bond cap
-// zip_maxdim (default 2 maxdim) and a 100x tighter cutoff leave head-room for the final, exact-gauge
-// compress! (src/mps.jl:913-973) that fixes the reference's post-conditions (bonds <= maxdim, unit norm in
-// the tensors, norm moved into `amplitude`).  Cost O(n r D chi (D + chi)) instead of O(n (D chi)^2 ...).
+// Fused apply-and-truncate: compress!(apply(W, psi); maxdim, tol, sweeps) WITHOUT ever writing the
+// (D chi)^2 product tensors.
+//   1. zip-up: psi is brought to right-canonical gauge (a copy); one left-to-right sweep carries the left
+//      environment L[r, alpha, a] = <phi_{<i} | W psi_{<i}> and per site forms only
+//          theta[(r, s), (beta, b)] = sum L[r, alpha, a] W[a, s', s, b] A[alpha, s', beta]      (2 r x D chi)
+//      whose truncated SVD (cap zip_maxdim = 2 maxdim, 100x tighter cutoff) gives the site phi_i (U) and the next
+//      environment (S V^h).  Its truncations see only psi's gauge, not the operator's right part: on flat-spectrum
+//      operands they discard weight the exact route keeps (1e-2 in 5 of 24 random products).
+//   2. one variational sweep right to left repairs that: with the left environments of step 1 and right environments
+//      R[(beta, b), r'] = <phi_{>i} | W psi_{>i}> built on the way, every site is replaced by the best tensor given the
+//      others,  phi_i = L_i A_i W_i R_i  (two small contraction kernels + one GEMM), and re-gauged by a thin QR.  No SVD,
+//      nothing of size (D chi)^2.  After it the state agrees with compress!(apply(W, psi)) of the CPU oracle to rounding on
+//      22 of the 24 random products and within the truncation's own error on the other two (numpy prototype and
+//      tests/test_gpu_parity.py::test_apply_compress_random_products_against_oracle).
+//   3. the exact-gauge compress! (src/mps.jl:913-973) fixes the reference's post-conditions (bonds <= maxdim by the
+//      ITensors rule, unit norm in the tensors, norm moved into `amplitude`).
+// Cost O(n r D chi (D + chi + r)) instead of O(n (D chi)^3).
 extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
                                   int64_t zip_maxdim, qil_mps** out) {
     QIL_REQUIRE(W && psi && out, QIL_EINVAL_ARG, "apply_compress: null argument");
@@ -588,12 +633,80 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
     // right-canonical copy of psi: the zip's truncations then see (nearly) orthonormal environments
     qil_mps* phi = nullptr;
     QIL_TRY(qil_mps_clone(psi, &phi));
-    int st = canonicalize_impl(phi, QIL_DIR_LEFT, 0, 1e-14, kNoCap);
-    if (st != QIL_OK) {
-        qil_mps_destroy(phi);
-        return st;
+    qil_mps* res = nullptr;
+    std::vector<void*> tmp;                          // every pool block this call owns outside a handle
+    std::vector<void*> Asite((size_t)N), Wsite((size_t)N), Lenv((size_t)N, nullptr);
+    std::vector<int> Rdim((size_t)N + 1, 1);
+    auto cleanup = [&](int code) {
+        for (void* p : tmp) qil_ctx_free(ctx, p);
+        if (phi) qil_mps_destroy(phi);
+        if (code != QIL_OK && res) qil_mps_destroy(res);
+        return code;
+    };
+    auto take = [&](size_t bytes, void** p) {
+        int s = qil_ctx_alloc(ctx, bytes, p);
+        if (s == QIL_OK) tmp.push_back(*p);
+        return s;
+    };
+    auto drop = [&](void* p) {
+        for (size_t t = tmp.size(); t-- > 0;)
+            if (tmp[t] == p) {
+                tmp.erase(tmp.begin() + (long)t);
+                break;
+            }
+        qil_ctx_free(ctx, p);
+    };
+    auto forget = [&](void* p) {                     // ownership moved into a handle
+        for (size_t t = tmp.size(); t-- > 0;)
+            if (tmp[t] == p) {
+                tmp.erase(tmp.begin() + (long)t);
+                break;
+            }
+    };
+    int st = canonicalize_impl(phi, QIL_DIR_LEFT, 0, 0.0, kNoCap, true);      // exact thin-QR gauge: psi loses nothing
+    if (st != QIL_OK) return cleanup(st);
+    // operands in the output dtype (a real operand of a complex product is widened once: KB..MB)
+    for (int64_t i = 0; i < N && st == QIL_OK; ++i) {
+        Asite[(size_t)i] = phi->site[(size_t)i];
+        Wsite[(size_t)i] = W->site[(size_t)i];
+        if (odt == QIL_C64 && !ac) {
+            const long long ne = phi->site_elems(i);
+            void* p = nullptr;
+            if ((st = take((size_t)ne * e, &p)) != QIL_OK) break;
+            hipLaunchKernelGGL(widen_f64, dim3(nblk(ne)), dim3(256), 0, ctx->stream, (const double*)phi->site[(size_t)i],
+                               (c64*)p, ne);
+            Asite[(size_t)i] = p;
+        }
+        if (odt == QIL_C64 && !wc) {
+            const long long ne = W->site_elems(i);
+            void* p = nullptr;
+            if ((st = take((size_t)ne * e, &p)) != QIL_OK) break;
+            hipLaunchKernelGGL(widen_f64, dim3(nblk(ne)), dim3(256), 0, ctx->stream, (const double*)W->site[(size_t)i],
+                               (c64*)p, ne);
+            Wsite[(size_t)i] = p;
+        }
     }
-    qil_mps* res = new qil_mps();
+    if (st != QIL_OK) return cleanup(st);
+    auto theta_of = [&](int64_t i, void** theta) {
+        const int Dl = (int)W->dims[(size_t)i], Dr = (int)W->dims[(size_t)i + 1];
+        const int cl = (int)phi->dims[(size_t)i], cr = (int)phi->dims[(size_t)i + 1];
+        int s2 = odt == QIL_F64
+                     ? zip_theta<double, double, double>(ctx, Lenv[(size_t)i], Wsite[(size_t)i], Asite[(size_t)i],
+                                                         Rdim[(size_t)i], Dl, Dr, cl, cr, theta)
+                     : zip_theta<c64, c64, c64>(ctx, Lenv[(size_t)i], Wsite[(size_t)i], Asite[(size_t)i], Rdim[(size_t)i], Dl,
+                                                Dr, cl, cr, theta);
+        if (s2 == QIL_OK) tmp.push_back(*theta);
+        return s2;
+    };
+    auto one = [&](void** p) {                       // 1 x 1 environment
+        int s2 = take(e, p);
+        const double v[2] = {1.0, 0.0};
+        if (s2 == QIL_OK && hipMemcpyAsync(*p, v, e, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            s2 = qil_fail(QIL_EHIP, "apply_compress: upload failed");
+        if (s2 == QIL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s2 = qil_fail(QIL_EHIP, "sync failed");
+        return s2;
+    };
+    res = new qil_mps();
     qil_chain_bind(res, ctx);
     res->dtype = odt;
     res->paired = psi->paired;
@@ -602,26 +715,15 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
     res->site.assign((size_t)N, nullptr);
     res->site_ids = psi->site_ids;
     res->amplitude = psi->amplitude;
-    void* Rm = nullptr;
-    st = qil_ctx_alloc(ctx, e, &Rm);
-    const double one[2] = {1.0, 0.0};
-    if (st == QIL_OK && hipMemcpyAsync(Rm, one, e, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        st = qil_fail(QIL_EHIP, "apply_compress: upload failed");
-    if (st == QIL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = qil_fail(QIL_EHIP, "sync failed");
-    int R = 1;
-    for (int64_t i = 0; i < N && st == QIL_OK; ++i) {
-        const int Dl = (int)W->dims[(size_t)i], Dr = (int)W->dims[(size_t)i + 1];
-        const int cl = (int)phi->dims[(size_t)i], cr = (int)phi->dims[(size_t)i + 1];
+    // ---- 1. zip-up, keeping the left environments
+    if ((st = one(&Lenv[0])) != QIL_OK) return cleanup(st);
+    for (int64_t i = 0; i < N; ++i) {
+        const int Dr = (int)W->dims[(size_t)i + 1], cr = (int)phi->dims[(size_t)i + 1];
+        const int R = Rdim[(size_t)i];
         void* theta = nullptr;
-        const void *Wp = W->site[(size_t)i], *Ap = phi->site[(size_t)i];
-        if (odt == QIL_F64) st = zip_theta<double, double, double>(ctx, Rm, Wp, Ap, R, Dl, Dr, cl, cr, &theta);
-        else if (wc && ac) st = zip_theta<c64, c64, c64>(ctx, Rm, Wp, Ap, R, Dl, Dr, cl, cr, &theta);
-        else if (wc) st = zip_theta<c64, c64, double>(ctx, Rm, Wp, Ap, R, Dl, Dr, cl, cr, &theta);
-        else st = zip_theta<c64, double, c64>(ctx, Rm, Wp, Ap, R, Dl, Dr, cl, cr, &theta);
-        if (st != QIL_OK) break;
-        qil_ctx_free(ctx, Rm);
-        Rm = nullptr;
+        if ((st = theta_of(i, &theta)) != QIL_OK) return cleanup(st);
         if (i + 1 == N) {                       // last site: theta is (R, 2, 1)
+            forget(theta);
             qil_chain_adopt(res, i, theta);
             res->dims[(size_t)i] = R;
             break;
@@ -630,17 +732,62 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
         void *U = nullptr, *SV = nullptr;
         st = svd_trunc_dev(ctx, odt, 2LL * R, (int64_t)cr * Dr, theta, 2LL * R, zip_cutoff, true, zip_maxdim, 1, 2, &r, &U,
                            &SV, nullptr);
-        qil_ctx_free(ctx, theta);
-        if (st != QIL_OK) break;
+        if (st != QIL_OK) return cleanup(st);
+        drop(theta);
         qil_chain_adopt(res, i, U);             // [R, s, r]
         res->dims[(size_t)i] = R;
         res->dims[(size_t)i + 1] = r;
-        Rm = SV;                                // [r, (beta, b)] == R[r, alpha, a] of the next site
-        R = (int)r;
+        tmp.push_back(SV);
+        Lenv[(size_t)i + 1] = SV;               // [r, (beta, b)] == L[r, alpha, a] of the next site
+        Rdim[(size_t)i + 1] = (int)r;
     }
-    if (Rm) qil_ctx_free(ctx, Rm);
-    qil_mps_destroy(phi);
-    if (st == QIL_OK) st = qil_compress(res, maxdim, tol, sweeps);
+    // ---- 2. variational sweep right to left
+    void* Renv = nullptr;                       // [(beta, b), r']
+    int rp = 1;
+    if ((st = one(&Renv)) != QIL_OK) return cleanup(st);
+    for (int64_t i = N - 1; i >= 0; --i) {
+        const int Dl = (int)W->dims[(size_t)i], Dr = (int)W->dims[(size_t)i + 1];
+        const int cl = (int)phi->dims[(size_t)i], cr = (int)phi->dims[(size_t)i + 1];
+        const int R = Rdim[(size_t)i];
+        void *theta = nullptr, *T = nullptr;
+        if ((st = theta_of(i, &theta)) != QIL_OK) return cleanup(st);
+        if ((st = take((size_t)2 * R * rp * e, &T)) != QIL_OK) return cleanup(st);
+        st = qil_dev_gemm(ctx, odt, 0, 0, 2LL * R, rp, (int64_t)cr * Dr, theta, 2LL * R, Renv, (int64_t)cr * Dr, T, 2LL * R);
+        if (st != QIL_OK) return cleanup(st);
+        drop(theta);
+        forget(T);
+        if ((st = qil_chain_set_site(res, i, T, R, rp)) != QIL_OK) return cleanup(st);
+        if (i == 0) break;
+        if ((st = gauge_site_left(res, i, 0.0, kNoCap, true)) != QIL_OK) return cleanup(st);
+        const int K = (int)res->dims[(size_t)i];
+        void *Y = nullptr, *Z = nullptr, *Rn = nullptr;
+        if ((st = take((size_t)2 * cl * Dr * rp * e, &Y)) != QIL_OK) return cleanup(st);
+        st = qil_dev_gemm(ctx, odt, 0, 0, 2LL * cl, (int64_t)Dr * rp, cr, Asite[(size_t)i], 2LL * cl, Renv, cr, Y, 2LL * cl);
+        if (st != QIL_OK) return cleanup(st);
+        if ((st = take((size_t)cl * Dl * 2 * rp * e, &Z)) != QIL_OK) return cleanup(st);
+        if (odt == QIL_F64)
+            hipLaunchKernelGGL(fit_env_stage<double>, dim3(nblk((long long)cl * Dl * 2 * rp)), dim3(256), 0, ctx->stream,
+                               (const double*)Y, (const double*)Wsite[(size_t)i], (double*)Z, cl, Dl, Dr, rp);
+        else
+            hipLaunchKernelGGL(fit_env_stage<c64>, dim3(nblk((long long)cl * Dl * 2 * rp)), dim3(256), 0, ctx->stream,
+                               (const c64*)Y, (const c64*)Wsite[(size_t)i], (c64*)Z, cl, Dl, Dr, rp);
+        if (hipGetLastError() != hipSuccess) return cleanup(qil_fail(QIL_EHIP, "apply_compress: launch failed"));
+        if ((st = take((size_t)cl * Dl * K * e, &Rn)) != QIL_OK) return cleanup(st);
+        // R_{i-1}[(alpha, a), k] = sum_{s, r'} Z[(alpha, a), (s, r')] conj(phi_i[k, (s, r')])
+        st = qil_dev_gemm(ctx, odt, 0, 2, (int64_t)cl * Dl, K, 2LL * rp, Z, (int64_t)cl * Dl, res->site[(size_t)i], K, Rn,
+                          (int64_t)cl * Dl);
+        if (st != QIL_OK) return cleanup(st);
+        drop(Y);
+        drop(Z);
+        drop(Renv);
+        Renv = Rn;
+        rp = K;
+    }
+    (void)cleanup(QIL_OK);
+    phi = nullptr;
+    tmp.clear();
+    // ---- 3. exact-gauge truncation
+    st = qil_compress(res, maxdim, tol, sweeps);
     if (st != QIL_OK) {
         qil_mps_destroy(res);
         return st;

@@ -204,6 +204,23 @@ def apply_coefficient_batch(W, psi, bits):
     return out.real.copy()
 
 
+def apply_coefficient_sweep(Ws, psi, bits):
+    """For every operator of `Ws` (e.g. the DT MPOs of a damping sweep): materialise W * psi with the apply kernel
+    and read it out at the same configurations -- the loop `out = W * psi; coefficient(out, bits)` of the
+    reference's sweeps (docs/src/tutorials/dt.jl:150-197) with one upload, one download and one synchronisation
+    for the whole batch.  Returns a (len(Ws), nb) complex array."""
+    Ws = list(Ws)
+    b = _bits_array(psi, bits)
+    nb = b.shape[0]
+    out = np.zeros((len(Ws), nb), dtype=np.complex128)
+    if not Ws or nb == 0:
+        return out
+    hs = (C.c_void_p * len(Ws))(*[W.handle for W in Ws])
+    L.check(L.lib.qil_apply_coefficient_sweep(hs, len(Ws), psi.handle, nb, b.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                              out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
 # ---------------------------------------------------------------- dense read-out, norm
 def mps_to_vector(psi, reverse=False):
     n = _ntensors(psi)

@@ -56,22 +56,35 @@ def sweep(items, work_fn, width: int, dist=None, device=None):
     return gather_results(local, len(items), width, dist if world > 1 else None, device)
 
 
-def damping_sweep(psi, sigmas, build_mpo, bits, dist=None, device=None):
+def damping_sweep(psi, sigmas, bits, build_mpo=None, dist=None, device=None, cutoff=1e-14, maxdim=1000):
     """BASELINE.json configs[3]: one paired-register signal x many damping values.
 
     psi        device ZTMPS (replicated on every rank; it is MBs)
-    sigmas     sequence of omega_r values
-    build_mpo  callable sigma -> list of numpy MPO site tensors W[a, s_in, s_out, b] (2n of them);
-               the transform builders are host-side producers
+    sigmas     sequence of omega_r values, dealt round-robin to the ranks
     bits       (nb, 2n) sampled configurations
+    build_mpo  None (default): this rank's share of the DT MPOs is built in ONE launch of the persistent device
+               builder (`build_dt_mpo_batch`, one workgroup per damping value) and applied / sampled by
+               `apply_coefficient_sweep` (one synchronisation for the whole share).  A callable
+               sigma -> list of numpy site tensors W[a, s_in, s_out, b] takes the per-value host route instead
+               (any other operator family).
     Returns (len(sigmas), nb) coefficients of W(sigma) * psi, in sigma order, on every rank."""
     from .containers import PairedSiteMPO
-    from .ops import apply, coefficient_batch
+    from .ops import apply, coefficient_batch, apply_coefficient_sweep
     bits = np.asarray(bits)
+    sigmas = list(sigmas)
+    if build_mpo is not None:
+        def work(sig):
+            W = PairedSiteMPO(build_mpo(sig), sites=psi.site_ids, ctx=psi.ctx)
+            return coefficient_batch(apply(W, psi), bits)
 
-    def work(sig):
-        W = PairedSiteMPO(build_mpo(sig), ctx=psi.ctx)
-        out = apply(W, psi)
-        return coefficient_batch(out, bits)
-
-    return sweep(list(sigmas), work, bits.shape[0], dist, device)
+        return sweep(sigmas, work, bits.shape[0], dist, device)
+    from .builders import build_dt_mpo_batch
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    mine = shard_items(len(sigmas), world, rank)
+    local = {}
+    if mine:
+        Ws = build_dt_mpo_batch(psi, [sigmas[i] for i in mine], cutoff, maxdim, psi.ctx)
+        res = apply_coefficient_sweep(Ws, psi, bits)
+        local = {i: res[k] for k, i in enumerate(mine)}
+    return gather_results(local, len(sigmas), bits.shape[0], dist if world > 1 else None, device)
