@@ -552,6 +552,111 @@ def test_config2_n20_chi32_D64_qft_vs_fft(qil):
     assert np.abs(full - F).max() < 1e-9 * np.abs(F).max()
 
 
+def _zt_closed_form(terms, n, wr, kk, ll):
+    """chi(k, l) = (1/N) sum_j x_j exp(-(wr k + 2 pi i l) j / N)  (test/test_zt_transformer.jl:20-39) for a signal given
+    as a sum of exponentials x_j = sum_m c_m exp(lam_m j / N): every term is a geometric series,
+    sum_{j<N} exp(z j / N) = expm1(z) / expm1(z / N)."""
+    N = 2.0 ** n
+    out = np.zeros(len(kk), dtype=np.complex128)
+    for c, lam in terms:
+        z = lam - wr * np.asarray(kk, dtype=np.float64) - 2j * np.pi * np.asarray(ll, dtype=np.float64)
+        den = np.expm1(z / N)
+        out += c * np.where(den == 0, N, np.expm1(z) / np.where(den == 0, 1.0, den))          # z = 0: N equal terms
+    return out / N
+
+
+def _structured_terms():
+    """x_j = sin(2 pi 5 j/N) exp(-3 j/N) + 0.5 cos(2 pi 11 j/N) as (coefficient, exponent) pairs."""
+    return [(0.5 / 1j, -3.0 + 2j * np.pi * 5.0), (-0.5 / 1j, -3.0 - 2j * np.pi * 5.0),
+            (0.25, 2j * np.pi * 11.0), (0.25, -2j * np.pi * 11.0)]
+
+
+def _kl_bits(n, kk, ll):
+    bits = np.zeros((len(kk), 2 * n), dtype=np.uint8)
+    for i in range(n):
+        bits[:, 2 * i] = (np.asarray(kk) >> i) & 1            # main_i <- bit i of k (lsb first)
+        bits[:, 2 * i + 1] = (np.asarray(ll) >> i) & 1        # copy_i <- bit i of l (lsb first)
+    return bits
+
+
+def test_config3_genuine_zt_mpo_embedded_to_chi128(qil):
+    """configs[2] with the GENUINE operator: build_zt_mpo(24, 2 pi) at its natural bonds (~89),
+    zero-embedded and gauge-mixed to the dense chi_c = 128 profile (the operator is exactly unchanged), applied to a
+    saturated chi_s = 64 paired-register state: the 80 GB materialised result at 256 random configurations against the
+    CPU oracle's lazy restatement on the NATURAL-bond operator (1e-9 relative)."""
+    n, L = 24, 48
+    rng = np.random.default_rng(20240128)
+    Wnat = qil.build_zt_mpo(n, 2 * np.pi)
+    wnat = Wnat.to_host()
+    cap = saturated_profile(L, 128, base=4)
+    assert all(d <= c for d, c in zip(Wnat.bond_dims, cap)), (Wnat.bond_dims, cap)
+    W = qil.PairedSiteMPO(_embed_and_gauge(wnat, cap, rng))
+    cb = saturated_profile(L, 64)
+    psi = qil.ZTMPS.alloc(cb, dtype=np.float64, amplitude=1.0).fill_random(20240064)
+    out = W * psi
+    assert out.bond_dims == [c * d for c, d in zip(cb, cap)] and out.dtype == np.complex128
+    bits = rng.integers(0, 2, size=(256, L)).astype(np.uint8)
+    got = qil.coefficient_batch(out, bits)
+    del out
+    ref = O.lazy_coefficient_batch(O.SingleSiteMPO(wnat), O.SignalMPS(psi.to_host(), amplitude=1.0), bits)
+    assert rel(got, ref) < 1e-9
+    assert rel(qil.apply_coefficient_batch(W, psi, bits), ref) < 1e-9
+
+
+def test_config3_natural_bond_signal_vs_analytical_zt(qil):
+    """The same n = 24 zT operator on a signal-derived ZTMPS at natural bonds: chi(k, l) of the materialised W * psi at
+    256 (k, l) points against the closed form (the reference's analytical_zt, test/test_zt_transformer.jl:20-39, whose
+    own bound is 2e-7 absolute at n <= 4, MPO-cutoff limited; here relative to the largest sampled |chi|)."""
+    n = 24
+    N = 2 ** n
+    j = np.arange(N, dtype=np.float64)
+    x = np.sin(2 * np.pi * 5.0 * j / N) * np.exp(-3.0 * j / N) + 0.5 * np.cos(2 * np.pi * 11.0 * j / N)
+    psi = qil.signal_ztmps(x, method="rsvd", k=24, p=5, q=2, cutoff=1e-13)
+    W = qil.build_zt_mpo(psi, 2 * np.pi)
+    out = W * psi
+    rng = np.random.default_rng(11)
+    kk, ll = rng.integers(0, 64, size=256), rng.integers(0, 32, size=256)
+    got = qil.coefficient_batch(out, _kl_bits(n, kk, ll))
+    ref = _zt_closed_form(_structured_terms(), n, 2 * np.pi, kk, ll)
+    assert np.abs(got - ref).max() < 2e-6 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    grid = qil.coefficient_grid(out, np.arange(8), np.arange(16))
+    gk, gl = np.meshgrid(np.arange(8), np.arange(16), indexing="ij")
+    gref = _zt_closed_form(_structured_terms(), n, 2 * np.pi, gk.ravel(), gl.ravel()).reshape(8, 16)
+    assert np.abs(grid - gref).max() < 2e-6 * np.abs(gref).max()
+
+
+def test_config5_n30_rsvd_encode_and_zt_apply(qil):
+    """configs[4] at full size: n = 30 paired-register signal produced IN HBM (8.6 GB, never on the host),
+    signal_ztmps(:rsvd, k=128, p=5, q=2), zT MPO at its natural bonds, lazy read-out of chi(k, l) (the saturated
+    materialised product would be 406 GB) and -- the structured signal's encoded bonds being small --
+    also the materialised apply; both against the closed form (<= 2e-7 absolute, the reference's zT bound)."""
+    torch = pytest.importorskip("torch")
+    n = 30
+    N = 2 ** n
+    dev = torch.device("cuda", qil.default_context().device)
+    jd = torch.arange(N, dtype=torch.float64, device=dev)
+    xd = torch.sin(2 * np.pi * 5.0 * jd / N) * torch.exp(-3.0 * jd / N) + 0.5 * torch.cos(2 * np.pi * 11.0 * jd / N)
+    del jd
+    torch.cuda.synchronize()
+    psi = qil.signal_ztmps(xd, method="rsvd", k=128, p=5, q=2, cutoff=1e-12, maxdim=128)
+    del xd
+    torch.cuda.empty_cache()
+    assert isinstance(psi, qil.ZTMPS) and len(psi) == n and max(psi.bond_dims) <= 133
+    W = qil.build_zt_mpo_batch(psi, [2 * np.pi], cutoff=1e-14)[0]
+    rng = np.random.default_rng(5)
+    kk, ll = rng.integers(0, 64, size=64), rng.integers(0, 32, size=64)
+    bits = _kl_bits(n, kk, ll)
+    ref = _zt_closed_form(_structured_terms(), n, 2 * np.pi, kk, ll)
+    lazy = qil.apply_coefficient_batch(W, psi, bits)
+    # measured 3.9e-8 absolute = 2.2e-6 of the largest sampled |chi| (MPO cutoff 1e-14 over 60 tensors); the reference's
+    # own bound for the zT transform is 2e-7 absolute (test/test_zt_transformer.jl:106)
+    assert np.abs(lazy - ref).max() < 2e-7 and np.abs(lazy - ref).max() < 5e-6 * np.abs(ref).max()
+    out = W * psi
+    assert out.bond_dims == [c * d for c, d in zip(psi.bond_dims, W.bond_dims)]
+    mat = qil.coefficient_batch(out, bits)
+    assert np.abs(mat - lazy).max() < 1e-12 * np.abs(mat).max()
+
+
 def test_config3_n24_chi64_D128_full_size_vs_cpu_oracle(qil):
     """configs[2] at full size (48 sites, 80 GB result): sampled coefficients of the materialised
     HIP result vs the CPU oracle's lazy restatement on the same (W, psi); and homogeneity
