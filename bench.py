@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- MPO x MPS site-contractions/sec on MI355X (BASELINE.json metric).
 
-A "step" is one `apply(W, psi)` over one synthetic n-qubit paired-register signal: 48 site
-contractions at the metric configuration (n=24 zT layout, chi_s=64, chi_c=128, complex128 output,
-80.06 GB written per step).  Inputs are resident in HBM before the timed
-region; the output is a fresh device MPS each step (caching pool).  With --gpus N > 1 every rank
-applies the operator to its OWN independent signal (weak scaling, no data-path collective); RCCL
-is used only for the barrier, the max-over-ranks time and the final gather of the coefficient
-samples.
+Default workload (`zt_n24_chi64_D128`, the configuration the metric is quoted on): a "step" is one
+`apply(W, psi)` over one synthetic n-qubit paired-register signal: 48 site contractions, chi_s=64,
+chi_c=128, complex128 output, 80.06 GB written per step.  Inputs are resident in HBM
+before the timed region; the output is a fresh device MPS each step (caching pool).  With --gpus N > 1
+every rank applies the operator to its OWN independent signal (weak scaling, no data-path collective);
+RCCL is used only for the barrier, the max-over-ranks time and the final gather of the coefficient samples.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = site_apply_grouped, HBM-store
-bound; algorithmic bytes / live HIP-event kernel time) and `cpu_baseline` (the numpy oracle timed
-on this box's host cores on a bounded sample of the same workload).
+`--workload dt_sweep_n24_s64` (BASELINE.json configs[3]): a step is one whole damping sweep -- 64 DT MPOs built
+by the persistent device builder, applied to one encoded n=24 signal and sampled at 1024 configurations each --
+with the 64 values dealt round-robin to the ranks (strong scaling) and one RCCL all_gather of the samples.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (before anything touches the GPU).
+
+Prints ONE JSON line (rank 0) with
+  roofline      dominant kernel = site_apply_grouped (HBM-store bound): algorithmic bytes / live HIP-event time
+  truncate      the other half of "apply-and-truncate": the fused apply_compress and the exact compress!(apply)
+                on the zT product of an encoded n=24 signal (chi 15 x D ~89, 48 sites, maxdim 64), with an MFMA
+                flop model against the f64 matrix peak
+  cpu_baseline  the C++/OpenMP CPU backend behind the same C ABI (oracle/cpu, all cores and one thread) and the
+                numpy port of the oracle, timed on this box's host cores on the same workload
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +37,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
+F64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4: 2048 flop / 64 cycles / SIMD, 1024 SIMDs, 2.4 GHz
 
 WORKLOADS = {
     # name: (sites L, paired, chi cap, D cap, description)
@@ -36,6 +47,8 @@ WORKLOADS = {
     "qft_n24_chi64_D128": (24, False, 64, 128, "n=24 single register apply, chi_s=64, chi_c=128"),
     "qft_n20_chi32_D64": (20, False, 32, 64, "n=20 single register apply, chi_s=32, chi_c=64 (configs[1])"),
     "tiny": (12, False, 16, 32, "debug size"),
+    "dt_sweep_n24_s64": (48, True, 0, 0, "n=24 signal x 64 damping values: build_dt_mpo sweep, apply, 1024 samples each "
+                                        "(configs[3]); values dealt round-robin to the ranks"),
 }
 
 
@@ -47,8 +60,8 @@ def profiles(L, chi, D):
 
 def algorithmic_bytes(cb, db, w_bytes=16, a_bytes=8, o_bytes=16):
     """per site  out*(Dl chil)*2*(Dr chir) [write B once] + W + A read once."""
-    c = [1] + cb + [1]
-    d = [1] + db + [1]
+    c = [1] + list(cb) + [1]
+    d = [1] + list(db) + [1]
     tot = 0
     for i in range(len(c) - 1):
         tot += o_bytes * (d[i] * c[i]) * 2 * (d[i + 1] * c[i + 1])
@@ -56,20 +69,35 @@ def algorithmic_bytes(cb, db, w_bytes=16, a_bytes=8, o_bytes=16):
     return tot
 
 
-def cpu_baseline(qil, W, psi, cb, db, L, budget_s=30.0):
-    """Time the numpy oracle (`oracle.apply_site`, the reference's K=2 GEMM + permute formulation,
-    apply.jl:101,114,118) on this box's host cores.  Pass 1 times every distinct site shape once to
-    estimate the whole apply; if the estimate fits the budget (about 10-30 s of CPU work) the oracle
-    then applies ALL sites and that wall time is the baseline; otherwise the per-shape times are
-    summed over the sites (stated in `sample`)."""
-    import oracle as O
+def lib_sha16():
+    import qilaplace_jl_amd as qil
+    with open(qil.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of THIS round
+    (profiles/r02_pmc_traffic.json, written by tools/collect_pmc.py from separate WRITE_SIZE / FETCH_SIZE passes
+    with the guide's unit and gfx950 corrections).  Only reported when the counters were collected with the
+    library binary that is running now (sha recorded next to them); otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        rec = json.load(open(path))
+        if rec.get("lib_sha16") != lib_sha16():
+            return None, f"{os.path.basename(path)} was collected with another build of libqilhip.so"
+        return rec.get(workload), os.path.basename(path)
     except Exception:
-        threads = os.cpu_count() or 1
-    c = [1] + cb + [1]
-    d = [1] + db + [1]
+        return None, None
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def numpy_port_time(W, psi, cb, db, L, budget_s=20.0):
+    """The numpy oracle (`oracle.apply_site`, the reference's K=2 GEMM + permute formulation, apply.jl:101,114,118):
+    every distinct site shape timed once, summed over the sites (shapes whose result exceeds 8 GB scaled from the
+    largest timed one)."""
+    import oracle as O
+    c = [1] + list(cb) + [1]
+    d = [1] + list(db) + [1]
     shapes = {}
     for i in range(L):
         shapes.setdefault((d[i], d[i + 1], c[i], c[i + 1]), []).append(i)
@@ -87,25 +115,111 @@ def cpu_baseline(qil, W, psi, cb, db, L, budget_s=30.0):
         t_shape[shp] = dt
         spent += dt
     big = max(t_shape, key=size)
-    est = sum(t_shape.get(s, t_shape[big] * size(s) / size(big)) * len(idx) for s, idx in shapes.items())
-    if len(t_shape) == len(shapes) and est <= budget_s:
-        Wh, Ah = W.to_host(), psi.to_host()
-        t0 = time.perf_counter()
-        for Wi, Ai in zip(Wh, Ah):
-            B = O.apply_site(Wi, Ai)
-            del B
-        total = time.perf_counter() - t0
-        sample = (f"oracle.apply_site (numpy K=2 GEMM + permute) over ALL {L} sites of the same workload, "
-                  f"one pass, {total:.1f} s wall")
-    else:
-        total = est
-        sample = (f"oracle.apply_site timed once per distinct site shape ({len(t_shape)} of {len(shapes)} shapes, "
-                  f"{spent:.1f} s of CPU work); full-apply time = sum over the {L} sites of their shape's time "
-                  f"({total:.1f} s estimated)")
-    return {"value": L / total, "unit": "site-contractions/s", "cores": int(threads), "kind": "port",
-            "sample": sample}
+    total = sum(t_shape.get(s, t_shape[big] * size(s) / size(big)) * len(idx) for s, idx in shapes.items())
+    return total, len(t_shape), len(shapes), spent
 
 
+def cpu_baseline(W, psi, cb, db, L):
+    """SURVEY.md 8d "CPU baseline beside it": (1) the C++/OpenMP backend behind the same C ABI (oracle/cpu/libqilcpu.so):
+    one apply over ALL sites of the same (W, psi), all cores and one thread; (2) the numpy port of the oracle."""
+    import subprocess
+    from oracle.cpu_backend import CpuBackend
+    lib = os.path.join(ROOT, "oracle", "cpu", "lib", "libqilcpu.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "cpu")], check=True, stdout=subprocess.DEVNULL)
+    cpu = CpuBackend(lib)
+    Wh, Ah = W.to_host(), psi.to_host()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # `nproc` of a container can exceed the cores it really gets: the team size is the fastest of these on the largest site
+    teams = sorted({t for t in (avail, avail // 2, avail // 4, 64, 32, 16, 8, 4) if 1 <= t <= avail}, reverse=True)
+    t_all, cores, nbytes = cpu.time_apply(Wh, Ah, teams, reps=2)
+    t_one, _, _ = cpu.time_apply(Wh, Ah, 1, reps=1)
+    t_np, ns, nshapes, spent = numpy_port_time(W, psi, cb, db, L)
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    return {
+        "value": L / t_all, "unit": "site-contractions/s", "cores": int(cores), "kind": "port",
+        "sample": (f"C++/OpenMP backend behind the same C ABI (oracle/cpu/libqilcpu.so): one apply over ALL {L} sites of the "
+                   f"same (W, psi), every site written into one reusable buffer of the largest site's size, mean of 2 passes "
+                   f"after a dry run: {t_all:.2f} s = {nbytes / t_all / 1e9:.1f} GB/s of output on {cores} threads, the fastest team "
+                   f"size of {teams} on the largest site (nproc = {os.cpu_count()}, affinity = {avail})"),
+        "gb_per_s": nbytes / t_all / 1e9,
+        "single_thread": {"value": L / t_one, "seconds_per_apply": t_one, "gb_per_s": nbytes / t_one / 1e9, "cores": 1},
+        "numpy_port": {"value": L / t_np, "seconds_per_apply": t_np, "cores": int(blas_threads),
+                       "sample": f"oracle.apply_site (numpy K=2 GEMM + permute) timed once per distinct site shape "
+                                 f"({ns} of {nshapes} shapes, {spent:.1f} s of CPU work), summed over the {L} sites"},
+    }
+
+
+# ---------------------------------------------------------------------------------------------- truncate block
+def svd_flops(m, n):
+    """Golub-Van Loan count of a thin SVD with both factors (6 m n^2 + 20 n^3, n = short side)."""
+    n, m = min(m, n), max(m, n)
+    return 6.0 * m * n * n + 20.0 * n ** 3
+
+
+def truncate_block(qil, ctx, reps=3):
+    """The 'truncate' of apply-and-truncate on the pipeline's own operands (cfg4-shaped): n=24 structured signal
+    encoded to chi ~15, genuine zT MPO (D ~89), product bond ~1335, truncated to maxdim 64 at tol 1e-8."""
+    n, N = 24, 2 ** 24
+    j = np.arange(N, dtype=np.float64)
+    x = np.sin(2 * np.pi * 5.0 * j / N) * np.exp(-3.0 * j / N) + 0.5 * np.cos(2 * np.pi * 11.0 * j / N)
+    rng = np.random.default_rng(1001)
+    x = x + sum(0.1 * rng.random() * np.sin(40.0 * (rng.random() - 0.5) * j / N) for _ in range(6))
+    psi = qil.signal_ztmps(x, method="rsvd", k=15, p=5, q=2, cutoff=1e-12)
+    W = qil.build_zt_mpo(psi, 2 * np.pi)
+    maxdim, tol = 64, 1e-8
+    fused = qil.apply_compress(W, psi, maxdim=maxdim, tol=tol)          # warm-up (pool, code objects)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fused = qil.apply_compress(W, psi, maxdim=maxdim, tol=tol)
+    ctx.synchronize()
+    t_fused = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    prod = W * psi
+    ctx.synchronize()
+    t_apply = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    qil.compress(prod, maxdim=maxdim, tol=tol)
+    ctx.synchronize()
+    t_exact = time.perf_counter() - t0
+    bits = np.random.default_rng(3).integers(0, 2, size=(256, 2 * n)).astype(np.uint8)
+    c_f, c_e = qil.coefficient_batch(fused, bits), qil.coefficient_batch(prod, bits)
+    c_x = qil.apply_coefficient_batch(W, psi, bits)
+    scale = np.abs(c_x).max()
+    P = [1] + [c * d for c, d in zip(psi.bond_dims, W.bond_dims)] + [1]
+    # flop models (stated, not measured): exact route = one gauge pass of truncated SVDs over the product sites
+    # (P_l x 2 P_r, the later passes run at <= maxdim); fused route = the zip-up's theta SVDs (2 r x D chi) with
+    # r <= 2 maxdim plus its contraction GEMMs
+    f_exact = sum(svd_flops(P[i], 2 * P[i + 1]) for i in range(1, len(P) - 1))
+    r = 2 * maxdim
+    f_fused = sum(svd_flops(2 * min(r, P[i]), P[i + 1]) + 2.0 * 2 * min(r, P[i]) * P[i + 1] * 2 * r
+                  for i in range(len(P) - 1))
+    return {
+        "op": "compress!(apply(W_zt, psi); maxdim=64, tol=1e-8), n=24 paired (48 sites), encoded signal x genuine zT MPO",
+        "mps_bonds_max": max(psi.bond_dims), "mpo_bonds_max": max(W.bond_dims), "product_bond_max": max(P),
+        "fused_apply_compress_ms": t_fused * 1e3, "exact_apply_ms": t_apply * 1e3, "exact_compress_ms": t_exact * 1e3,
+        "site_truncations_per_s_fused": 2 * n / t_fused, "site_truncations_per_s_exact": 2 * n / (t_apply + t_exact),
+        "bonds_fused_max": max(fused.bond_dims), "bonds_exact_max": max(prod.bond_dims),
+        "err_fused_vs_exact_product": float(np.abs(c_f - c_x).max() / scale),
+        "err_exact_route_vs_exact_product": float(np.abs(c_e - c_x).max() / scale),
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS,
+                     "achieved": f_exact / t_exact / 1e12, "frac": f_exact / t_exact / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                     "achieved_fused": f_fused / t_fused / 1e12,
+                     "model": "Golub-Van Loan thin-SVD flops 6mn^2+20n^3 of the truncated SVDs (+2mnk of the fused route's "
+                              "GEMMs), shapes from the bond profiles; the SVDs are one-sided Jacobi (latency-bound vector "
+                              "code between MFMA GEMMs), so this fraction is the honest distance to the matrix peak"},
+    }
+
+
+# ---------------------------------------------------------------------------------------------- ranks
 def spawn_ranks(n):
     """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment), started by a parent
     that never initialises the GPU.  stdout of rank 0 is relayed (its last line is the JSON result); the exit code is
@@ -128,41 +242,76 @@ def spawn_ranks(n):
     return rc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="zt_n24_chi64_D128", choices=sorted(WORKLOADS))
-    ap.add_argument("--queries", type=int, default=64, help="coefficient samples for max|coeff err|")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Ranks:
+    """RANK / WORLD_SIZE from the launcher's environment; torch.distributed over RCCL when there is more than one.
+    QIL_BENCH_FORCE_DIST=1 exercises the collective code path at N=1; QIL_BENCH_BACKEND=gloo (+ every rank on device 0)
+    lets a 1-GPU box run the N-rank logic end to end."""
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` without a launcher: this process touches no GPU (nothing HIP- or torch-related
-        # has been imported yet), starts one child per GPU and relays rank 0's JSON line
-        sys.exit(spawn_ranks(args.gpus))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    # QIL_BENCH_FORCE_DIST=1 exercises the RCCL code path (barrier, all_reduce, gather) even at N=1
-    if world > 1 or os.environ.get("QIL_BENCH_FORCE_DIST") == "1":
+    def __init__(self, gpus):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.backend = os.environ.get("QIL_BENCH_BACKEND", "nccl")
+        if self.backend == "gloo":
+            self.local_rank = 0
+        if self.world > 1 or os.environ.get("QIL_BENCH_FORCE_DIST") == "1":
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+            self.world = dist.get_world_size()
+        if self.world != gpus and os.environ.get("QIL_BENCH_FORCE_DIST") != "1":
+            sys.exit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={self.world} ranks")
+
+    @property
+    def device(self):
+        return f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu"
+
+    def barrier(self, ctx):
+        ctx.synchronize()
+        if self.dist is not None:
+            import torch
+            self.dist.barrier()
+            if self.backend == "nccl":
+                torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        if self.dist is None:
+            return list(values)
         import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()
-    if world != args.gpus and os.environ.get("QIL_BENCH_FORCE_DIST") != "1":
-        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        t = torch.tensor(list(values), dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
 
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def emit(res):
+    try:                                   # RCCL prints a banner through C stdio: flush it first so
+        import ctypes                      # the JSON line is the last line of stdout
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(res), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------- workloads
+def run_apply(args, rk):
     import qilaplace_jl_amd as qil
-    ctx = qil.Context(local_rank)
+    ctx = qil.Context(rk.local_rank)
     qil.set_default_context(ctx)
-
+    rank, world = rk.rank, rk.world
     L, paired, chi, D, desc = WORKLOADS[args.workload]
     cb, db = profiles(L, chi, D)
     mps_cls = qil.ZTMPS if paired else qil.SignalMPS
@@ -172,34 +321,22 @@ def main():
     W = mpo_cls.alloc(db, dtype=np.complex128, ctx=ctx).fill_random(777)
     abytes = algorithmic_bytes(cb, db)
 
-    def barrier():
-        ctx.synchronize()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
-
     out = None
     for _ in range(args.warmup):
         del out
         out = qil.apply(W, psi)
-    barrier()
+    rk.barrier(ctx)
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         del out                      # the previous result's blocks go back to the pool
         out = qil.apply(W, psi)
-    barrier()
+    rk.barrier(ctx)
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     n_launch, kernel_ms = ctx.profile_read(reset=True)
-
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = rk.max_over_ranks([elapsed])[0]
 
     # ---- accuracy: sampled coefficients of the materialised W*psi vs the lazy HIP path and vs
     # the CPU oracle (lazy restatement on the same W, psi)
@@ -216,54 +353,135 @@ def main():
         ph = O.SignalMPS(psi.to_host(), amplitude=psi.amplitude)
         c_ref = O.lazy_coefficient_batch(Wh, ph, bits)
         err_oracle = float(np.abs(c_mat - c_ref).max() / max(np.abs(c_ref).max(), 1e-300))
-    if dist is not None:
+    if rk.dist is not None:
         import torch
-        mine = torch.tensor(np.stack([c_mat.real, c_mat.imag], -1), device=f"cuda:{local_rank}")
+        mine = torch.tensor(np.stack([c_mat.real, c_mat.imag], -1), device=rk.device)
         gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gathered, dst=0)           # the one RCCL data collective (KB-scale)
+        rk.dist.gather(mine, gathered, dst=0)           # the one RCCL data collective (KB-scale)
+    del out
+    if rank != 0:
+        return
+    ms_step = elapsed / args.steps * 1e3
+    k_ms = kernel_ms / max(n_launch, 1)
+    achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, tsrc = pmc_traffic(args.workload)
+    res = {
+        "metric": "MPO×MPS site-contractions/sec + max |coeff err|, n=24 χ_s=64 χ_c=128",
+        "value": L * world / (elapsed / args.steps),
+        "unit": "site-contractions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "description": desc, "sites": L,
+                   "mps_bonds_max": chi, "mpo_bonds_max": D,
+                   "output_bytes_per_step": abytes, "parallelism": f"replicas x{world} (one signal per GPU)",
+                   "ranks_reported_by_collective_backend": world, "lib_sha16": lib_sha16()},
+        "max_coeff_err": err_oracle if err_oracle is not None else err_lazy,
+        "coeff_err": {"materialised_vs_lazy_hip": err_lazy, "materialised_vs_cpu_oracle": err_oracle,
+                      "queries": args.queries, "kind": "max relative"},
+        "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<c64,double>",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+                     "traffic": traffic, "traffic_source": tsrc, "kernel_ms": k_ms, "launches_timed": n_launch,
+                     "algorithmic_bytes_per_launch": abytes},
+    }
+    if world == 1 and not args.no_truncate:
+        del W, psi
+        ctx.trim()
+        res["truncate"] = truncate_block(qil, ctx)
+        psi = mps_cls.alloc(cb, dtype=np.float64, amplitude=1.0, ctx=ctx).fill_random(20240064 + rank)
+        W = mpo_cls.alloc(db, dtype=np.complex128, ctx=ctx).fill_random(777)
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(W, psi, cb, db, L)
+    emit(res)
 
-    if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        k_ms = kernel_ms / max(n_launch, 1)
-        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload)
-            except Exception:
-                traffic = None
-        res = {
-            "metric": "MPO×MPS site-contractions/sec + max |coeff err|, n=24 χ_s=64 χ_c=128",
-            "value": L * world / (elapsed / args.steps),
-            "unit": "site-contractions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "description": desc, "sites": L,
-                       "mps_bonds_max": chi, "mpo_bonds_max": D,
-                       "output_bytes_per_step": abytes, "parallelism": f"replicas x{world} (one signal per GPU)"},
-            "max_coeff_err": err_oracle if err_oracle is not None else err_lazy,
-            "coeff_err": {"materialised_vs_lazy_hip": err_lazy, "materialised_vs_cpu_oracle": err_oracle,
-                          "queries": args.queries, "kind": "max relative"},
-            "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<c64,double>",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-                         "traffic": traffic, "kernel_ms": k_ms, "launches_timed": n_launch,
-                         "algorithmic_bytes_per_launch": abytes},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(qil, W, psi, cb, db, L)
-        try:                                   # RCCL prints a banner through C stdio: flush it first so
-            import ctypes                      # the JSON line is the last line of stdout
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+def run_sweep(args, rk):
+    """configs[3]: one encoded n=24 signal x 64 damping values; a step = one whole sweep (device build of this rank's
+    share, apply + 1024 samples per value, one all_gather).  Strong scaling: the 64 values are dealt to the ranks."""
+    import qilaplace_jl_amd as qil
+    ctx = qil.Context(rk.local_rank)
+    qil.set_default_context(ctx)
+    n, N, nsig, nsamp = 24, 2 ** 24, 64, 1024
+    j = np.arange(N, dtype=np.float64)
+    rng = np.random.default_rng(1001)                       # :multi_sin_exp-like structured signal (Signals.jl:64-85)
+    ak = rng.random(10)
+    ak /= np.linalg.norm(ak)
+    wk = 40.0 / N * (rng.random(10) - 0.5)
+    lk = -2.0 / N * rng.random(10)
+    x = sum(ak[k] * np.sin(wk[k] * j) * np.exp(lk[k] * j) for k in range(10))
+    psi = qil.signal_ztmps(x, method="rsvd", k=15, p=5, q=2, cutoff=1e-12)
+    sig = np.linspace(0.25, 16.0, nsig)
+    bits = np.random.default_rng(7).integers(0, 2, size=(nsamp, 2 * n)).astype(np.uint8)
+    dist = rk.dist if rk.world > 1 else None
+    dev = rk.device if dist is not None and rk.backend == "nccl" else None
+    res = None
+    for _ in range(args.warmup):
+        res = qil.damping_sweep(psi, sig, bits, dist=dist, device=dev)
+    rk.barrier(ctx)
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = qil.damping_sweep(psi, sig, bits, dist=dist, device=dev)
+    rk.barrier(ctx)
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    n_launch, kernel_ms = ctx.profile_read(reset=True)
+    elapsed = rk.max_over_ranks([elapsed])[0]
+    if rk.rank != 0:
+        return
+    kk = (bits[:, 0::2].astype(np.int64) * (1 << np.arange(n))[None, :]).sum(1)
+    jj = (bits[:, 1::2].astype(np.int64) * (1 << np.arange(n - 1, -1, -1))[None, :]).sum(1)
+    peak = np.abs(x).max() / np.sqrt(N)
+    err = max(float(np.abs(res[r] - x[jj] * np.exp(-sig[r] * kk * jj / N) / np.sqrt(N)).max() / peak) for r in range(nsig))
+    Ws = qil.build_dt_mpo_batch(psi, [sig[0], sig[-1]])
+    ab = sum(algorithmic_bytes(psi.bond_dims, W.bond_dims, w_bytes=8, a_bytes=8, o_bytes=8) for W in Ws) / 2.0
+    k_ms = kernel_ms / max(n_launch, 1)
+    achieved = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    emit({
+        "metric": "MPO×MPS site-contractions/sec + max |coeff err|, n=24 damping sweep (configs[3])",
+        "value": nsig * 2 * n / (elapsed / args.steps), "unit": "site-contractions/s",
+        "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "description": WORKLOADS[args.workload][4], "sites": 2 * n,
+                   "damping_values": nsig, "samples_per_value": nsamp, "mps_bonds_max": max(psi.bond_dims),
+                   "mpo_bonds_max": max(max(W.bond_dims) for W in Ws),
+                   "parallelism": f"64 damping values round-robin over {rk.world} rank(s), one all_gather",
+                   "lib_sha16": lib_sha16()},
+        "max_coeff_err": err, "coeff_err": {"vs_closed_form_rel_to_signal_peak": err, "queries": nsig * nsamp},
+        "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<double,double> (the sweep's apply launches; the step is "
+                     "dominated by the latency-bound dt_build_persistent chain, see DESIGN.md 3.6)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel_ms": k_ms, "launches_timed": n_launch,
+                     "algorithmic_bytes_per_launch": ab},
+    })
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="default: 400 applies (>= 5 s timed) / 20 sweeps")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="zt_n24_chi64_D128", choices=sorted(WORKLOADS))
+    ap.add_argument("--queries", type=int, default=64, help="coefficient samples for max|coeff err|")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-truncate", action="store_true")
+    args = ap.parse_args()
+    sweep = args.workload == "dt_sweep_n24_s64"
+    if args.steps is None:
+        args.steps = 20 if sweep else 400
+    if args.warmup is None:
+        args.warmup = 2 if sweep else 3
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process touches no GPU (nothing HIP- or torch-related
+        # has been imported yet), starts one child per GPU and relays rank 0's JSON line
+        sys.exit(spawn_ranks(args.gpus))
+    rk = Ranks(args.gpus)
+    (run_sweep if sweep else run_apply)(args, rk)
+    rk.finish()
 
 
 if __name__ == "__main__":
