@@ -17,7 +17,7 @@ using ..Mpo: SingleSiteMPO, PairedSiteMPO
 using ..ApplyMPO: _as_single_site_mpo
 
 export DeviceMPS, DeviceMPO, to_device, to_host, signal_mps_device, marginal, mps_block, apply_compress,
-    compress_mpo!, build_dt_mpo_batch
+    compress_mpo!, build_dt_mpo_batch, apply_coefficient_sweep
 
 const LIB = get(ENV, "QILHIP_LIB", "libqilhip.so")
 
@@ -278,6 +278,17 @@ function mps_block(psi::DeviceMPS, spec::AbstractVector{<:Integer}; reverse::Boo
     check(ccall((:qil_mps_block, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ptr{Cvoid}),
                 psi.h, Vector{UInt8}(spec), reverse, out))
     return out
+end
+# the body of a damping sweep: for every operator materialise W * psi and read it out at the same configurations
+# (the loop of docs/src/tutorials/dt.jl:150-197) -- one upload, one download, one synchronisation
+function apply_coefficient_sweep(Ws::Vector{<:DeviceMPO}, psi::DeviceMPS, bits::AbstractMatrix{<:Integer})
+    nb = size(bits, 1)
+    b = permutedims(UInt8.(bits))                       # query-major, site fastest
+    out = Matrix{ComplexF64}(undef, nb, length(Ws))
+    hs = Ptr{Cvoid}[W.h for W in Ws]
+    check(ccall((:qil_apply_coefficient_sweep, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int64, Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cvoid}),
+                hs, length(Ws), psi.h, nb, b, out))
+    return permutedims(out)                             # (operator, query)
 end
 # build_dt_mpo for a sweep of damping values, built together on the device (dt_transformer.jl:312-412)
 function build_dt_mpo_batch(psi::DeviceMPS, wrs::AbstractVector{<:Real}; cutoff::Float64=1e-14, maxdim::Int=1000)

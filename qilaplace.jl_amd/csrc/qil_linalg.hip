@@ -1405,6 +1405,393 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
     return QIL_OK;
 }
 
+// ------------------------------------------------------------------ mid-size SVD with ONE isometric factor
+// The gauge sweeps (canonicalize!, compress!, the zip-up) keep only ONE factor of every SVD as a site tensor; the other
+// is multiplied into the neighbour.  Then no rotation matrix has to be accumulated: the isometric factor is the
+// normalised rotated work matrix itself and the other one is a GEMM with the operand (no division by singular
+// values).  Half the LDS per column => blocks of 16 columns instead of 8 (15 outer rounds per sweep at 256 columns
+// instead of 31), half the rotation work per pair, cached squared norms (one wave reduction per pair instead of three).
+
+// rotation of a column pair from |x|^2 = al, |y|^2 = be, x^H y = gr + i gi (see pb_rotation in qil_build_persist.hip):
+// c, s (signed by be - al), the phase e^{i phi} = g / |g| and |g|
+template <bool CX>
+__device__ __forceinline__ bool rotation_fast(double al, double be, double gr, double gi, double tol, double& c, double& s,
+                                              double& pr, double& pi, double& gabs, bool& big) {
+    const double g2 = CX ? fma(gr, gr, gi * gi) : gr * gr;
+    const double ab = al * be;
+    big = g2 > kQuadraticOff * kQuadraticOff * ab;
+    if (!(g2 > tol * tol * ab) || g2 == 0.0) return false;
+    const double d = be - al;
+    const double rh = rsqrt_refined(fma(d, d, 4.0 * g2));
+    const double c2 = fma(0.5 * fabs(d), rh, 0.5);
+    const double rc = rsqrt_refined(c2);
+    c = c2 * rc;
+    if (CX) {
+        const double ig = rsqrt_refined(g2);
+        gabs = g2 * ig;
+        pr = gr * ig;
+        pi = gi * ig;
+    } else {
+        gabs = fabs(gr);
+        pr = gr >= 0 ? 1.0 : -1.0;
+        pi = 0.0;
+    }
+    s = copysign(gabs * rh * rc, d);
+    return true;
+}
+
+template <class T, int BB, int KM>
+__global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict__ A, long long lda, int m, int n, int nb,
+                                                                  int round, int all_pairs, double tol,
+                                                                  int* __restrict__ rotated,
+                                                                  const double* __restrict__ negligible) {
+    constexpr int W = 2 * BB;
+    constexpr bool CX = sizeof(T) == 16;
+    extern __shared__ __attribute__((aligned(16))) char jn_smem[];
+    const int la = m | 1;
+    T* As = reinterpret_cast<T*>(jn_smem);
+    double* nr2 = reinterpret_cast<double*>(As + (size_t)la * W);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int P, Q;
+    {
+        const int i = blockIdx.x;
+        if (i == 0) {
+            P = nb - 1;
+            Q = round;
+        } else {
+            P = (round + i) % (nb - 1);
+            Q = (round + nb - 1 - i) % (nb - 1);
+        }
+        if (P > Q) {
+            const int t = P;
+            P = Q;
+            Q = t;
+        }
+    }
+    auto gcol = [&](int k) { return (k < BB ? P * BB + k : Q * BB + (k - BB)); };
+    if (P * BB >= n) return;                               // both blocks are padding
+    // staging: every wave owns two of the 2 BB columns; their squared norms are taken on the way
+    const int kc0 = wave, kc1 = wave + BB;
+    const int gc0 = gcol(kc0), gc1 = gcol(kc1);
+    {
+        const T* s0 = A + lda * gc0;
+        const T* s1 = A + lda * gc1;
+        T t0[KM], t1[KM];
+#pragma unroll
+        for (int u = 0; u < KM; ++u) {
+            const int r = lane + 64 * u;
+            t0[u] = (gc0 < n && r < m) ? s0[r] : T{};
+            t1[u] = (gc1 < n && r < m) ? s1[r] : T{};
+        }
+        T* d0 = As + (size_t)la * kc0;
+        T* d1 = As + (size_t)la * kc1;
+        double n0 = 0, n1 = 0;
+#pragma unroll
+        for (int u = 0; u < KM; ++u) {
+            const int r = lane + 64 * u;
+            if (r < m) {
+                d0[r] = t0[u];
+                d1[r] = t1[u];
+            }
+            n0 += abs2_t(t0[u]);
+            n1 += abs2_t(t1[u]);
+        }
+        n0 = wave_sum(n0);
+        n1 = wave_sum(n1);
+        if (lane == 0) {
+            nr2[kc0] = n0;
+            nr2[kc1] = n1;
+        }
+    }
+    __syncthreads();
+    const double ng = negligible ? *negligible : 0.0;
+    int flags = 0;
+    const int nin = all_pairs ? W - 1 : BB;
+    for (int t = 0; t < nin; ++t) {
+        int p, q;
+        if (all_pairs) {
+            if (wave == 0) {
+                p = W - 1;
+                q = t;
+            } else {
+                p = t + wave;
+                q = t + W - 1 - wave;
+                if (p >= W - 1) p -= W - 1;
+                if (q >= W - 1) q -= W - 1;
+            }
+            if (p > q) {
+                const int t2 = p;
+                p = q;
+                q = t2;
+            }
+        } else {
+            p = wave;
+            q = wave + t;
+            if (q >= BB) q -= BB;
+            q += BB;
+        }
+        if (gcol(p) < n && gcol(q) < n) {
+            T* ap = As + (size_t)la * p;
+            T* aq = As + (size_t)la * q;
+            T xs[KM], ys[KM];
+#pragma unroll
+            for (int u = 0; u < KM; ++u) {
+                const int r = lane + 64 * u;
+                xs[u] = r < m ? ap[r] : T{};
+                ys[u] = r < m ? aq[r] : T{};
+            }
+            const double al = nr2[p], be = nr2[q];
+            double gr = 0, gi = 0;
+#pragma unroll
+            for (int u = 0; u < KM; ++u) dot_parts(xs[u], ys[u], gr, gi);
+            gr = wave_sum(gr);
+            if (CX) gi = wave_sum(gi);
+            double c, sn, pr, pi, gabs;
+            bool big;
+            if (!(al < ng || be < ng) && rotation_fast<CX>(al, be, gr, gi, tol, c, sn, pr, pi, gabs, big)) {
+                flags |= big ? 3 : 1;
+                double aln = 0, ben = 0;
+#pragma unroll
+                for (int u = 0; u < KM; ++u) {
+                    const int r = lane + 64 * u;
+                    rotate_pair(xs[u], ys[u], c, sn, pr, pi);
+                    if (r < m) {
+                        ap[r] = xs[u];
+                        aq[r] = ys[u];
+                    }
+                }
+                // |x'|^2 = c^2 al + s^2 be - 2 c s |g|,  |y'|^2 = s^2 al + c^2 be + 2 c s |g|; after strong
+                // cancellation the column's norm is taken from the rotated registers instead
+                const double cs2 = 2.0 * c * sn * gabs, c2 = c * c, s2 = sn * sn;
+                aln = fma(c2, al, fma(s2, be, -cs2));
+                ben = fma(s2, al, fma(c2, be, cs2));
+                if (aln < 0.25 * al || ben < 0.25 * be) {
+                    double ea = 0, eb = 0;
+#pragma unroll
+                    for (int u = 0; u < KM; ++u) {
+                        ea += abs2_t(xs[u]);
+                        eb += abs2_t(ys[u]);
+                    }
+                    aln = wave_sum(ea);
+                    ben = wave_sum(eb);
+                }
+                if (lane == 0) {
+                    nr2[p] = aln;
+                    nr2[q] = ben;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && flags) {        // plain stores of the same value from every rotating wave
+        rotated[0] = 1;
+        if (flags & 2) rotated[1] = 1;
+    }
+    auto unstage = [&](int gc, int kc) {
+        if (gc < n) {
+            T* d = A + lda * gc;
+            const T* sp = As + (size_t)la * kc;
+            T t0[KM];
+#pragma unroll
+            for (int u = 0; u < KM; ++u) {
+                const int r = lane + 64 * u;
+                t0[u] = r < m ? sp[r] : T{};
+            }
+#pragma unroll
+            for (int u = 0; u < KM; ++u) {
+                const int r = lane + 64 * u;
+                if (r < m) d[r] = t0[u];
+            }
+        }
+    };
+    unstage(gc0, kc0);
+    unstage(gc1, kc1);
+}
+
+template <class T, int BB, int KM>
+int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nblk, int round, double tol, int* flag,
+                           const double* negl) {
+    const size_t lds = (size_t)2 * BB * (size_t)(k | 1) * sizeof(T) + (size_t)2 * BB * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM>), dim3(nblk / 2), dim3(64 * BB), lds, ctx->stream, X, ldx, k, k,
+                       nblk, round, round == 0 ? 1 : 0, tol, flag, negl);
+    return QIL_OK;
+}
+
+// B (p x q, ldb; destroyed) = Uiso diag(S) V^H:  Uiso (p x k, k = min(p, q)) orthonormal columns sorted by descending
+// singular value, S on the host, SVh (k x q) = diag(S) V^H.  Serves 97 <= k < 640 with the columns resident in LDS;
+// *handled = 0 (nothing touched beyond B's contents being intact) sends the caller to the general svd_impl.
+template <class T>
+int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb, T* Uiso, long long ldu, double* S_host,
+                 T* SVh, long long ldsvh, double negl_rel, int* handled) {
+    *handled = 0;
+    const long long k = std::min(p, q);
+    static const bool enabled = !(getenv("QIL_SVD_LEFT") && atoi(getenv("QIL_SVD_LEFT")) == 0);
+    if (!enabled || k < 97 || k >= 640) return QIL_OK;
+    const size_t per_col = (size_t)(k | 1) * sizeof(T) + sizeof(double);
+    int bb = 0;
+    // blocks of 8 columns by default: the rounds are ISSUE-bound (one wave per pair, ~130 instructions of f64 / DPP work per
+    // pair and round), so 16-column blocks -- 16 waves per CU, four per SIMD, half as many workgroups -- halve the outer
+    // rounds but serialise four pairs on every SIMD: measured 158 vs 150 ms for compress! 256 -> 128 on 24 sites
+    static const int bb_cap = getenv("QIL_SVD_LEFT_BB") ? atoi(getenv("QIL_SVD_LEFT_BB")) : 8;
+    if (bb_cap >= 16 && 32 * per_col <= 150 * 1024) bb = 16;
+    else if (16 * per_col <= 150 * 1024) bb = 8;
+    else return QIL_OK;
+    const bool dbg = getenv("QIL_SVD_DEBUG") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[svd-left] %lld x %lld: %s %.2f ms\n", p, q, what,
+                std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    const bool tall = p >= q;
+    static const bool second_qr = getenv("QIL_SVD_LEFT_QR2") && atoi(getenv("QIL_SVD_LEFT_QR2")) == 1;
+    const int cj = sizeof(T) == 16 ? 2 : 1;
+    const unsigned gk = (unsigned)std::min<long long>((k * k + 255) / 256, 65536);
+    void *rbuf = nullptr, *xbuf = nullptr, *bh = nullptr, *flag = nullptr, *nrm = nullptr, *negl = nullptr, *wbuf = nullptr;
+    auto release = [&]() {
+        for (void* b : {rbuf, xbuf, bh, flag, nrm, negl, wbuf})
+            if (b) qil_ctx_free(ctx, b);
+    };
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * k) * sizeof(T), &rbuf));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * k) * sizeof(T), &xbuf));
+    T* R = static_cast<T*>(rbuf);
+    T* X = static_cast<T*>(xbuf);
+    T* Qm = nullptr;
+    long long ldq = 0, qrows = 0;
+    if (tall) {
+        QIL_TRY(qr_impl<T>(ctx, p, q, B, ldb, R, k));
+        bool ok = true;
+        QIL_TRY(qr_reorthogonalise<T>(ctx, p, q, B, ldb, R, k, dbg, &ok));
+        if (!ok) {                                   // B = Q R reproduces the operand: hand it back intact
+            void* tmp = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(p * q) * sizeof(T), &tmp));
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, p, q, q, B, ldb, R, k, static_cast<T*>(tmp), p));
+            QIL_HIP(hipMemcpy2DAsync(B, (size_t)ldb * sizeof(T), tmp, (size_t)p * sizeof(T), (size_t)p * sizeof(T), (size_t)q,
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+            qil_ctx_free(ctx, tmp);
+            release();
+            return QIL_OK;
+        }
+        Qm = B;
+        ldq = ldb;
+        qrows = p;
+        if (second_qr) {
+            // R^H = Q1 R1; the columns of X = R1^H are rotated (R = X Q1^H has the same left singular vectors)
+            void* r1 = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * k) * sizeof(T), &r1));
+            hipLaunchKernelGGL(conj_transpose<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)R, k, k, k, X, k);
+            QIL_TRY(qr_impl<T>(ctx, k, k, X, k, static_cast<T*>(r1), k));
+            QIL_TRY(qr_reorthogonalise<T>(ctx, k, k, X, k, static_cast<T*>(r1), k, dbg, nullptr));
+            hipLaunchKernelGGL(conj_transpose<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)r1, k, k, k, X, k);
+            qil_ctx_free(ctx, r1);
+        } else {
+            QIL_HIP(hipMemcpyAsync(X, R, (size_t)(k * k) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    } else {
+        // B^H = Q R  =>  B = R^H Q^H: the left singular vectors of B are those of X = R^H
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(q * p) * sizeof(T), &bh));
+        hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((p * q + 255) / 256, 65536)), dim3(256), 0,
+                           ctx->stream, (const T*)B, ldb, p, q, static_cast<T*>(bh), q);
+        QIL_TRY(qr_impl<T>(ctx, q, p, static_cast<T*>(bh), q, R, k));
+        bool ok = true;
+        QIL_TRY(qr_reorthogonalise<T>(ctx, q, p, static_cast<T*>(bh), q, R, k, dbg, &ok));
+        if (!ok) {
+            release();
+            return QIL_OK;
+        }
+        hipLaunchKernelGGL(conj_transpose<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)R, k, k, k, X, k);
+    }
+    lap("QR");
+    QIL_TRY(qil_ctx_alloc(ctx, 256, &flag));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * sizeof(double), &nrm));
+    if (negl_rel > 0.0) {
+        QIL_TRY(qil_ctx_alloc(ctx, 256, &negl));
+        hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)k), dim3(256), 0, ctx->stream, (const T*)X, k, k, (double*)nrm);
+        hipLaunchKernelGGL(negligible_threshold, dim3(1), dim3(256), 0, ctx->stream, (const double*)nrm, (int)k, negl_rel,
+                           (double*)negl);
+    }
+    const double tol = std::max(1e-15, 4.0 * 1.1e-16 * std::sqrt((double)k));
+    const int nblk = (int)(((k + bb - 1) / bb + 1) / 2 * 2);
+    const int km = (int)((k + 63) / 64);
+    int sweeps = 0;
+    for (; sweeps < 40; ++sweeps) {
+        QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
+        for (int round = 0; round < nblk - 1; ++round) {
+#define QIL_NOV(BBv, KMv) QIL_TRY((launch_block_round_nov<T, BBv, KMv>(ctx, X, k, (int)k, nblk, round, tol, (int*)flag, (const double*)negl)))
+            if (bb == 16) {
+                if (km <= 4) QIL_NOV(16, 4);
+                else if (km <= 7) QIL_NOV(16, 7);
+                else QIL_NOV(16, 10);
+            } else {
+                if (km <= 4) QIL_NOV(8, 4);
+                else if (km <= 7) QIL_NOV(8, 7);
+                else QIL_NOV(8, 10);
+            }
+#undef QIL_NOV
+        }
+        int hv[2] = {0, 0};
+        QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        if (dbg) fprintf(stderr, "[svd-left] sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[0], hv[1]);
+        if (!hv[1]) break;
+    }
+    lap("sweeps");
+    hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)k), dim3(256), 0, ctx->stream, (const T*)X, k, k, (double*)nrm);
+    std::vector<double> sig((size_t)k);
+    QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int> perm((size_t)k);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return sig[(size_t)a] > sig[(size_t)b]; });
+    std::vector<double> inv((size_t)k);
+    for (long long j = 0; j < k; ++j) {
+        const double sv = sig[(size_t)perm[(size_t)j]];
+        S_host[j] = sv;
+        inv[(size_t)j] = sv > 0 ? 1.0 / sv : 0.0;
+    }
+    void *hp = nullptr, *dp = nullptr;
+    int slot = -1;
+    const size_t up = (size_t)k * (sizeof(double) + sizeof(int));
+    QIL_TRY(qil_ctx_desc_acquire(ctx, up, &hp, &dp, &slot));
+    memcpy(hp, inv.data(), (size_t)k * sizeof(double));
+    memcpy(static_cast<char*>(hp) + (size_t)k * sizeof(double), perm.data(), (size_t)k * sizeof(int));
+    QIL_HIP(hipMemcpyAsync(dp, hp, up, hipMemcpyHostToDevice, ctx->stream));
+    const double* scd = static_cast<const double*>(dp);
+    const int* permd = reinterpret_cast<const int*>(static_cast<const char*>(dp) + (size_t)k * sizeof(double));
+    // W = normalised rotated columns in sorted order
+    T* Wm = nullptr;
+    long long ldw = k;
+    if (tall) {
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * k) * sizeof(T), &wbuf));
+        Wm = static_cast<T*>(wbuf);
+    } else {
+        Wm = Uiso;
+        ldw = ldu;
+    }
+    hipLaunchKernelGGL(gather_cols<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)X, k, k, permd, scd, Wm, ldw, (int)k, 0);
+    QIL_TRY(qil_ctx_desc_commit(ctx, slot));
+    if (tall) {
+        QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, qrows, k, k, Qm, ldq, Wm, ldw, Uiso, ldu));          // Uiso = Q W
+        QIL_TRY(gemm_dispatch<T>(ctx, cj, 0, k, q, k, Wm, ldw, R, k, SVh, ldsvh));               // S V^H = W^H R
+    } else {
+        QIL_TRY(gemm_dispatch<T>(ctx, cj, 0, k, q, p, Wm, ldw, B, ldb, SVh, ldsvh));             // S V^H = W^H B
+    }
+    QIL_HIP(hipGetLastError());
+    lap("factors out");
+    release();
+    *handled = 1;
+    return QIL_OK;
+}
+
 // Thin SVD A = U diag(S) Vh by one-sided Jacobi on the SHORT side.
 //   1. orientation: the work matrix has rows >= cols (A^H if m < n);
 //   2. tall-skinny (rows >= 8 cols): QR first, Jacobi on the cols x cols factor R, U = Q U_R;
@@ -2077,6 +2464,15 @@ int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int6
     if (dtype == QIL_C64)
         return svd_impl<c64>(ctx, m, n, (c64*)A, lda, (c64*)U, ldu, S_host, (c64*)Vh, ldvh, negligible_rel);
     return svd_impl<double>(ctx, m, n, (double*)A, lda, (double*)U, ldu, S_host, (double*)Vh, ldvh, negligible_rel);
+}
+
+int qil_dev_svd_left(qil_context* ctx, int dtype, int64_t p, int64_t q, void* B, int64_t ldb, void* Uiso, int64_t ldu,
+                     double* S_host, void* SVh, int64_t ldsvh, double negligible_rel, int* handled) {
+    if (dtype == QIL_C64)
+        return svd_left_mid<c64>(ctx, p, q, static_cast<c64*>(B), ldb, static_cast<c64*>(Uiso), ldu, S_host,
+                                 static_cast<c64*>(SVh), ldsvh, negligible_rel, handled);
+    return svd_left_mid<double>(ctx, p, q, static_cast<double*>(B), ldb, static_cast<double*>(Uiso), ldu, S_host,
+                                static_cast<double*>(SVh), ldsvh, negligible_rel, handled);
 }
 
 int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* R,

@@ -56,10 +56,30 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
     std::vector<double> S((size_t)r0);
     // with a truncating cutoff, columns 100x below it (and never above 1e-30 |A|_F^2) are not worth rotating
     const double negl_rel = use_cutoff && cutoff > 0 ? std::min(1e-30, 1e-2 * cutoff) : 0.0;
-    QIL_TRY(qil_dev_svd(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0, negl_rel));
+    // Gauge sweeps keep ONE factor as the site (isometric) and multiply the other into the neighbour: the mid-size path
+    // that accumulates no rotation matrix (qil_dev_svd_left) serves them; everything else takes the general SVD.
+    int handled = 0;
+    if (absorb == 2) {            // U isometric, S Vh absorbed
+        QIL_TRY(qil_dev_svd_left(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0, negl_rel, &handled));
+    } else if (absorb == 1) {     // Vh isometric, U S absorbed: the same problem on A^H
+        void *At = nullptr, *Vi = nullptr, *SU = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &At));
+        QIL_TRY(qil_dev_transpose(ctx, dtype, 1, m, n, A, lda, At, n));                         // A^H (n x m)
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * r0) * e, &Vi));
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r0 * m) * e, &SU));
+        QIL_TRY(qil_dev_svd_left(ctx, dtype, n, m, At, n, Vi, n, S.data(), SU, r0, negl_rel, &handled));
+        if (handled) {
+            QIL_TRY(qil_dev_transpose(ctx, dtype, 1, n, r0, Vi, n, Vh, r0));                    // Vh = V^H   (r0 x n)
+            QIL_TRY(qil_dev_transpose(ctx, dtype, 1, r0, m, SU, r0, U, m));                     // U S = (S U^H)^H
+        }
+        qil_ctx_free(ctx, At);
+        qil_ctx_free(ctx, Vi);
+        qil_ctx_free(ctx, SU);
+    }
+    if (!handled) QIL_TRY(qil_dev_svd(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0, negl_rel));
     const int64_t r = qil_truncation_rank(S.data(), r0, cutoff, use_cutoff, maxdim, mindim);
-    if (absorb == 1) QIL_TRY(qil_dev_scale(ctx, dtype, 1, m, r, U, m, S.data()));
-    if (absorb == 2) QIL_TRY(qil_dev_scale(ctx, dtype, 0, r, n, Vh, r0, S.data()));
+    if (!handled && absorb == 1) QIL_TRY(qil_dev_scale(ctx, dtype, 1, m, r, U, m, S.data()));
+    if (!handled && absorb == 2) QIL_TRY(qil_dev_scale(ctx, dtype, 0, r, n, Vh, r0, S.data()));
     if (r < r0) {  // compact Vh rows to leading dimension r
         void* Vc = nullptr;
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * n) * e, &Vc));
