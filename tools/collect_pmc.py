@@ -61,6 +61,8 @@ def main():
                          "VGPR_Count", "SGPR_Count"])
             wr.writerows(rows)
     json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r02_pmc_traffic.json"), "w"), indent=1)
+    import shutil
+    shutil.rmtree(out, ignore_errors=True)
     print(json.dumps(rec))
 
 
