@@ -962,6 +962,204 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long l
         }
 }
 
+// ------------------------------------------------------------------ Householder panel (in LDS)
+// Thin QR of one panel P (m x b, b <= 32) resident in LDS, the intra-panel step of the blocked QR below (r02; it
+// replaces the CGS2 panel kernel gs_fused there: ~110-150 us per 512 x 32 panel -> ~15 us).  Householder reflectors
+// (every wave derives the reflector of column j redundantly from its registers and updates the trailing columns it
+// owns: one barrier per column), explicit Q formed barrier-free (one column per wave, held in registers), positive
+// real diagonal of R by a column phase.  Staircase form for numerically dependent columns -- residual below 1e-13 of
+// the column's ORIGINAL norm (ref_norm: measured by the blocked driver before its projections): such a column gets no
+// reflector and no row, comes out as a ZERO column of Q with a zero row of R, and P = Q R still holds (its components
+// along the earlier reflectors' rows stay in R) -- the contract the CGS2 kernel established for rank-deficient
+// operands (product bonds before truncation, sketches wider than the rank).
+template <class T>
+__device__ __forceinline__ T hh_mul_conj(T a, T b);      // conj(a) * b
+template <>
+__device__ __forceinline__ double hh_mul_conj<double>(double a, double b) { return a * b; }
+template <>
+__device__ __forceinline__ c64 hh_mul_conj<c64>(c64 a, c64 b) {
+    return c64{a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re};
+}
+__device__ __forceinline__ double hh_cmul(double a, double b) { return a * b; }
+__device__ __forceinline__ c64 hh_cmul(c64 a, c64 b) { return c64{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ double hh_wave_sum(double v) { return wave_sum(v); }
+__device__ __forceinline__ c64 hh_wave_sum(c64 v) { return c64{wave_sum(v.re), wave_sum(v.im)}; }
+
+template <class T, int KM>
+__global__ __launch_bounds__(1024) void hh_panel(T* __restrict__ P, long long lda, int m, int b, T* __restrict__ R,
+                                                 long long ldr, const double* __restrict__ ref_norm) {
+    constexpr int NW = 16;
+    extern __shared__ __attribute__((aligned(16))) char hp_smem[];
+    const int la = m | 1;
+    T* Ps = reinterpret_cast<T*>(hp_smem);
+    double* kap = reinterpret_cast<double*>(Ps + (size_t)la * b);       // b: kappa of column j's reflector (0: none)
+    double* dia = kap + 32;                                              // b: |R_jj|
+    double* refn = dia + 32;                                             // b: reference norms
+    T* pha = reinterpret_cast<T*>(refn + 32);                            // b: column phase making R_jj real positive
+    int* rowof = reinterpret_cast<int*>(pha + 32);                       // b: staircase row of column j, -1 = dependent
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // stage: wave w owns columns w, w + 16
+    for (int c = wave; c < b; c += NW) {
+        const T* src = P + lda * c;
+        T t0[KM];
+#pragma unroll
+        for (int u = 0; u < KM; ++u) {
+            const int r = lane + 64 * u;
+            t0[u] = r < m ? src[r] : T{};
+        }
+        double nn = 0;
+#pragma unroll
+        for (int u = 0; u < KM; ++u) {
+            const int r = lane + 64 * u;
+            if (r < m) Ps[r + (size_t)la * c] = t0[u];
+            nn += abs2_t(t0[u]);
+        }
+        nn = wave_sum(nn);
+        if (lane == 0) refn[c] = ref_norm ? ref_norm[c] : sqrt(nn);
+    }
+    __syncthreads();
+    int rr = 0;                                            // staircase row: identical in every thread
+    for (int j = 0; j < b; ++j) {
+        const T* x = Ps + (size_t)la * j;
+        T xs[KM];
+        double s2 = 0;
+#pragma unroll
+        for (int u = 0; u < KM; ++u) {
+            const int r = lane + 64 * u;
+            xs[u] = (r > rr && r < m) ? x[r] : T{};
+            s2 += abs2_t(xs[u]);
+        }
+        s2 = wave_sum(s2);
+        const T alpha = rr < m ? x[rr] : T{};
+        const double a2 = abs2_t(alpha);
+        const double nrm = sqrt(a2 + s2);
+        const double rn = refn[j];
+        const bool dep = rr >= m || !(nrm > 1e-13 * rn) || rn == 0.0;
+        double kappa = 0.0, absa = 0.0;
+        T pa{}, diff{};
+        if (!dep) {
+            absa = sqrt(a2);
+            // phase of alpha (1 if alpha == 0): beta = -phase * nrm, u_r = alpha - beta = phase (|alpha| + nrm)
+            reinterpret_cast<double*>(&pa)[0] = 1.0;
+            if (absa > 0.0) pa = scale_t(alpha, 1.0 / absa);
+            diff = scale_t(pa, absa + nrm);
+            kappa = 1.0 / (nrm * (nrm + absa));
+            for (int c = j + 1 + ((wave - (j + 1)) % NW + NW) % NW; c < b; c += NW) {
+                T* y = Ps + (size_t)la * c;
+                T ys[KM];
+#pragma unroll
+                for (int u = 0; u < KM; ++u) {
+                    const int r = lane + 64 * u;
+                    ys[u] = (r > rr && r < m) ? y[r] : T{};
+                }
+                const T yr = y[rr];
+                T w{};
+#pragma unroll
+                for (int u = 0; u < KM; ++u) w = add_t(w, hh_mul_conj(xs[u], ys[u]));
+                w = hh_wave_sum(w);
+                w = add_t(w, hh_mul_conj(diff, yr));
+                const T f = scale_t(w, kappa);
+#pragma unroll
+                for (int u = 0; u < KM; ++u) {
+                    const int r = lane + 64 * u;
+                    if (r > rr && r < m) y[r] = sub_t(ys[u], hh_cmul(f, xs[u]));
+                }
+                if (lane == 0) y[rr] = sub_t(yr, hh_cmul(f, diff));
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            kap[j] = kappa;
+            rowof[j] = dep ? -1 : rr;
+            if (!dep) {
+                dia[j] = nrm;
+                pha[j] = scale_t(pa, -1.0);                 // beta / |beta|
+                Ps[rr + (size_t)la * j] = diff;             // first entry of u_j (nobody reads alpha again)
+            }
+        }
+        if (!dep) ++rr;
+    }
+    __syncthreads();
+    // R block (b x b): row jj = conj(phase_jj) * staircase row rowof[jj]; zero rows for dependent columns
+    if (R)
+        for (int t = tid; t < b * b; t += 1024) {
+            const int jj = t % b, c = t / b;
+            T v{};
+            const int ro = rowof[jj];
+            if (ro >= 0 && c >= jj) {
+                if (c == jj) reinterpret_cast<double*>(&v)[0] = dia[jj];
+                else v = hh_mul_conj(pha[jj], Ps[ro + (size_t)la * c]);
+            }
+            R[jj + ldr * c] = v;
+        }
+    // explicit Q: column c = phase_c * H_{j0} ... H_{jk} e_{rowof[c]} over the independent columns j <= c, last first
+    for (int c = wave; c < b; c += NW) {
+        T* dst = P + lda * c;
+        const int ro = rowof[c];
+        T q[KM];
+#pragma unroll
+        for (int u = 0; u < KM; ++u) {
+            q[u] = T{};
+            if (lane + 64 * u == ro) reinterpret_cast<double*>(&q[u])[0] = 1.0;
+        }
+        if (ro >= 0)
+            for (int j = c; j >= 0; --j) {
+                const double kappa = kap[j];
+                const int rj = rowof[j];
+                if (kappa == 0.0 || rj < 0) continue;
+                const T* x = Ps + (size_t)la * j;
+                T xs[KM];
+                T w{};
+#pragma unroll
+                for (int u = 0; u < KM; ++u) {
+                    const int r = lane + 64 * u;
+                    xs[u] = (r >= rj && r < m) ? x[r] : T{};
+                    w = add_t(w, hh_mul_conj(xs[u], q[u]));
+                }
+                w = hh_wave_sum(w);
+                const T f = scale_t(w, kappa);
+#pragma unroll
+                for (int u = 0; u < KM; ++u) q[u] = sub_t(q[u], hh_cmul(f, xs[u]));
+            }
+        const T ph = ro >= 0 ? pha[c] : T{};
+#pragma unroll
+        for (int u = 0; u < KM; ++u) {
+            const int r = lane + 64 * u;
+            if (r < m) dst[r] = ro >= 0 ? hh_cmul(q[u], ph) : T{};
+        }
+    }
+}
+
+// true when the panel fits (LDS and rows-per-lane budget); launches it
+template <class T>
+bool hh_panel_fits(long long m, int b) {
+    return b <= 32 && m <= 64 * 19 && (size_t)(m | 1) * b * sizeof(T) + 1536 <= 150 * 1024;
+}
+template <class T>
+int hh_panel_launch(qil_context* ctx, T* P, long long lda, long long m, int b, T* R, long long ldr, const double* ref_norm) {
+    const size_t lds = (size_t)(m | 1) * b * sizeof(T) + 1536;
+    const int km = (int)((m + 63) / 64);
+#define QIL_HHP(KMv)                                                                                                   \
+    do {                                                                                                               \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hh_panel<T, KMv>),                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                      \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((hh_panel<T, KMv>), dim3(1), dim3(1024), lds, ctx->stream, P, lda, (int)m, b, R, ldr, ref_norm); \
+    } while (0)
+    if (km <= 2) QIL_HHP(2);
+    else if (km <= 4) QIL_HHP(4);
+    else if (km <= 6) QIL_HHP(6);
+    else if (km <= 9) QIL_HHP(9);
+    else if (km <= 13) QIL_HHP(13);
+    else QIL_HHP(19);
+#undef QIL_HHP
+    QIL_HIP(hipGetLastError());
+    return QIL_OK;
+}
+
 // launches gs_fused with the slice in LDS whenever rows_per_workgroup x n fits
 template <class T>
 int gs_fused_launch(qil_context* ctx, unsigned nwg, T* A, long long lda, long long mtot, int n, T* R, long long ldr,
@@ -2234,6 +2432,7 @@ int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, 
 template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
     static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 2048;   // tuning aid
+    static const bool hh_panels = !(getenv("QIL_QR_HH") && atoi(getenv("QIL_QR_HH")) == 0);                   // tuning aid
     // one launch for the whole factorisation: single panels, and anything whose slice fits one CU's LDS
     const bool fits_lds = ((size_t)2 * (n + (n & 1)) + (size_t)(m | 1) * n) * sizeof(T) <= 150 * 1024;
     // panels go through the row-chunk tree from TALL rows on, and already from 1024 rows when a rows x 16 panel does
@@ -2282,6 +2481,8 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
         T* Rjj = R ? R + j0 + ldr * j0 : (T*)nullptr;
         if (tree)
             QIL_TRY(tsqr_panel<T>(ctx, m, b, P, lda, Rjj, ldr, (const double*)nbuf + j0));
+        else if (hh_panels && hh_panel_fits<T>(m, b))
+            QIL_TRY(hh_panel_launch<T>(ctx, P, lda, m, b, Rjj, ldr, (const double*)nbuf + j0));
         else
             QIL_TRY(gs_fused_launch<T>(ctx, 1u, P, lda, m, b, Rjj, ldr, (const double*)nbuf + j0, 0LL));
     }
