@@ -1638,18 +1638,26 @@ __device__ __forceinline__ bool rotation_fast(double al, double be, double gr, d
     return true;
 }
 
-template <class T, int BB, int KM>
-__global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict__ A, long long lda, int m, int n, int nb,
-                                                                  int round, int all_pairs, double tol,
-                                                                  int* __restrict__ rotated,
-                                                                  const double* __restrict__ negligible) {
+// G lanes per column pair (64 = one wave per pair, 16 = one DPP row per pair: four pairs share a wave's instruction
+// stream, so the ~40 instructions of the rotation and the reduction tree are paid once per four pairs), KM = rows per
+// lane (m <= G KM), BB columns per block; BB G threads.
+template <class T, int BB, int KM, int G>
+__global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__ A, long long lda, int m, int n, int nb,
+                                                                 int round, int all_pairs, double tol,
+                                                                 int* __restrict__ rotated,
+                                                                 const double* __restrict__ negligible) {
     constexpr int W = 2 * BB;
+    constexpr int NT = BB * G;
+    constexpr int NWV = NT / 64;                    // waves
+    constexpr int KW = (KM * G + 63) / 64;          // rows per lane when a whole wave walks a column
     constexpr bool CX = sizeof(T) == 16;
     extern __shared__ __attribute__((aligned(16))) char jn_smem[];
     const int la = m | 1;
     T* As = reinterpret_cast<T*>(jn_smem);
     double* nr2 = reinterpret_cast<double*>(As + (size_t)la * W);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gl = tid & (G - 1), grp = tid / G;    // lane within the pair's group, group = pair slot
+    auto gsum = [](double v) { return G == 16 ? row16_sum(v) : wave_sum(v); };
     int P, Q;
     {
         const int i = blockIdx.x;
@@ -1668,38 +1676,26 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict_
     }
     auto gcol = [&](int k) { return (k < BB ? P * BB + k : Q * BB + (k - BB)); };
     if (P * BB >= n) return;                               // both blocks are padding
-    // staging: every wave owns two of the 2 BB columns; their squared norms are taken on the way
-    const int kc0 = wave, kc1 = wave + BB;
-    const int gc0 = gcol(kc0), gc1 = gcol(kc1);
-    {
-        const T* s0 = A + lda * gc0;
-        const T* s1 = A + lda * gc1;
-        T t0[KM], t1[KM];
+    // staging: the waves share the 2 BB columns; squared norms are taken on the way
+    for (int kc = wave; kc < W; kc += NWV) {
+        const int gc = gcol(kc);
+        const T* s0 = A + lda * gc;
+        T t0[KW];
 #pragma unroll
-        for (int u = 0; u < KM; ++u) {
+        for (int u = 0; u < KW; ++u) {
             const int r = lane + 64 * u;
-            t0[u] = (gc0 < n && r < m) ? s0[r] : T{};
-            t1[u] = (gc1 < n && r < m) ? s1[r] : T{};
+            t0[u] = (gc < n && r < m) ? s0[r] : T{};
         }
-        T* d0 = As + (size_t)la * kc0;
-        T* d1 = As + (size_t)la * kc1;
-        double n0 = 0, n1 = 0;
+        T* d0 = As + (size_t)la * kc;
+        double n0 = 0;
 #pragma unroll
-        for (int u = 0; u < KM; ++u) {
+        for (int u = 0; u < KW; ++u) {
             const int r = lane + 64 * u;
-            if (r < m) {
-                d0[r] = t0[u];
-                d1[r] = t1[u];
-            }
+            if (r < m) d0[r] = t0[u];
             n0 += abs2_t(t0[u]);
-            n1 += abs2_t(t1[u]);
         }
         n0 = wave_sum(n0);
-        n1 = wave_sum(n1);
-        if (lane == 0) {
-            nr2[kc0] = n0;
-            nr2[kc1] = n1;
-        }
+        if (lane == 0) nr2[kc] = n0;
     }
     __syncthreads();
     const double ng = negligible ? *negligible : 0.0;
@@ -1708,12 +1704,12 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict_
     for (int t = 0; t < nin; ++t) {
         int p, q;
         if (all_pairs) {
-            if (wave == 0) {
+            if (grp == 0) {
                 p = W - 1;
                 q = t;
             } else {
-                p = t + wave;
-                q = t + W - 1 - wave;
+                p = t + grp;
+                q = t + W - 1 - grp;
                 if (p >= W - 1) p -= W - 1;
                 if (q >= W - 1) q -= W - 1;
             }
@@ -1723,8 +1719,8 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict_
                 q = t2;
             }
         } else {
-            p = wave;
-            q = wave + t;
+            p = grp;
+            q = grp + t;
             if (q >= BB) q -= BB;
             q += BB;
         }
@@ -1734,7 +1730,7 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict_
             T xs[KM], ys[KM];
 #pragma unroll
             for (int u = 0; u < KM; ++u) {
-                const int r = lane + 64 * u;
+                const int r = gl + G * u;
                 xs[u] = r < m ? ap[r] : T{};
                 ys[u] = r < m ? aq[r] : T{};
             }
@@ -1742,16 +1738,15 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict_
             double gr = 0, gi = 0;
 #pragma unroll
             for (int u = 0; u < KM; ++u) dot_parts(xs[u], ys[u], gr, gi);
-            gr = wave_sum(gr);
-            if (CX) gi = wave_sum(gi);
+            gr = gsum(gr);
+            if (CX) gi = gsum(gi);
             double c, sn, pr, pi, gabs;
             bool big;
             if (!(al < ng || be < ng) && rotation_fast<CX>(al, be, gr, gi, tol, c, sn, pr, pi, gabs, big)) {
                 flags |= big ? 3 : 1;
-                double aln = 0, ben = 0;
 #pragma unroll
                 for (int u = 0; u < KM; ++u) {
-                    const int r = lane + 64 * u;
+                    const int r = gl + G * u;
                     rotate_pair(xs[u], ys[u], c, sn, pr, pi);
                     if (r < m) {
                         ap[r] = xs[u];
@@ -1761,8 +1756,8 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict_
                 // |x'|^2 = c^2 al + s^2 be - 2 c s |g|,  |y'|^2 = s^2 al + c^2 be + 2 c s |g|; after strong
                 // cancellation the column's norm is taken from the rotated registers instead
                 const double cs2 = 2.0 * c * sn * gabs, c2 = c * c, s2 = sn * sn;
-                aln = fma(c2, al, fma(s2, be, -cs2));
-                ben = fma(s2, al, fma(c2, be, cs2));
+                double aln = fma(c2, al, fma(s2, be, -cs2));
+                double ben = fma(s2, al, fma(c2, be, cs2));
                 if (aln < 0.25 * al || ben < 0.25 * be) {
                     double ea = 0, eb = 0;
 #pragma unroll
@@ -1770,10 +1765,10 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict_
                         ea += abs2_t(xs[u]);
                         eb += abs2_t(ys[u]);
                     }
-                    aln = wave_sum(ea);
-                    ben = wave_sum(eb);
+                    aln = gsum(ea);
+                    ben = gsum(eb);
                 }
-                if (lane == 0) {
+                if (gl == 0) {
                     nr2[p] = aln;
                     nr2[q] = ben;
                 }
@@ -1781,42 +1776,40 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round_nov(T* __restrict_
         }
         __syncthreads();
     }
-    if (lane == 0 && flags) {        // plain stores of the same value from every rotating wave
+    if (gl == 0 && flags) {          // plain stores of the same value from every rotating group
         rotated[0] = 1;
         if (flags & 2) rotated[1] = 1;
     }
-    auto unstage = [&](int gc, int kc) {
-        if (gc < n) {
-            T* d = A + lda * gc;
-            const T* sp = As + (size_t)la * kc;
-            T t0[KM];
+    for (int kc = wave; kc < W; kc += NWV) {
+        const int gc = gcol(kc);
+        if (gc >= n) continue;
+        T* d = A + lda * gc;
+        const T* sp = As + (size_t)la * kc;
+        T t0[KW];
 #pragma unroll
-            for (int u = 0; u < KM; ++u) {
-                const int r = lane + 64 * u;
-                t0[u] = r < m ? sp[r] : T{};
-            }
-#pragma unroll
-            for (int u = 0; u < KM; ++u) {
-                const int r = lane + 64 * u;
-                if (r < m) d[r] = t0[u];
-            }
+        for (int u = 0; u < KW; ++u) {
+            const int r = lane + 64 * u;
+            t0[u] = r < m ? sp[r] : T{};
         }
-    };
-    unstage(gc0, kc0);
-    unstage(gc1, kc1);
+#pragma unroll
+        for (int u = 0; u < KW; ++u) {
+            const int r = lane + 64 * u;
+            if (r < m) d[r] = t0[u];
+        }
+    }
 }
 
-template <class T, int BB, int KM>
+template <class T, int BB, int KM, int G>
 int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nblk, int round, double tol, int* flag,
                            const double* negl) {
     const size_t lds = (size_t)2 * BB * (size_t)(k | 1) * sizeof(T) + (size_t)2 * BB * sizeof(double);
     static bool attr = false;
     if (!attr) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM>),
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM>), dim3(nblk / 2), dim3(64 * BB), lds, ctx->stream, X, ldx, k, k,
+    hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k, k,
                        nblk, round, round == 0 ? 1 : 0, tol, flag, negl);
     return QIL_OK;
 }
@@ -1833,11 +1826,17 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     if (!enabled || k < 97 || k >= 640) return QIL_OK;
     const size_t per_col = (size_t)(k | 1) * sizeof(T) + sizeof(double);
     int bb = 0;
-    // blocks of 8 columns by default: the rounds are ISSUE-bound (one wave per pair, ~130 instructions of f64 / DPP work per
-    // pair and round), so 16-column blocks -- 16 waves per CU, four per SIMD, half as many workgroups -- halve the outer
-    // rounds but serialise four pairs on every SIMD: measured 158 vs 150 ms for compress! 256 -> 128 on 24 sites
-    static const int bb_cap = getenv("QIL_SVD_LEFT_BB") ? atoi(getenv("QIL_SVD_LEFT_BB")) : 8;
-    if (bb_cap >= 16 && 32 * per_col <= 150 * 1024) bb = 16;
+    // Block / group shape (QIL_SVD_LEFT_MODE = 64 | 16, tuning aid).  A sweep over n columns is n - 1 inner rounds of n / 2
+    // pairs whatever the blocking; an inner round is issue-bound (~100 f64 / DPP instructions per pair on the wave that
+    // owns it), and every outer round pays a launch plus the staging of its columns (~8 us).  Mode 64 (default): one wave
+    // per pair, blocks of 8 columns, 512 threads = two waves per SIMD hiding each other's LDS and dependent-issue
+    // latency: 256 columns = 128 us of inner rounds + 31 x 8 us of outer rounds per sweep.  Mode 16: one 16-lane DPP row
+    // per pair, blocks of 16 columns on 256 threads (half the outer rounds, the rotation chain paid once per four pairs)
+    // -- but one wave per SIMD with all latency exposed: measured 160 vs 146 ms (f64) and 251 vs 208 ms (c64) for
+    // compress! 256 -> 128 on 24 sites.
+    static const int mode = getenv("QIL_SVD_LEFT_MODE") ? atoi(getenv("QIL_SVD_LEFT_MODE")) : 64;
+    const int G = mode == 64 ? 64 : 16;
+    if (32 * per_col <= 150 * 1024 && G == 16) bb = 16;
     else if (16 * per_col <= 150 * 1024) bb = 8;
     else return QIL_OK;
     const bool dbg = getenv("QIL_SVD_DEBUG") != nullptr;
@@ -1924,15 +1923,25 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     for (; sweeps < 40; ++sweeps) {
         QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
         for (int round = 0; round < nblk - 1; ++round) {
-#define QIL_NOV(BBv, KMv) QIL_TRY((launch_block_round_nov<T, BBv, KMv>(ctx, X, k, (int)k, nblk, round, tol, (int*)flag, (const double*)negl)))
-            if (bb == 16) {
-                if (km <= 4) QIL_NOV(16, 4);
-                else if (km <= 7) QIL_NOV(16, 7);
-                else QIL_NOV(16, 10);
+#define QIL_NOV(BBv, KMv, Gv) QIL_TRY((launch_block_round_nov<T, BBv, KMv, Gv>(ctx, X, k, (int)k, nblk, round, tol, (int*)flag, (const double*)negl)))
+            if (G == 16) {
+                const int k16 = (int)((k + 15) / 16);
+                if (bb == 16) {
+                    if (k16 <= 8) QIL_NOV(16, 8, 16);
+                    else if (k16 <= 16) QIL_NOV(16, 16, 16);
+                    else if (k16 <= 24) QIL_NOV(16, 24, 16);
+                    else if (k16 <= 32) QIL_NOV(16, 32, 16);
+                    else QIL_NOV(16, 40, 16);
+                } else {
+                    if (k16 <= 16) QIL_NOV(8, 16, 16);
+                    else if (k16 <= 24) QIL_NOV(8, 24, 16);
+                    else if (k16 <= 32) QIL_NOV(8, 32, 16);
+                    else QIL_NOV(8, 40, 16);
+                }
             } else {
-                if (km <= 4) QIL_NOV(8, 4);
-                else if (km <= 7) QIL_NOV(8, 7);
-                else QIL_NOV(8, 10);
+                if (km <= 4) QIL_NOV(8, 4, 64);
+                else if (km <= 7) QIL_NOV(8, 7, 64);
+                else QIL_NOV(8, 10, 64);
             }
 #undef QIL_NOV
         }

@@ -10,6 +10,7 @@
 // Matricisations are chosen so that every reshape is free in the canonical column-major layouts
 // and the one-sided Jacobi SVD always rotates the SHORT side (see the notes at each call site).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "qil_internal.h"
@@ -609,7 +610,7 @@ extern "C" int qil_canonicalize(qil_mps* psi, int direction, int64_t center, dou
     return canonicalize_impl(psi, direction, center, cutoff, maxdim);
 }
 
-extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps);
+static int compress_impl(qil_mps* psi, int64_t maxdim, double tol, int sweeps, bool right_canonical);
 
 // Fused apply-and-truncate: compress!(apply(W, psi); maxdim, tol, sweeps) WITHOUT ever writing the
 // (D chi)^2 product tensors.
@@ -735,6 +736,26 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
     res->site.assign((size_t)N, nullptr);
     res->site_ids = psi->site_ids;
     res->amplitude = psi->amplitude;
+    const bool fdbg = getenv("QIL_FUSED_DEBUG") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!fdbg) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[apply_compress] %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    // sketch matrix for capped bonds (one for the whole call: any sub-block of a Gaussian matrix is Gaussian)
+    static const bool sketch = !(getenv("QIL_ZIP_SKETCH") && atoi(getenv("QIL_ZIP_SKETCH")) == 0);   // tuning aid
+    void* Om = nullptr;
+    int64_t om_ld = 1;
+    if (sketch && zip_maxdim < kNoCap / 2) {
+        for (int64_t i = 0; i + 1 < N; ++i) om_ld = std::max<int64_t>(om_ld, phi->dims[(size_t)i + 1] * W->dims[(size_t)i + 1]);
+        if (zip_maxdim < om_ld) {
+            if ((st = take((size_t)(om_ld * zip_maxdim) * e, &Om)) != QIL_OK) return cleanup(st);
+            if ((st = qil_dev_fill_normal(ctx, odt, Om, om_ld * zip_maxdim, 0x51b0e7c5ull, 1.0)) != QIL_OK) return cleanup(st);
+        }
+    }
     // ---- 1. zip-up, keeping the left environments
     if ((st = one(&Lenv[0])) != QIL_OK) return cleanup(st);
     for (int64_t i = 0; i < N; ++i) {
@@ -750,9 +771,25 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
         }
         int64_t r = 0;
         void *U = nullptr, *SV = nullptr;
-        st = svd_trunc_dev(ctx, odt, 2LL * R, (int64_t)cr * Dr, theta, 2LL * R, zip_cutoff, true, zip_maxdim, 1, 2, &r, &U,
-                           &SV, nullptr);
-        if (st != QIL_OK) return cleanup(st);
+        const int64_t rows = 2LL * R, Pc = (int64_t)cr * Dr;
+        if (sketch && zip_maxdim < std::min(rows, Pc)) {
+            // capped bond: an orthonormal basis of theta Omega (Omega: Pc x zip_maxdim, seeded Gaussian) instead of
+            // theta's truncated SVD -- the variational sweep below re-optimises every site anyway, and with it the
+            // sketched zip-up reproduces the oracle's compress!(apply) on all 24 random products exactly as the SVD one
+            // does (numpy prototype, then tests); one GEMM + one thin QR + one GEMM instead of a 2r x D chi SVD
+            r = zip_maxdim;
+            void* Y = nullptr;
+            if ((st = qil_ctx_alloc(ctx, (size_t)(rows * r) * e, &Y)) != QIL_OK) return cleanup(st);
+            st = qil_dev_gemm(ctx, odt, 0, 0, rows, r, Pc, theta, rows, Om, om_ld, Y, rows);
+            if (st == QIL_OK) st = qil_dev_qr_positive(ctx, odt, rows, r, Y, rows, nullptr, 0, true);
+            if (st == QIL_OK) st = qil_ctx_alloc(ctx, (size_t)(r * Pc) * e, &SV);
+            if (st == QIL_OK) st = qil_dev_gemm(ctx, odt, odt == QIL_C64 ? 2 : 1, 0, r, Pc, rows, Y, rows, theta, rows, SV, r);
+            if (st != QIL_OK) return cleanup(st);
+            U = Y;
+        } else {
+            st = svd_trunc_dev(ctx, odt, rows, Pc, theta, rows, zip_cutoff, true, zip_maxdim, 1, 2, &r, &U, &SV, nullptr);
+            if (st != QIL_OK) return cleanup(st);
+        }
         drop(theta);
         qil_chain_adopt(res, i, U);             // [R, s, r]
         res->dims[(size_t)i] = R;
@@ -761,6 +798,7 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
         Lenv[(size_t)i + 1] = SV;               // [r, (beta, b)] == L[r, alpha, a] of the next site
         Rdim[(size_t)i + 1] = (int)r;
     }
+    lap("gauge + zip-up");
     // ---- 2. variational sweep right to left
     void* Renv = nullptr;                       // [(beta, b), r']
     int rp = 1;
@@ -803,11 +841,13 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
         Renv = Rn;
         rp = K;
     }
+    lap("variational sweep");
     (void)cleanup(QIL_OK);
     phi = nullptr;
     tmp.clear();
     // ---- 3. exact-gauge truncation
-    st = qil_compress(res, maxdim, tol, sweeps);
+    st = compress_impl(res, maxdim, tol, sweeps, true);        // the variational sweep left res right-canonical
+    lap("compress!");
     if (st != QIL_OK) {
         qil_mps_destroy(res);
         return st;
@@ -816,7 +856,16 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
     return QIL_OK;
 }
 
+static int compress_impl(qil_mps* psi, int64_t maxdim, double tol, int sweeps, bool right_canonical);
+
 extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps) {
+    return compress_impl(psi, maxdim, tol, sweeps, false);
+}
+
+// right_canonical: the caller guarantees every site but the first is a right isometry (the fused apply-and-truncate
+// after its variational sweep).  canonicalize!(:left) of such a state can neither truncate nor change anything but the
+// gauge (all its singular values are 1), so it is not run.
+static int compress_impl(qil_mps* psi, int64_t maxdim, double tol, int sweeps, bool right_canonical) {
     QIL_REQUIRE(psi, QIL_EINVAL_ARG, "compress!: null handle");
     const int64_t N = psi->n();
     QIL_REQUIRE(N >= 2, QIL_EDOMAIN, "SignalMPS must have at least 2 sites.");   // mps.jl:918
@@ -826,7 +875,7 @@ extern "C" int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps
     qil_call_scope call_scope(ctx);
     const int dt = psi->dtype;
     const double cutoff = tol * tol / ((double)(N - 1) * sweeps);               // mps.jl:920
-    QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, 1e-12, kNoCap));            // mps.jl:923
+    if (!right_canonical) QIL_TRY(canonicalize_impl(psi, QIL_DIR_LEFT, 0, 1e-12, kNoCap));            // mps.jl:923
     // The reference truncates the two-site tensor psi[j] psi[j+1] (mps.jl:929, :946).  In canonical gauge --
     // which every step of the sweep maintains -- that tensor has the same singular values and the same kept
     // subspace as the single site next to the orthogonality centre (its neighbour is an isometry), so each
