@@ -770,6 +770,38 @@ def test_device_dt_builder_bonds_and_transform(qil, pins):
             assert np.abs(qil.coefficient_batch(out, bits) - ref).max() < 5e-7 * max(1.0, np.abs(ref).max())
 
 
+def test_device_dt_builder_routes_agree_and_keep_site_ids(qil, monkeypatch):
+    """The persistent one-launch builder, its launch-per-step fallback (forced here through a tiny in-LDS capacity and
+    through QIL_DT_BUILDER) and the host chain give the same operators; MPOs built for a ZTMPS carry ITS site labels at
+    every n (build_dt_mpo(psi::ZTMPS, ...) builds on psi's sites, dt_transformer.jl:409-412)."""
+    n = 9
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    psi0 = qil.signal_ztmps(x, cutoff=1e-13)
+    ids = [100 + 3 * i for i in range(2 * n)]
+    psi = qil.ZTMPS(psi0.to_host(), amplitude=psi0.amplitude, sites=ids)
+    sig = [0.25, 1.0, 2 * np.pi]
+    bits = np.random.default_rng(2).integers(0, 2, size=(256, 2 * n)).astype(np.uint8)
+    Wp = qil.build_dt_mpo_batch(psi, sig)
+    assert all(W.site_ids == ids for W in Wp)
+    ref = [qil.coefficient_batch(W * psi, bits) for W in Wp]                 # apply checks the site labels
+    monkeypatch.setenv("QIL_DT_DCAP", "8")                                    # truncated bonds > 4 overflow -> fallback
+    Wf = qil.build_dt_mpo_batch(psi, sig)
+    monkeypatch.delenv("QIL_DT_DCAP")
+    monkeypatch.setenv("QIL_DT_BUILDER", "launches")
+    Wl = qil.build_dt_mpo_batch(psi, sig)
+    monkeypatch.delenv("QIL_DT_BUILDER")
+    for Ws in (Wf, Wl):
+        assert all(W.site_ids == ids for W in Ws)
+        for W, r in zip(Ws, ref):
+            assert np.abs(qil.coefficient_batch(W * psi, bits) - r).max() < 1e-13 * np.abs(r).max()
+    host = qil.build_dt_mpo(psi, 1.0, device=False)
+    one = qil.build_dt_mpo(psi, 1.0)                                          # n >= 8: device route
+    assert one.site_ids == ids == host.site_ids
+    assert np.abs(qil.coefficient_batch(one * psi, bits) - qil.coefficient_batch(host * psi, bits)).max() < 1e-12
+    zt = qil.build_zt_mpo(psi, 2 * np.pi)
+    assert zt.site_ids == ids and (zt * psi).site_ids == ids
+
+
 # ---------------------------------------------------------------- fused apply-and-truncate (SURVEY 8f-2)
 @pytest.mark.parametrize("wdt,adt", [(np.float64, np.float64), (np.complex128, np.float64), (np.complex128, np.complex128)])
 def test_apply_compress_lossless_equals_apply(qil, wdt, adt):
