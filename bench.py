@@ -462,7 +462,7 @@ def run_sweep(args, rk):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 400 applies (>= 5 s timed) / 20 sweeps")
+    ap.add_argument("--steps", type=int, default=None, help="default: 1000 applies (12 s timed) / 40 sweeps (9 s)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="zt_n24_chi64_D128", choices=sorted(WORKLOADS))
     ap.add_argument("--queries", type=int, default=64, help="coefficient samples for max|coeff err|")
@@ -471,7 +471,7 @@ def main():
     args = ap.parse_args()
     sweep = args.workload == "dt_sweep_n24_s64"
     if args.steps is None:
-        args.steps = 20 if sweep else 400
+        args.steps = 40 if sweep else 1000
     if args.warmup is None:
         args.warmup = 2 if sweep else 3
 
