@@ -950,6 +950,33 @@ def test_qr_rank_deficient_inputs(qil, m, l, dt):
     assert 3 <= int(d.sum()) <= 6                                          # numerical rank ~4
 
 
+@pytest.mark.parametrize("m,n,rank", [(400, 96, 40), (512, 256, 100), (700, 130, 130), (520, 160, 7)])
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+def test_qr_blocked_panels_with_dependent_columns(qil, m, n, rank, dt):
+    """Blocked QR with Householder panels in LDS (hh_panel): exactly dependent columns inside a panel and across panels
+    (every column a combination of `rank` generators, duplicates included) come out as ZERO columns of Q with zero rows
+    of R, the others orthonormal, Q R = A, diag(R) real >= 0, and exactly `rank` columns survive."""
+    rng = np.random.default_rng(1234 + m + n)
+    G = lambda *s: rng.standard_normal(s) + (1j * rng.standard_normal(s) if dt == np.complex128 else 0)
+    C = G(rank, n)
+    C[:, : min(rank, n)] += 3 * np.eye(rank, n)[:, : min(rank, n)]          # the first `rank` columns independent
+    A = G(m, rank) @ C
+    if n > rank + 2:
+        A[:, rank + 1] = A[:, 0]                                             # an exact duplicate, a scaled duplicate
+        A[:, rank + 2] = -2.5 * A[:, 1]
+    Q, R = qil.qr_positive(A)
+    Gm = Q.conj().T @ Q
+    d = np.real(np.diag(Gm))
+    assert np.all((np.abs(d - 1) < 1e-12) | (d == 0)), d
+    assert np.abs(Gm - np.diag(d)).max() < 1e-10
+    assert np.abs(Q @ R - A).max() < 1e-11 * np.abs(A).max()
+    assert np.all(np.real(np.diag(R)) >= 0) and np.abs(np.imag(np.diag(R))).max() == 0
+    assert np.abs(np.tril(R, -1)).max() == 0
+    assert int(round(d.sum())) == rank, (int(round(d.sum())), rank)
+    dead = d == 0
+    assert np.abs(R[dead, :]).max(initial=0.0) == 0                          # zero rows for dropped columns
+
+
 def test_qr_full_rank_matches_lapack_up_to_phase(qil):
     rng = np.random.default_rng(82)
     for shape in ((64, 33), (200, 40), (3000, 70)):
