@@ -940,10 +940,33 @@ __global__ void pb_copy_out(const double* __restrict__ ws, long long site_cap, i
 
 }  // namespace
 
+static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff, int64_t maxdim,
+                         const int64_t* site_ids, qil_mpo** out, int* fallback);
+
 // Returns QIL_OK with *fallback = 1 when some value exceeded the in-LDS capacities (caller takes the
-// launch-per-step route); out[] untouched in that case.
+// launch-per-step route); out[] holds no handles in that case.  Large sweeps go through in chunks so that the
+// per-value workspace (2 chains x 2n sites x 86 KB) stays within ~8 GiB.
 int qil_build_dt_persistent(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff, int64_t maxdim,
                             const int64_t* site_ids, qil_mpo** out, int* fallback) {
+    *fallback = 0;
+    const int64_t per_value = 2 * (2 * n) * (52LL * 4 * 52) * (int64_t)sizeof(double);
+    const int64_t chunk = std::max<int64_t>(256, (8LL << 30) / std::max<int64_t>(per_value, 1));
+    for (int64_t off = 0; off < nb; off += chunk) {
+        const int64_t cnt = std::min(chunk, nb - off);
+        int st = persist_chunk(ctx, n, cnt, wrs + off, cutoff, maxdim, site_ids, out + off, fallback);
+        if (st != QIL_OK || *fallback) {
+            for (int64_t b = 0; b < off; ++b) {
+                qil_mpo_destroy(out[b]);
+                out[b] = nullptr;
+            }
+            return st;
+        }
+    }
+    return QIL_OK;
+}
+
+static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff, int64_t maxdim,
+                         const int64_t* site_ids, qil_mpo** out, int* fallback) {
     *fallback = 0;
     const int L = (int)(2 * n);
     if (L > PB_MAXL) {
