@@ -43,6 +43,115 @@ int copy_2d(qil_context* ctx, int dtype, int64_t rows, int64_t cols, const void*
     return QIL_OK;
 }
 
+// out[2 * block] += |A - D|_F^2 over this block's elements, out[2 * block + 1] += |A|_F^2   (A: lda, D: ldd; doubles viewed
+// as reals: nre = 1 real / 2 complex values per element)
+__global__ __launch_bounds__(256) void residual_sumsq(const double* __restrict__ A, long long lda, const double* __restrict__ D,
+                                                       long long ldd, long long m, long long n, int nre,
+                                                       double* __restrict__ out) {
+    __shared__ double red[8];
+    double r2 = 0, a2 = 0;
+    const long long rows = m * nre;
+    for (long long t = blockIdx.x * 256LL + threadIdx.x; t < rows * n; t += (long long)gridDim.x * 256) {
+        const long long i = t % rows, j = t / rows;
+        const double a = A[i + lda * nre * j], d = D[i + ldd * nre * j];
+        r2 = fma(a - d, a - d, r2);
+        a2 = fma(a, a, a2);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        r2 += __shfl_xor(r2, o);
+        a2 += __shfl_xor(a2, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave] = r2;
+        red[4 + wave] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        out[2 * blockIdx.x + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, double cutoff,
+                  bool use_cutoff, int64_t maxdim, int64_t mindim, int absorb, int64_t* rank, void** U_out,
+                  void** Vh_out, std::vector<double>* S_out);
+
+// Low-rank fast path of a TRUNCATING SVD of a large operand (every product bond before its truncation is heavily
+// rank-deficient: bond 1008 of the zT product carries ~60 singular values above 1e-6 of the largest).  Range finder
+// with one power iteration, Q = orth(A (A^H (A Omega))) (k = 128 columns, then 256), B = Q^H A, and the residual
+// |A - Q B|_F^2 is MEASURED: the path is taken only if it is below 1e-8 of the weight the caller's cutoff allows to be
+// discarded -- then the truncation rule sees the same decision as on A itself -- and the truncated SVD of the k x n
+// matrix B gives the factors (U = Q U_B).  Otherwise *done = 0 and A is intact.
+static int svd_trunc_lowrank(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, double cutoff,
+                             int64_t maxdim, int64_t mindim, int absorb, int64_t* rank, void** U_out, void** Vh_out,
+                             std::vector<double>* S_out, int* done) {
+    *done = 0;
+    static const bool enabled = !(getenv("QIL_SVD_LOWRANK") && atoi(getenv("QIL_SVD_LOWRANK")) == 0);   // tuning aid
+    const int64_t r0 = std::min(m, n);
+    if (!enabled || r0 < 384 || !(cutoff > 0)) return QIL_OK;
+    const size_t e = qil_elem_size(dtype);
+    const int cj = dtype == QIL_C64 ? 2 : 1;
+    const int nre = dtype == QIL_C64 ? 2 : 1;
+    for (int64_t k : {(int64_t)128, (int64_t)256}) {
+        if (k * 3 > r0) break;
+        void *Om = nullptr, *Y = nullptr, *Z = nullptr, *B = nullptr, *D = nullptr, *part = nullptr;
+        auto release = [&]() {
+            for (void* b : {Om, Y, Z, B, D, part})
+                if (b) qil_ctx_free(ctx, b);
+        };
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * k) * e, &Om));
+        QIL_TRY(qil_dev_fill_normal(ctx, dtype, Om, n * k, 0x10a4c0deull + (uint64_t)k, 1.0));
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * k) * e, &Y));
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * k) * e, &Z));
+        QIL_TRY(qil_dev_gemm(ctx, dtype, 0, 0, m, k, n, A, lda, Om, n, Y, m));                       // Y = A Omega
+        QIL_TRY(qil_dev_qr_positive(ctx, dtype, m, k, Y, m, nullptr, 0, false));
+        QIL_TRY(qil_dev_gemm(ctx, dtype, cj, 0, n, k, m, A, lda, Y, m, Z, n));                       // Z = A^H Y
+        QIL_TRY(qil_dev_qr_positive(ctx, dtype, n, k, Z, n, nullptr, 0, false));
+        QIL_TRY(qil_dev_gemm(ctx, dtype, 0, 0, m, k, n, A, lda, Z, n, Y, m));                        // Y = A Z
+        QIL_TRY(qil_dev_qr_positive(ctx, dtype, m, k, Y, m, nullptr, 0, true));                      // Q (orthonormal)
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * n) * e, &B));
+        QIL_TRY(qil_dev_gemm(ctx, dtype, cj, 0, k, n, m, Y, m, A, lda, B, k));                       // B = Q^H A
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &D));
+        QIL_TRY(qil_dev_gemm(ctx, dtype, 0, 0, m, n, k, Y, m, B, k, D, m));                          // D = Q B
+        const unsigned nblk_ = (unsigned)std::min<long long>((m * n * nre + 255) / 256, 1024);
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)nblk_ * 2 * sizeof(double), &part));
+        hipLaunchKernelGGL(residual_sumsq, dim3(nblk_), dim3(256), 0, ctx->stream, (const double*)A, (long long)lda,
+                           (const double*)D, (long long)m, (long long)m, (long long)n, nre, (double*)part);
+        std::vector<double> hp((size_t)nblk_ * 2);
+        QIL_HIP(hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        double rho = 0, tot = 0;
+        for (unsigned b = 0; b < nblk_; ++b) {
+            rho += hp[2 * b];
+            tot += hp[2 * b + 1];
+        }
+        if (getenv("QIL_SVD_DEBUG")) fprintf(stderr, "[svd-lowrank] %lld x %lld, k = %lld: residual^2 / total = %.3e (cutoff %.1e)\n",
+                                             (long long)m, (long long)n, (long long)k, tot > 0 ? rho / tot : 0.0, cutoff);
+        if (!(rho <= 1e-8 * cutoff * tot)) {
+            release();
+            continue;
+        }
+        int64_t r = 0;
+        void *Ub = nullptr, *Vh = nullptr;
+        std::vector<double> S;
+        int st = svd_trunc_dev(ctx, dtype, k, n, B, k, cutoff, true, maxdim, mindim, absorb, &r, &Ub, &Vh, &S);
+        if (st != QIL_OK) return st;
+        void* U = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * std::min(m, n)) * e, &U));     // callers index U with ld m only
+        QIL_TRY(qil_dev_gemm(ctx, dtype, 0, 0, m, r, k, Y, m, Ub, k, U, m));                         // U = Q U_B
+        qil_ctx_free(ctx, Ub);
+        release();
+        *rank = r;
+        *U_out = U;
+        *Vh_out = Vh;
+        if (S_out) *S_out = std::move(S);
+        *done = 1;
+        return QIL_OK;
+    }
+    return QIL_OK;
+}
+
 // Truncated SVD of the device matrix A (m x n, lda; destroyed).  Outputs are fresh pool blocks:
 //   U  (m x r, ld m)   -- optionally scaled by S (absorb = 1)
 //   Vh (r x n, ld r)   -- optionally scaled by S (absorb = 2)
@@ -51,6 +160,11 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
                   void** Vh_out, std::vector<double>* S_out) {
     const int64_t r0 = std::min(m, n);
     const size_t e = qil_elem_size(dtype);
+    if (use_cutoff) {
+        int done = 0;
+        QIL_TRY(svd_trunc_lowrank(ctx, dtype, m, n, A, lda, cutoff, maxdim, mindim, absorb, rank, U_out, Vh_out, S_out, &done));
+        if (done) return QIL_OK;
+    }
     void *U = nullptr, *Vh = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * r0) * e, &U));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r0 * n) * e, &Vh));

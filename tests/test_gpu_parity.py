@@ -977,6 +977,25 @@ def test_qr_blocked_panels_with_dependent_columns(qil, m, n, rank, dt):
     assert np.abs(R[dead, :]).max(initial=0.0) == 0                          # zero rows for dropped columns
 
 
+@pytest.mark.parametrize("m,n,r,cplx", [(900, 700, 50, False), (1008, 2016, 60, True), (2016, 1008, 110, False),
+                                        (800, 600, 200, False)])
+def test_svd_trunc_low_rank_fast_path(qil, m, n, r, cplx):
+    """Large truncating SVDs of rank-deficient operands (what every product bond is before its truncation) take a
+    range-finder route whose residual |A - Q Q^H A|_F^2 is MEASURED against the cutoff before it is trusted; the last
+    case (rank 200 > the 128-column sketch, 3 x 256 > 600) must fall back to the full SVD.  Either way: LAPACK's
+    singular values, the ITensors rank, A = U S Vh, isometric factors."""
+    rng = np.random.default_rng(17)
+    G = lambda *s: rng.standard_normal(s) + (1j * rng.standard_normal(s) if cplx else 0)
+    A = (G(m, r) * np.logspace(0, -5, r)) @ G(r, n)
+    A += 1e-17 * np.abs(A).max() * G(m, n)
+    Sref = np.linalg.svd(A, compute_uv=False)
+    U, S, Vh = qil.svd_trunc(A, cutoff=1e-12)
+    assert len(S) == O.truncation_rank(Sref, cutoff=1e-12) == r
+    assert np.abs(S - Sref[:r]).max() <= 1e-13 * Sref[0]
+    assert np.abs((U * S) @ Vh - A).max() <= 1e-12 * np.abs(A).max()
+    assert np.abs(U.conj().T @ U - np.eye(r)).max() < 1e-12 and np.abs(Vh @ Vh.conj().T - np.eye(r)).max() < 1e-12
+
+
 def test_qr_full_rank_matches_lapack_up_to_phase(qil):
     rng = np.random.default_rng(82)
     for shape in ((64, 33), (200, 40), (3000, 70)):
