@@ -305,7 +305,8 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     const bool can_split = bt.count == 1 || (ldc == m && bt.c_bs == m * n && !bt.cmap);
     // few output tiles + long K (projections Q^H P, sketches of skinny panels): split K over the chip
     int splits = 1;
-    if (can_split && tiles * bt.count < 128 && k >= 1024)
+    static const long long split_min_k = getenv("QIL_GEMM_SPLIT_MIN_K") ? atoll(getenv("QIL_GEMM_SPLIT_MIN_K")) : 1024;   // tuning aid (512: exact compress! of the bond-1008 product 572 -> 534 ms, compress! 512 -> 256 330 -> 355 ms)
+    if (can_split && tiles * bt.count < 128 && k >= split_min_k)
         splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / (tiles * bt.count)), 64);
     if (splits < 2) splits = 1;
     long long kchunk = k, cstride = 0, c_bs = bt.c_bs;
@@ -2448,7 +2449,8 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     // not fit LDS (complex panels above ~580 rows): its 512-row chunks do, and a single workgroup factoring such a
     // panel out of L2 takes ~290 us instead of three short launches
     const bool panel16_fits = ((size_t)32 + (size_t)(m | 1) * 16) * sizeof(T) <= 150 * 1024;
-    const bool tree = m >= TALL || (!panel16_fits && m >= 1024);
+    static const long long tree_min = getenv("QIL_TSQR_NOFIT_ROWS") ? atoll(getenv("QIL_TSQR_NOFIT_ROWS")) : 1024;       // tuning aid (768: neutral)
+    const bool tree = m >= TALL || (!panel16_fits && m >= tree_min);
     if (n <= 16 || fits_lds) {
         if (tree && n <= 16) {
             void* nb0 = nullptr;
