@@ -53,9 +53,9 @@ struct PbState {
     double blk[16];
     int blk_dl, blk_dr;
     double kap[PB_DMAX], dif[PB_DMAX], beta[PB_DMAX];
-    double sig[PB_DMAX], inv[PB_DMAX];
+    double sig[PB_DMAX], inv[PB_DMAX], nrp[PB_DMAX];
     int perm[PB_DMAX], act[PB_DMAX];
-    int rank, rot, err, nact;
+    int rank, rot, rot2, err, nact;
     double red[8];
     unsigned long long cyc[PB_NCYC], t0;
 };
@@ -442,7 +442,10 @@ __device__ void pb_jacobi_t(double* A, int lda, int m, int n, PbState& st, doubl
             v = pb_gsum<G>(v);
             if (lane == 0) st.sig[j] = v;
         }
-        if (tid == 0) st.rot = 0;
+        if (tid == 0) {
+            st.rot = 0;
+            st.rot2 = 0;
+        }
         __syncthreads();
         if (tid < n) {
             // rank of this column among the kept ones; all norms read into registers first (one LDS latency, not n)
@@ -456,7 +459,10 @@ __device__ void pb_jacobi_t(double* A, int lda, int m, int n, PbState& st, doubl
                 pos += kq && q < tid;
                 tot += kq;
             }
-            if (keep) st.act[pos] = tid;
+            if (keep) {
+                st.act[pos] = tid;
+                st.nrp[pos] = mine;                 // squared norm by tournament position: read together with act[]
+            }
             if (tid == 0) st.nact = tot;
         }
         __syncthreads();
@@ -476,8 +482,10 @@ __device__ void pb_jacobi_t(double* A, int lda, int m, int n, PbState& st, doubl
                     if (q >= npad - 1) q -= npad - 1;
                 }
                 if (p >= nact || q >= nact) continue;
-                double* ap = A + lda * st.act[p];
-                double* aq = A + lda * st.act[q];
+                const int cp = st.act[p], cq = st.act[q];
+                const double al = st.nrp[p], be = st.nrp[q];
+                double* ap = A + lda * cp;
+                double* aq = A + lda * cq;
                 double x[MU], y[MU];
 #pragma unroll
                 for (int u = 0; u < MU; ++u) {
@@ -485,35 +493,55 @@ __device__ void pb_jacobi_t(double* A, int lda, int m, int n, PbState& st, doubl
                     x[u] = r < m ? ap[r] : 0.0;
                     y[u] = r < m ? aq[r] : 0.0;
                 }
-                double al = 0, be = 0, g = 0;
+                // squared norms are carried in st.nrp (exact at the start of every sweep, updated with each rotation):
+                // one reduction per pair instead of three
+                double g = 0;
 #pragma unroll
-                for (int u = 0; u < MU; ++u) {
-                    al = fma(x[u], x[u], al);
-                    be = fma(y[u], y[u], be);
-                    g = fma(x[u], y[u], g);
-                }
-                al = pb_gsum<G>(al);
-                be = pb_gsum<G>(be);
+                for (int u = 0; u < MU; ++u) g = fma(x[u], y[u], g);
                 g = pb_gsum<G>(g);
                 if (al < negligible || be < negligible) continue;
                 double c, sn;
                 bool big;
                 if (!pb_rotation(al, be, g, tol, c, sn, big)) continue;
-                if (lane == 0) atomicOr(&st.rot, big ? 3 : 1);
+                if (lane == 0) {                      // plain stores of the same value from every rotating pair
+                    st.rot = 1;
+                    if (big) st.rot2 = 1;
+                }
                 const double sg = g >= 0 ? sn : -sn;
 #pragma unroll
                 for (int u = 0; u < MU; ++u) {
                     const int r = lane + G * u;
+                    const double xn = fma(-sg, y[u], c * x[u]), yn = fma(sg, x[u], c * y[u]);
+                    x[u] = xn;
+                    y[u] = yn;
                     if (r < m) {
-                        ap[r] = fma(-sg, y[u], c * x[u]);
-                        aq[r] = fma(sg, x[u], c * y[u]);
+                        ap[r] = xn;
+                        aq[r] = yn;
                     }
+                }
+                // |x'|^2 = c^2 al + s^2 be - 2 c s |g|, |y'|^2 = s^2 al + c^2 be + 2 c s |g|; after strong cancellation
+                // the norm is taken from the rotated registers instead
+                const double cs2 = 2.0 * c * sn * fabs(g), c2 = c * c, s2 = sn * sn;
+                double aln = fma(c2, al, fma(s2, be, -cs2)), ben = fma(s2, al, fma(c2, be, cs2));
+                if (aln < 0.25 * al || ben < 0.25 * be) {
+                    double ea = 0, eb = 0;
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) {
+                        ea = fma(x[u], x[u], ea);
+                        eb = fma(y[u], y[u], eb);
+                    }
+                    aln = pb_gsum<G>(ea);
+                    ben = pb_gsum<G>(eb);
+                }
+                if (lane == 0) {
+                    st.nrp[p] = aln;
+                    st.nrp[q] = ben;
                 }
             }
             __syncthreads();
         }
         rounds += npad - 1;
-        const int any = st.rot;
+        const int any = st.rot2 ? 2 : 0;
         __syncthreads();
         if (!(any & 2)) {
             ++sweeps;
