@@ -57,9 +57,15 @@ __device__ __forceinline__ double wave_sum(double v) {
     v = row16_sum(v);
     return (read_lane_d(v, 0) + read_lane_d(v, 16)) + (read_lane_d(v, 32) + read_lane_d(v, 48));
 }
+// every lane of a 32-lane half ends with that half's total
+__device__ __forceinline__ double half32_sum(double v) {
+    v = row16_sum(v);
+    const double lo = read_lane_d(v, 0) + read_lane_d(v, 16), hi = read_lane_d(v, 32) + read_lane_d(v, 48);
+    return (threadIdx.x & 32) ? hi : lo;
+}
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
-    return G == 16 ? row16_sum(v) : wave_sum(v);
+    return G == 16 ? row16_sum(v) : G == 32 ? half32_sum(v) : wave_sum(v);
 }
 
 // sums `NV` doubles per thread across a 256-thread workgroup; result valid in all threads

@@ -1611,54 +1611,84 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
 // values).  Half the LDS per column => blocks of 16 columns instead of 8 (15 outer rounds per sweep at 256 columns
 // instead of 31), half the rotation work per pair, cached squared norms (one wave reduction per pair instead of three).
 
-// rotation of a column pair from |x|^2 = al, |y|^2 = be, x^H y = gr + i gi (see pb_rotation in qil_build_persist.hip):
-// c, s (signed by be - al), the phase e^{i phi} = g / |g| and |g|
+// Rotation of a column pair from |x|^2 = al, |y|^2 = be, x^H y = gr + i gi:  x' = c x - conj(sg) y,  y' = sg x + c y with
+// sg = s e^{i phi} = (sr, si), e^{i phi} = g / |g|, s signed by be - al; sabs = |sg|, gabs ~ |g|.
+// The dependent chain of this computation sits on the critical path of every inner round, so it is kept short: the angle comes
+// from the raw hardware reciprocal square roots (relative error ~1e-8, which only decides how completely THIS pair is
+// annihilated -- quadratic convergence absorbs it), and unitarity, which must hold to rounding because the errors of
+// thousands of rotations add up in the singular values, is restored exactly afterwards: with eps = c0^2 + |sg0|^2 - 1
+// (|eps| < 1e-6) both are scaled by 1 / sqrt(1 + eps) = 1 - eps / 2 + 3 eps^2 / 8 + O(eps^3 < 1e-18).
 template <bool CX>
-__device__ __forceinline__ bool rotation_fast(double al, double be, double gr, double gi, double tol, double& c, double& s,
-                                              double& pr, double& pi, double& gabs, bool& big) {
+__device__ __forceinline__ bool rotation_fast(double al, double be, double gr, double gi, double tol, double& c, double& sr,
+                                              double& si, double& sabs, double& gabs, bool& big) {
     const double g2 = CX ? fma(gr, gr, gi * gi) : gr * gr;
     const double ab = al * be;
     big = g2 > kQuadraticOff * kQuadraticOff * ab;
     if (!(g2 > tol * tol * ab) || g2 == 0.0) return false;
     const double d = be - al;
-    const double rh = rsqrt_refined(fma(d, d, 4.0 * g2));
+    const double rh = __builtin_amdgcn_rsq(fma(d, d, 4.0 * g2));
     const double c2 = fma(0.5 * fabs(d), rh, 0.5);
-    const double rc = rsqrt_refined(c2);
-    c = c2 * rc;
-    if (CX) {
-        const double ig = rsqrt_refined(g2);
-        gabs = g2 * ig;
-        pr = gr * ig;
-        pi = gi * ig;
-    } else {
-        gabs = fabs(gr);
-        pr = gr >= 0 ? 1.0 : -1.0;
-        pi = 0.0;
-    }
-    s = copysign(gabs * rh * rc, d);
+    const double rc = __builtin_amdgcn_rsq(c2);
+    const double c0 = c2 * rc;
+    const double q = copysign(rh * rc, d);            // sg0 = q g
+    const double sr0 = q * gr, si0 = CX ? q * gi : 0.0;
+    const double s02 = CX ? fma(sr0, sr0, si0 * si0) : sr0 * sr0;
+    const double eps = fma(c0, c0, s02 - 1.0);
+    const double f = fma(eps, fma(eps, 0.375, -0.5), 1.0);
+    c = c0 * f;
+    sr = sr0 * f;
+    si = si0 * f;
+    // |sg| and |g| only feed the carried norms (re-taken from the data at every staging): raw accuracy is enough
+    gabs = CX ? g2 * __builtin_amdgcn_rsq(g2) : fabs(gr);
+    sabs = fabs(q) * gabs * f;
     return true;
 }
+__device__ __forceinline__ void rotate_pair_sg(double& x, double& y, double c, double sr, double) {
+    const double xn = fma(c, x, -sr * y), yn = fma(sr, x, c * y);
+    x = xn;
+    y = yn;
+}
+__device__ __forceinline__ void rotate_pair_sg(c64& x, c64& y, double c, double sr, double si) {
+    // x' = c x - conj(sg) y ;  y' = sg x + c y
+    const c64 xn{fma(c, x.re, -fma(sr, y.re, si * y.im)), fma(c, x.im, -fma(sr, y.im, -si * y.re))};
+    const c64 yn{fma(c, y.re, fma(sr, x.re, -si * x.im)), fma(c, y.im, fma(sr, x.im, si * x.re))};
+    x = xn;
+    y = yn;
+}
 
-// G lanes per column pair (64 = one wave per pair, 16 = one DPP row per pair: four pairs share a wave's instruction
-// stream, so the ~40 instructions of the rotation and the reduction tree are paid once per four pairs), KM = rows per
-// lane (m <= G KM), BB columns per block; BB G threads.
-template <class T, int BB, int KM, int G>
+// One outer round of the block tournament without V: workgroup i holds the column blocks (P, Q) of this round in LDS and
+// orthogonalises their column pairs in BB (cross pairs; AP: all 2 BB - 1 rounds of all pairs) inner rounds.
+// G lanes per column pair (64 = one wave per pair, 32 = two pairs per wave sharing the instruction stream of the rotation),
+// KM = rows per lane, BB columns per block; BB G threads.  The inner round is issue-bound (~130 instructions on the wave
+// that owns a pair), so it carries no predicates at all: the LDS image of a column has KM G rows, zero beyond m, every lane
+// loads and stores all its KM elements, and whether the first round's pairing (AP) applies is a compile-time switch.  In
+// cross rounds group `grp` keeps column p = grp of the lower block in registers over all BB inner rounds; only its partner
+// travels through LDS.  (Measured, tools/micro/jacobi_round_cost.hip, k = 256 f64: the predicated version spent 1.07 us per
+// inner round -- ~40 exec-mask branches -- of a 12.1 us round.)
+template <class T, int BB, int KM, int G, bool AP, bool PROF = false>
 __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__ A, long long lda, int m, int n, int nb,
-                                                                 int round, int all_pairs, double tol,
-                                                                 int* __restrict__ rotated,
-                                                                 const double* __restrict__ negligible) {
+                                                                 int round, double tol, int* __restrict__ rotated,
+                                                                 const double* __restrict__ negligible,
+                                                                 long long* __restrict__ prof = nullptr) {
+    // PROF (tools/micro/jacobi_round_cost.hip only): shader-clock stamps start / staged / rotated / stored + the 100 MHz clock
+    long long st[5];
+    if (PROF) {
+        st[0] = __builtin_amdgcn_s_memtime();
+        st[4] = __builtin_amdgcn_s_memrealtime();
+    }
     constexpr int W = 2 * BB;
     constexpr int NT = BB * G;
     constexpr int NWV = NT / 64;                    // waves
-    constexpr int KW = (KM * G + 63) / 64;          // rows per lane when a whole wave walks a column
+    constexpr int ROWS = KM * G;                    // LDS rows of a column (>= m)
+    constexpr int KW = ROWS / 64;                   // rows per lane when a whole wave walks a column
+    static_assert(ROWS % 64 == 0, "whole waves walk a column");
     constexpr bool CX = sizeof(T) == 16;
     extern __shared__ __attribute__((aligned(16))) char jn_smem[];
-    const int la = m | 1;
-    T* As = reinterpret_cast<T*>(jn_smem);
-    double* nr2 = reinterpret_cast<double*>(As + (size_t)la * W);
+    T* As = reinterpret_cast<T*>(jn_smem);          // [W][ROWS]
+    double* nr2 = reinterpret_cast<double*>(As + (size_t)ROWS * W);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gl = tid & (G - 1), grp = tid / G;    // lane within the pair's group, group = pair slot
-    auto gsum = [](double v) { return G == 16 ? row16_sum(v) : wave_sum(v); };
+    auto gsum = [](double v) { return group_sum<G>(v); };
     int P, Q;
     {
         const int i = blockIdx.x;
@@ -1677,34 +1707,53 @@ __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__
     }
     auto gcol = [&](int k) { return (k < BB ? P * BB + k : Q * BB + (k - BB)); };
     if (P * BB >= n) return;                               // both blocks are padding
-    // staging: the waves share the 2 BB columns; squared norms are taken on the way
-    for (int kc = wave; kc < W; kc += NWV) {
-        const int gc = gcol(kc);
-        const T* s0 = A + lda * gc;
-        T t0[KW];
+    // staging: the waves share the 2 BB columns (all of a wave's loads in flight at once); squared norms are taken on the way
+    constexpr int CPW = W / NWV;
+    static_assert(W % NWV == 0, "whole columns per wave");
+    {
+        T t0[CPW][KW];
 #pragma unroll
-        for (int u = 0; u < KW; ++u) {
-            const int r = lane + 64 * u;
-            t0[u] = (gc < n && r < m) ? s0[r] : T{};
-        }
-        T* d0 = As + (size_t)la * kc;
-        double n0 = 0;
+        for (int cc = 0; cc < CPW; ++cc) {
+            const int gc = gcol(wave + cc * NWV);
+            const bool cv = gc < n;
+            const T* s0 = A + lda * (cv ? gc : 0);
+            // rows / columns beyond the matrix: a valid address is loaded and the value multiplied by 0 (a select would be
+            // turned into a branch around each load, with a wait inside -- eight serialised round trips to memory)
 #pragma unroll
-        for (int u = 0; u < KW; ++u) {
-            const int r = lane + 64 * u;
-            if (r < m) d0[r] = t0[u];
-            n0 += abs2_t(t0[u]);
+            for (int u = 0; u < KW; ++u) {
+                const int r = lane + 64 * u;
+                t0[cc][u] = scale_t(s0[r < m ? r : 0], (cv && r < m) ? 1.0 : 0.0);
+            }
         }
-        n0 = wave_sum(n0);
-        if (lane == 0) nr2[kc] = n0;
+#pragma unroll
+        for (int cc = 0; cc < CPW; ++cc) {
+            T* d0 = As + ROWS * (wave + cc * NWV);
+            double n0 = 0;
+#pragma unroll
+            for (int u = 0; u < KW; ++u) {
+                d0[lane + 64 * u] = t0[cc][u];
+                n0 += abs2_t(t0[cc][u]);
+            }
+            n0 = wave_sum(n0);
+            if (lane == 0) nr2[wave + cc * NWV] = n0;
+        }
     }
     __syncthreads();
+    if (PROF) st[1] = __builtin_amdgcn_s_memtime();
     const double ng = negligible ? *negligible : 0.0;
     int flags = 0;
-    const int nin = all_pairs ? W - 1 : BB;
+    constexpr int nin = AP ? W - 1 : BB;
+    T xs[KM];
+    double alk = 0;
+    if (!AP) {
+        const T* ap = As + ROWS * grp;
+#pragma unroll
+        for (int u = 0; u < KM; ++u) xs[u] = ap[gl + G * u];
+        alk = nr2[grp];
+    }
     for (int t = 0; t < nin; ++t) {
         int p, q;
-        if (all_pairs) {
+        if (AP) {
             if (grp == 0) {
                 p = W - 1;
                 q = t;
@@ -1726,37 +1775,33 @@ __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__
             q += BB;
         }
         if (gcol(p) < n && gcol(q) < n) {
-            T* ap = As + (size_t)la * p;
-            T* aq = As + (size_t)la * q;
-            T xs[KM], ys[KM];
+            T* ap = As + ROWS * p;
+            T* aq = As + ROWS * q;
+            T ys[KM];
 #pragma unroll
             for (int u = 0; u < KM; ++u) {
-                const int r = gl + G * u;
-                xs[u] = r < m ? ap[r] : T{};
-                ys[u] = r < m ? aq[r] : T{};
+                if (AP) xs[u] = ap[gl + G * u];
+                ys[u] = aq[gl + G * u];
             }
-            const double al = nr2[p], be = nr2[q];
+            const double al = AP ? nr2[p] : alk, be = nr2[q];
             double gr = 0, gi = 0;
 #pragma unroll
             for (int u = 0; u < KM; ++u) dot_parts(xs[u], ys[u], gr, gi);
             gr = gsum(gr);
             if (CX) gi = gsum(gi);
-            double c, sn, pr, pi, gabs;
+            double c, sr, si, sn, gabs;
             bool big;
-            if (!(al < ng || be < ng) && rotation_fast<CX>(al, be, gr, gi, tol, c, sn, pr, pi, gabs, big)) {
+            if (!(al < ng || be < ng) && rotation_fast<CX>(al, be, gr, gi, tol, c, sr, si, sn, gabs, big)) {
                 flags |= big ? 3 : 1;
 #pragma unroll
                 for (int u = 0; u < KM; ++u) {
-                    const int r = gl + G * u;
-                    rotate_pair(xs[u], ys[u], c, sn, pr, pi);
-                    if (r < m) {
-                        ap[r] = xs[u];
-                        aq[r] = ys[u];
-                    }
+                    rotate_pair_sg(xs[u], ys[u], c, sr, si);
+                    if (AP) ap[gl + G * u] = xs[u];
+                    aq[gl + G * u] = ys[u];
                 }
                 // |x'|^2 = c^2 al + s^2 be - 2 c s |g|,  |y'|^2 = s^2 al + c^2 be + 2 c s |g|; after strong
                 // cancellation the column's norm is taken from the rotated registers instead
-                const double cs2 = 2.0 * c * sn * gabs, c2 = c * c, s2 = sn * sn;
+                const double cs2 = 2.0 * c * sn * gabs * (be >= al ? 1.0 : -1.0), c2 = c * c, s2 = sn * sn;
                 double aln = fma(c2, al, fma(s2, be, -cs2));
                 double ben = fma(s2, al, fma(c2, be, cs2));
                 if (aln < 0.25 * al || ben < 0.25 * be) {
@@ -1769,14 +1814,22 @@ __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__
                     aln = gsum(ea);
                     ben = gsum(eb);
                 }
+                alk = aln;
                 if (gl == 0) {
-                    nr2[p] = aln;
+                    if (AP) nr2[p] = aln;
                     nr2[q] = ben;
                 }
             }
         }
         __syncthreads();
     }
+    if (!AP) {
+        T* ap = As + ROWS * grp;
+#pragma unroll
+        for (int u = 0; u < KM; ++u) ap[gl + G * u] = xs[u];
+        __syncthreads();
+    }
+    if (PROF) st[2] = __builtin_amdgcn_s_memtime();
     if (gl == 0 && flags) {          // plain stores of the same value from every rotating group
         rotated[0] = 1;
         if (flags & 2) rotated[1] = 1;
@@ -1785,33 +1838,51 @@ __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__
         const int gc = gcol(kc);
         if (gc >= n) continue;
         T* d = A + lda * gc;
-        const T* sp = As + (size_t)la * kc;
+        const T* sp = As + ROWS * kc;
         T t0[KW];
 #pragma unroll
-        for (int u = 0; u < KW; ++u) {
-            const int r = lane + 64 * u;
-            t0[u] = r < m ? sp[r] : T{};
-        }
+        for (int u = 0; u < KW; ++u) t0[u] = sp[lane + 64 * u];
 #pragma unroll
         for (int u = 0; u < KW; ++u) {
             const int r = lane + 64 * u;
             if (r < m) d[r] = t0[u];
         }
     }
+    if (PROF && tid == 0 && blockIdx.x == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long t3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
+        prof[0] += st[1] - st[0];
+        prof[1] += st[2] - st[1];
+        prof[2] += t3 - st[2];
+        prof[3] += r3 - st[4];
+        prof[4] += 1;
+    }
+}
+
+template <class T, int BB, int KM, int G>
+constexpr size_t block_round_nov_lds() {
+    return (size_t)2 * BB * KM * G * sizeof(T) + (size_t)2 * BB * sizeof(double);
 }
 
 template <class T, int BB, int KM, int G>
 int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nblk, int round, double tol, int* flag,
                            const double* negl) {
-    const size_t lds = (size_t)2 * BB * (size_t)(k | 1) * sizeof(T) + (size_t)2 * BB * sizeof(double);
+    constexpr size_t lds = block_round_nov_lds<T, BB, KM, G>();
+    static_assert(lds <= 156 * 1024, "column blocks must fit the LDS");
     static bool attr = false;
     if (!attr) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G>),
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k, k,
-                       nblk, round, round == 0 ? 1 : 0, tol, flag, negl);
+    if (round == 0)
+        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
+                           k, nblk, round, tol, flag, negl);
+    else
+        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, false>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
+                           k, nblk, round, tol, flag, negl);
     return QIL_OK;
 }
 
@@ -1825,21 +1896,20 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     const long long k = std::min(p, q);
     static const bool enabled = !(getenv("QIL_SVD_LEFT") && atoi(getenv("QIL_SVD_LEFT")) == 0);
     if (!enabled || k < 97 || k >= 640) return QIL_OK;
-    const size_t per_col = (size_t)(k | 1) * sizeof(T) + sizeof(double);
-    int bb = 0;
-    // Block / group shape (QIL_SVD_LEFT_MODE = 64 | 16, tuning aid).  A sweep over n columns is n - 1 inner rounds of n / 2
-    // pairs whatever the blocking; an inner round is issue-bound (~100 f64 / DPP instructions per pair on the wave that
-    // owns it), and every outer round pays a launch plus the staging of its columns (~8 us).  Mode 64 (default): one wave
-    // per pair, blocks of 8 columns, 512 threads = two waves per SIMD hiding each other's LDS and dependent-issue
-    // latency: 256 columns = 128 us of inner rounds + 31 x 8 us of outer rounds per sweep.  Mode 16: one 16-lane DPP row
-    // per pair, blocks of 16 columns on 256 threads (half the outer rounds, the rotation chain paid once per four pairs)
-    // -- but one wave per SIMD with all latency exposed: measured 160 vs 146 ms (f64) and 251 vs 208 ms (c64) for
-    // compress! 256 -> 128 on 24 sites.
+    // Block / group shape (QIL_SVD_LEFT_MODE = 64 | 32, tuning aid).  A sweep over n columns is n - 1 inner rounds of n / 2
+    // pairs whatever the blocking; an inner round is issue-bound on the wave that owns a pair, and every outer round pays a
+    // launch plus the staging of its columns.  Mode 64 (default): one wave per pair, blocks of 8 columns, 512 threads = two
+    // waves per SIMD hiding each other's LDS and dependent-issue latency.  Mode 32: two pairs per wave, blocks of 16
+    // columns (half the outer rounds, the rotation chain paid once per two pairs).
     static const int mode = getenv("QIL_SVD_LEFT_MODE") ? atoi(getenv("QIL_SVD_LEFT_MODE")) : 64;
-    const int G = mode == 64 ? 64 : 16;
-    if (32 * per_col <= 150 * 1024 && G == 16) bb = 16;
-    else if (16 * per_col <= 150 * 1024) bb = 8;
-    else return QIL_OK;
+    const int km = (int)((k + 63) / 64);             // rows per lane, one wave per column
+    int G = 64, bb = 8;
+    if (mode == 32 && (size_t)32 * km * 64 * sizeof(T) + 256 <= 150 * 1024) {
+        G = 32;
+        bb = 16;
+    } else if ((size_t)16 * km * 64 * sizeof(T) + 128 > 150 * 1024) {
+        return QIL_OK;
+    }
     const bool dbg = getenv("QIL_SVD_DEBUG") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -1919,30 +1989,44 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     }
     const double tol = std::max(1e-15, 4.0 * 1.1e-16 * std::sqrt((double)k));
     const int nblk = (int)(((k + bb - 1) / bb + 1) / 2 * 2);
-    const int km = (int)((k + 63) / 64);
     int sweeps = 0;
     for (; sweeps < 40; ++sweeps) {
         QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
         for (int round = 0; round < nblk - 1; ++round) {
 #define QIL_NOV(BBv, KMv, Gv) QIL_TRY((launch_block_round_nov<T, BBv, KMv, Gv>(ctx, X, k, (int)k, nblk, round, tol, (int*)flag, (const double*)negl)))
-            if (G == 16) {
-                const int k16 = (int)((k + 15) / 16);
-                if (bb == 16) {
-                    if (k16 <= 8) QIL_NOV(16, 8, 16);
-                    else if (k16 <= 16) QIL_NOV(16, 16, 16);
-                    else if (k16 <= 24) QIL_NOV(16, 24, 16);
-                    else if (k16 <= 32) QIL_NOV(16, 32, 16);
-                    else QIL_NOV(16, 40, 16);
+            if (G == 32) {
+                if constexpr (sizeof(T) == 8) {
+                    switch (km) {
+                        case 2: QIL_NOV(16, 4, 32); break;
+                        case 3: QIL_NOV(16, 6, 32); break;
+                        case 4: QIL_NOV(16, 8, 32); break;
+                        case 5: QIL_NOV(16, 10, 32); break;
+                        case 6: QIL_NOV(16, 12, 32); break;
+                        case 7: QIL_NOV(16, 14, 32); break;
+                        case 8: QIL_NOV(16, 16, 32); break;
+                        default: QIL_NOV(16, 18, 32); break;
+                    }
                 } else {
-                    if (k16 <= 16) QIL_NOV(8, 16, 16);
-                    else if (k16 <= 24) QIL_NOV(8, 24, 16);
-                    else if (k16 <= 32) QIL_NOV(8, 32, 16);
-                    else QIL_NOV(8, 40, 16);
+                    switch (km) {
+                        case 2: QIL_NOV(16, 4, 32); break;
+                        case 3: QIL_NOV(16, 6, 32); break;
+                        default: QIL_NOV(16, 8, 32); break;
+                    }
                 }
             } else {
-                if (km <= 4) QIL_NOV(8, 4, 64);
-                else if (km <= 7) QIL_NOV(8, 7, 64);
-                else QIL_NOV(8, 10, 64);
+                switch (km) {
+                    case 2: QIL_NOV(8, 2, 64); break;
+                    case 3: QIL_NOV(8, 3, 64); break;
+                    case 4: QIL_NOV(8, 4, 64); break;
+                    case 5: QIL_NOV(8, 5, 64); break;
+                    case 6: QIL_NOV(8, 6, 64); break;
+                    case 7: QIL_NOV(8, 7, 64); break;
+                    case 8: QIL_NOV(8, 8, 64); break;
+                    case 9: QIL_NOV(8, 9, 64); break;
+                    default:
+                        if constexpr (sizeof(T) == 8) QIL_NOV(8, 10, 64);
+                        break;
+                }
             }
 #undef QIL_NOV
         }
