@@ -207,6 +207,26 @@ def truncate_block(qil, ctx, reps=3):
     qil.compress(prod, maxdim=maxdim, tol=tol)
     ctx.synchronize()
     t_exact = time.perf_counter() - t0
+    # batch of 8 independent chains (qil_compress_batch) against one chain alone: compress! chi 256 -> 128 on 24 sites
+    def sat(L, chi):
+        return [int(min(2 ** (i + 1), 2 ** (L - 1 - i), chi)) for i in range(L - 1)]
+
+    def chains(k):
+        return [qil.SignalMPS.alloc(sat(24, 256), dtype=np.float64).fill_random(5 + i) for i in range(k)]
+
+    t_one = t_eight = None
+    for _ in range(2):                                                   # first round warms the pool and the worker streams
+        one, eight = chains(1)[0], chains(8)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        qil.compress(one, maxdim=128, tol=1e-10)
+        ctx.synchronize()
+        t_one = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        qil.compress_batch(eight, maxdim=128, tol=1e-10)
+        ctx.synchronize()
+        t_eight = time.perf_counter() - t0
+    del one, eight
     bits = np.random.default_rng(3).integers(0, 2, size=(256, 2 * n)).astype(np.uint8)
     c_f, c_e = qil.coefficient_batch(fused, bits), qil.coefficient_batch(prod, bits)
     c_x = qil.apply_coefficient_batch(W, psi, bits)
@@ -227,6 +247,8 @@ def truncate_block(qil, ctx, reps=3):
         "bonds_fused_max": max(fused.bond_dims), "bonds_exact_max": max(prod.bond_dims),
         "err_fused_vs_exact_product": float(np.abs(c_f - c_x).max() / scale),
         "err_exact_route_vs_exact_product": float(np.abs(c_e - c_x).max() / scale),
+        "compress_chi256_to_128_24_sites_ms": t_one * 1e3, "compress_batch_of_8_ms": t_eight * 1e3,
+        "batch_of_8_over_single": t_eight / t_one,
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS,
                      "achieved": f_exact / t_exact / 1e12, "frac": f_exact / t_exact / 1e12 / F64_MFMA_PEAK_TFLOPS,
                      "achieved_fused": f_fused / t_fused / 1e12,

@@ -204,6 +204,16 @@ int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps);
  * `error("unknown direction")`).                                                                         */
 int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_t maxdim);
 
+/* Batches of independent chains (the serial loops over signals / damping values of
+ * scripts/benchmark/zt_full_runtime.jl:151-221 and docs/src/tutorials/zt.jl:300-348 call compress! /
+ * zip_to_compress_mpo once per item).  Item j receives exactly qil_compress(items[j], ...) resp.
+ * qil_mpo_compress(items[j], ...), in place; the nb chains run concurrently on worker streams of their common
+ * context (each is a latency chain of small factorisations that fills a few percent of the chip), and the call
+ * returns when all are done.  All items must live in one context and be distinct handles (QIL_EINVAL_ARG);
+ * the first failing item's status is returned, the other items are still processed.                        */
+int qil_compress_batch(qil_mps* const* items, int64_t nb, int64_t maxdim, double tol, int sweeps);
+int qil_mpo_compress_batch(qil_mpo* const* items, int64_t nb, int direction, double cutoff, int64_t maxdim);
+
 /* Fused apply-and-truncate: the result of compress!(apply(W, psi); maxdim, tol, sweeps)
  * (apply.jl:75-122 followed by mps.jl:913-973) without materialising the (D chi)^2 product: a zip-up sweep
  * with intermediate bond cap zip_maxdim (<= 0: 2 maxdim) followed by the exact-gauge compress!.  Same error

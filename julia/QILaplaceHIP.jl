@@ -170,6 +170,22 @@ function compress_mpo!(W::DeviceMPO, direction::AbstractString="down"; cutoff::F
                 direction == "down" ? 0 : 1, cutoff, maxdim))
     return W
 end
+# batches of independent chains of one context: item j gets exactly compress!(items[j]; ...) / compress_mpo!(items[j], ...),
+# the chains run concurrently on the context's worker streams
+function compress!(items::AbstractVector{<:DeviceMPS}; maxdim::Int=typemax(Int), tol::Float64=1e-12, sweeps::Int=1)
+    hs = Ptr{Cvoid}[p.h for p in items]
+    check(ccall((:qil_compress_batch, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int64, Int64, Cdouble, Cint), hs, length(hs), maxdim, tol,
+                sweeps))
+    return items
+end
+function compress_mpo!(items::AbstractVector{<:DeviceMPO}, direction::AbstractString="down"; cutoff::Float64=1e-14,
+                       maxdim::Int=1000)
+    direction in ("down", "up") || error("zip_to_compress_mpo: unknown direction '$direction'")
+    hs = Ptr{Cvoid}[W.h for W in items]
+    check(ccall((:qil_mpo_compress_batch, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int64, Cint, Cdouble, Int64), hs, length(hs),
+                direction == "down" ? 0 : 1, cutoff, maxdim))
+    return items
+end
 function canonicalize!(psi::DeviceMPS, direction::Symbol; center=nothing, cutoff::Float64=1e-12,
                        maxdim::Int=typemax(Int))                                                   # mps.jl:787
     direction in (:right, :left) || throw(ArgumentError("Direction must be :right or :left"))

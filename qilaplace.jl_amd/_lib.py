@@ -119,6 +119,8 @@ PROTOTYPES = {
     "qil_canonicalize": [_vp, _int, _i64, _dbl, _i64],
     "qil_compress": [_vp, _i64, _dbl, _int],
     "qil_mpo_compress": [_vp, _int, _dbl, _i64],
+    "qil_compress_batch": [_pvp, _i64, _i64, _dbl, _int],
+    "qil_mpo_compress_batch": [_pvp, _i64, _int, _dbl, _i64],
     "qil_apply_compress": [_vp, _vp, _i64, _dbl, _int, _i64, _pvp],
     "qil_signal_mps": [_vp, _vp, _i64, _int, _int, _dbl, _i64, _i64, _i64, _int, _u64, _i64, _pvp],
     "qil_signal_ztmps": [_vp, _vp, _i64, _int, _int, _dbl, _i64, _i64, _i64, _int, _u64, _i64, _pvp],

@@ -345,8 +345,6 @@ def build_dt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None):
 
 
 _ZT_Q_CACHE = {}
-_WORKER_CTX = {}          # (device, worker index) -> Context of build_zt_mpo_batch's worker threads
-_WORKER_LOCK = __import__("threading").Lock()
 
 
 @_single_thread_blas
@@ -367,9 +365,9 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, worke
     together (qil_build_dt_mpo_batch), the QFT half once on the host (it does not depend on the damping), and
     per value the MPO x MPO product (zt_transformer.jl:103 -> qil_apply_mpo_mpo) and its compression
     (zt_transformer.jl:104 -> qil_mpo_compress) run on the device -- on the host that last step alone is the
-    largest part of a build (1.4 s of 2.6 s at n = 24).  With more than one value the per-value chains run on
-    `workers` (default 8) contexts concurrently."""
-    from .ops import apply, mpo_compress
+    largest part of a build (1.4 s of 2.6 s at n = 24).  With more than one value the per-value compression chains run
+    concurrently (qil_mpo_compress_batch)."""
+    from .ops import apply, mpo_compress_batch
     import threading
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
     n = _n_of(n_or_psi)
@@ -394,45 +392,11 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, worke
         raise box["err"]
     home = dts[0].ctx
     ids = dts[0].site_ids
-    nw = min(int(workers) if workers else 8, len(dts))
-    if nw <= 1 or n == 1:
-        Q = PairedSiteMPO(box["Q"], sites=ids, ctx=home)
-        out = []
-        for W_dt in dts:
-            W = apply(W_dt, Q)
-            out.append(W if n == 1 else mpo_compress(W, "down", cutoff, maxdim))
-        return out
-    # The per-value product + compression is a chain of ~100 small dependent factorisations: latency-bound on one
-    # stream, the GPU mostly idle.  Values are independent, so `nw` worker threads each drive their own qil_context
-    # (own stream and pool; the library is thread-safe across contexts and ctypes releases the GIL) and the chains
-    # overlap on the device.  Operands are KB-sized, so they cross contexts through host memory.
-    from .containers import Context
-    dt_host = [W.to_host() for W in dts]
-    results = [None] * len(dts)
-    errors = []
-
-    def _worker(k):
-        try:
-            # worker contexts persist across calls: a fresh pool pays one hipMalloc per distinct block size
-            wctx = _WORKER_CTX.get((home.device, k))
-            if wctx is None:
-                wctx = _WORKER_CTX[(home.device, k)] = Context(home.device)
-            Qk = PairedSiteMPO(box["Q"], sites=ids, ctx=wctx)
-            for j in range(k, len(dts), nw):
-                Wd = PairedSiteMPO(dt_host[j], sites=ids, ctx=wctx)
-                W = mpo_compress(apply(Wd, Qk), "down", cutoff, maxdim)
-                results[j] = W.to_host()
-                del W, Wd
-            del Qk
-        except Exception as e:                      # noqa: BLE001  (re-raised on the calling thread)
-            errors.append(e)
-
-    with _WORKER_LOCK:                                   # the persistent worker contexts serve one batch at a time
-        threads = [threading.Thread(target=_worker, args=(k,)) for k in range(nw)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-    if errors:
-        raise errors[0]
-    return [PairedSiteMPO(r, sites=ids, ctx=home) for r in results]
+    Q = PairedSiteMPO(box["Q"], sites=ids, ctx=home)
+    prods = [apply(W_dt, Q) for W_dt in dts]
+    if n == 1:
+        return prods
+    # The compression of a product is a chain of ~100 small dependent factorisations: latency-bound on one stream, the GPU
+    # mostly idle.  The values are independent, so the chains run concurrently on the context's worker streams
+    # (qil_mpo_compress_batch; `workers` is kept for callers of the earlier host-thread route and ignored).
+    return mpo_compress_batch(prods, "down", cutoff, maxdim)

@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -77,6 +79,18 @@ struct qil_context {
     // live chain handles: orphaned (ctx = nullptr, site pointers dropped) when the context is destroyed first,
     // so a handle released after its context touches nothing
     std::set<struct qil_chain*> chains;
+    // Batch entry points (qil_run_batch): independent chains run concurrently on this context's own stream (calling
+    // thread) and on worker contexts (own stream and pool, one host thread each), one batch at a time.  For the duration of
+    // a batch the home context's cached blocks are LENT: every participant misses in its own cache first, then takes from
+    // `lend_blocks` (all work enqueued on them is ordered before the batch by an event), then allocates; at the end the
+    // remaining lent blocks and the workers' caches return to the home cache, so steady-state batches allocate nothing.
+    std::vector<qil_context*> workers;
+    std::mutex batch_mutex;
+    qil_context* parent = nullptr;                   // worker -> home
+    bool lending = false;                            // home: a batch is running
+    std::multimap<size_t, void*> lend_blocks;        // guarded by pool_mutex
+    size_t lend_cached = 0;                          // bytes in lend_blocks (guarded by pool_mutex)
+    std::mutex pool_mutex;
 };
 
 int qil_ctx_activate(qil_context* ctx);  // hipSetDevice
@@ -90,6 +104,14 @@ int qil_ctx_desc_acquire(qil_context* ctx, size_t bytes, void** host, void** dev
 int qil_ctx_desc_commit(qil_context* ctx, int slot);
 int qil_ctx_prof_begin(qil_context* ctx);
 int qil_ctx_prof_end(qil_context* ctx);
+
+// Batches of independent chains.  A chain of truncations is a latency chain of small dependent kernels that occupies a
+// few percent of the chip; `fn` is run for every chain of the batch concurrently: chain j is handed (its pool blocks
+// change owner, nothing is copied) to worker context j % nw of the chains' common home context, one host thread per worker
+// drives it on that worker's stream, and the chains return to the home context before the call does.  The work of
+// each chain is exactly what fn(chain) does alone.  All chains must belong to the same context; nw = min(nb,
+// QIL_BATCH_WORKERS (default 8)).  Returns the first failing chain's status.
+int qil_run_batch(struct qil_chain* const* items, int64_t nb, const std::function<int(struct qil_chain*)>& fn);
 
 // ---------------------------------------------------------------- containers
 static inline size_t qil_elem_size(int dtype) { return dtype == QIL_C64 ? 16 : 8; }

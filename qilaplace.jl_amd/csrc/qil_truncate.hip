@@ -1036,6 +1036,22 @@ extern "C" int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_
     return QIL_OK;
 }
 
+extern "C" int qil_compress_batch(qil_mps* const* items, int64_t nb, int64_t maxdim, double tol, int sweeps) {
+    QIL_REQUIRE(nb >= 0 && (items || nb == 0), QIL_EINVAL_ARG, "compress_batch: null item array");
+    std::vector<qil_chain*> chains(items, items + nb);
+    return qil_run_batch(chains.data(), nb, [&](qil_chain* c) {
+        return compress_impl(static_cast<qil_mps*>(c), maxdim, tol, sweeps, false);
+    });
+}
+
+extern "C" int qil_mpo_compress_batch(qil_mpo* const* items, int64_t nb, int direction, double cutoff, int64_t maxdim) {
+    QIL_REQUIRE(nb >= 0 && (items || nb == 0), QIL_EINVAL_ARG, "mpo_compress_batch: null item array");
+    std::vector<qil_chain*> chains(items, items + nb);
+    return qil_run_batch(chains.data(), nb, [&](qil_chain* c) {
+        return qil_mpo_compress(static_cast<qil_mpo*>(c), direction, cutoff, maxdim);
+    });
+}
+
 extern "C" int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n, int dtype, double cutoff,
                              int64_t maxdim, int64_t mindim, int64_t* rank, void* U, double* S, void* Vh) {
     QIL_REQUIRE(ctx && A && rank && U && S && Vh, QIL_EINVAL_ARG, "svd: null argument");

@@ -304,6 +304,31 @@ def mpo_compress(W, direction="down", cutoff=1e-14, maxdim=None):
     return W
 
 
+def _handle_array(items):
+    items = list(items)
+    arr = (C.c_void_p * max(len(items), 1))(*[it.handle.value if isinstance(it.handle, C.c_void_p) else it.handle
+                                              for it in items])
+    return items, arr
+
+
+def compress_batch(psis, maxdim=None, tol=1e-12, sweeps=1):
+    """compress!(psi; maxdim, tol, sweeps) for every MPS of `psis` (independent chains of one context, e.g. the signals
+    of a sweep) -- in place, concurrently on the context's worker streams; returns the list."""
+    items, arr = _handle_array(psis)
+    L.check(L.lib.qil_compress_batch(arr, len(items), _maxdim(maxdim), float(tol), int(sweeps)))
+    return items
+
+
+def mpo_compress_batch(Ws, direction="down", cutoff=1e-14, maxdim=None):
+    """zip_to_compress_mpo(W, direction; cutoff, maxdim) for every MPO of `Ws` (one per damping value of a sweep) -- in
+    place, concurrently on the context's worker streams; returns the list."""
+    if direction not in ("down", "up"):
+        raise ValueError(f"zip_to_compress_mpo: unknown direction '{direction}'")
+    items, arr = _handle_array(Ws)
+    L.check(L.lib.qil_mpo_compress_batch(arr, len(items), 0 if direction == "down" else 1, float(cutoff), _maxdim(maxdim)))
+    return items
+
+
 def apply_compress(W, psi, maxdim=None, tol=1e-12, sweeps=1, zip_maxdim=None):
     """compress(apply(W, psi), maxdim, tol, sweeps) fused: a zip-up sweep that never writes the (D chi)^2
     product tensors, then the exact-gauge compress.  (The reference's `apply` ignores cutoff/maxdim, and so

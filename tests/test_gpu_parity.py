@@ -1788,3 +1788,91 @@ def test_pool_cache_stays_bounded_over_varied_shapes(qil):
     assert ctx.mem_info()["pool_cached"] - before < (256 << 20)
     ctx.trim()
     assert ctx.mem_info()["pool_cached"] == 0
+
+
+# ---------------------------------------------------------------- batches of independent chains
+def test_compress_batch_equals_item_by_item(qil):
+    """qil_compress_batch: item j receives exactly compress!(items[j]) -- same kernels in the same order on a worker
+    stream, so the tensors are bit-identical to the one-at-a-time results -- for mixed shapes and dtypes, more items than
+    workers, and the pool accounting returns to the home context."""
+    import gc
+    rng = np.random.default_rng(77)
+    ctx = qil.default_context()
+    gc.collect()
+    before = ctx.mem_info()["pool_in_use"]
+    specs = [(10, 24, np.float64), (8, 16, np.complex128), (12, 40, np.float64), (6, 8, np.complex128), (9, 130, np.float64),
+             (10, 24, np.complex128), (7, 12, np.float64), (11, 33, np.float64), (8, 100, np.complex128), (10, 20, np.float64),
+             (6, 6, np.float64)]
+    data = [random_mps_data(saturated_profile(L, chi), rng, dtype=dt) for L, chi, dt in specs]
+    single = [qil.compress(qil.SignalMPS([t.copy() for t in a], amplitude=1.3), maxdim=max(2, chi // 2), tol=1e-9, sweeps=2)
+              for a, (L, chi, dt) in zip(data, specs)]
+    # the batch entry takes one (maxdim, tol, sweeps) for all items: group by the cap
+    by_cap = {}
+    for j, (L, chi, dt) in enumerate(specs):
+        by_cap.setdefault(max(2, chi // 2), []).append(j)
+    batch = [None] * len(specs)
+    for cap, idx in by_cap.items():
+        items = [qil.SignalMPS([t.copy() for t in data[j]], amplitude=1.3) for j in idx]
+        got = qil.compress_batch(items, maxdim=cap, tol=1e-9, sweeps=2)
+        assert [g is it for g, it in zip(got, items)] == [True] * len(items)
+        for j, it in zip(idx, items):
+            batch[j] = it
+    for s, b in zip(single, batch):
+        assert b.bond_dims == s.bond_dims and b.amplitude == s.amplitude
+        for ts, tb in zip(s.to_host(), b.to_host()):
+            assert np.array_equal(ts, tb)
+    # one call with all eleven chains (more chains than workers), uniform cap
+    items = [qil.SignalMPS([t.copy() for t in a]) for a in data]
+    ref = [qil.compress(qil.SignalMPS([t.copy() for t in a]), maxdim=9, tol=1e-8) for a in data]
+    qil.compress_batch(items, maxdim=9, tol=1e-8)
+    for s, b in zip(ref, items):
+        assert b.bond_dims == s.bond_dims
+        for ts, tb in zip(s.to_host(), b.to_host()):
+            assert np.array_equal(ts, tb)
+    assert ctx.unowned_bytes() == 0
+    del items, ref, batch, single, s, b, got, it
+    gc.collect()
+    assert ctx.mem_info()["pool_in_use"] == before           # every block came back to the home pool's books
+    assert qil.compress_batch([], maxdim=4) == []
+
+
+def test_compress_batch_errors(qil):
+    """A failing item reports the reference's error for that item; the other items of the batch are still compressed;
+    duplicate handles and foreign contexts are refused before anything runs."""
+    rng = np.random.default_rng(78)
+    good = [qil.SignalMPS(random_mps_data(saturated_profile(8, 16), rng)) for _ in range(3)]
+    ref = [qil.compress(qil.SignalMPS(g.to_host()), maxdim=4) for g in good]
+    short = qil.SignalMPS([rng.standard_normal((1, 2, 1))])         # compress! needs >= 2 sites (mps.jl:918)
+    with pytest.raises(qil.QilDomainError, match="at least 2 sites"):
+        qil.compress_batch([good[0], short, good[1], good[2]], maxdim=4)
+    for g, r in zip(good, ref):
+        assert g.bond_dims == r.bond_dims
+        for tg, tr in zip(g.to_host(), r.to_host()):
+            assert np.array_equal(tg, tr)
+    with pytest.raises(ValueError, match="appears twice"):
+        qil.compress_batch([good[0], good[1], good[0]], maxdim=4)
+    other = qil.Context(0)
+    alien = qil.SignalMPS(random_mps_data(saturated_profile(8, 16), rng), ctx=other)
+    with pytest.raises(ValueError, match="another context"):
+        qil.compress_batch([good[0], alien], maxdim=4)
+    assert qil.default_context().unowned_bytes() == 0
+
+
+def test_mpo_compress_batch_equals_item_by_item(qil):
+    """qil_mpo_compress_batch on the MPO x MPO products of a damping sweep (zt_transformer.jl:103-104) against
+    qil_mpo_compress one product at a time: identical tensors."""
+    n = 5
+    Wq = O.build_zt_mpo(n, 0.0, cutoff=1e-14)
+    prods = [O.apply_mpo_mpo(O.build_dt_mpo(n, wr, cutoff=1e-14), Wq) for wr in (0.3, 0.9, 1.7, 2.6, 4.0, 6.1, 8.0, 9.5, 11.0)]
+    for direction in ("down", "up"):
+        ref = [qil.mpo_compress(qil.PairedSiteMPO([np.array(t) for t in p.data]), direction, cutoff=1e-13, maxdim=1000)
+               for p in prods]
+        items = [qil.PairedSiteMPO([np.array(t) for t in p.data]) for p in prods]
+        got = qil.mpo_compress_batch(items, direction, cutoff=1e-13, maxdim=1000)
+        assert all(g is it for g, it in zip(got, items))
+        for r, b in zip(ref, items):
+            assert b.bond_dims == r.bond_dims
+            for tr, tb in zip(r.to_host(), b.to_host()):
+                assert np.array_equal(tr, tb)
+    with pytest.raises(ValueError):
+        qil.mpo_compress_batch(items, "sideways")
