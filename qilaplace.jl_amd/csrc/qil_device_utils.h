@@ -57,6 +57,27 @@ __device__ __forceinline__ double wave_sum(double v) {
     v = row16_sum(v);
     return (read_lane_d(v, 0) + read_lane_d(v, 16)) + (read_lane_d(v, 32) + read_lane_d(v, 48));
 }
+// Totals of TWO values over the 64 lanes, both delivered to every lane, for the price of little more than one: a
+// v_permlane32_swap folds the halves so that lanes 0-31 carry a and lanes 32-63 carry b, the four DPP steps and one
+// v_permlane16_swap reduce each half, a last v_permlane32_swap broadcasts both totals (22 instructions against 2 x 25).
+// The whole wave must be active.
+__device__ __forceinline__ double swap_fold32(double x, double y) {   // lanes l < 32: x[l] + x[l + 32]; l >= 32: y[l - 32] + y[l]
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void wave_sum2(double& a, double& b) {
+    double t = row16_sum(swap_fold32(a, b));
+    {   // rows 0 + 1 and 2 + 3
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(t), (unsigned)__double2loint(t), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(t), (unsigned)__double2hiint(t), false, false);
+        t = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(t), (unsigned)__double2loint(t), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(t), (unsigned)__double2hiint(t), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
 // every lane of a 32-lane half ends with that half's total
 __device__ __forceinline__ double half32_sum(double v) {
     v = row16_sum(v);

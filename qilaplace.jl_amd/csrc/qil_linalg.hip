@@ -1787,8 +1787,12 @@ __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__
             double gr = 0, gi = 0;
 #pragma unroll
             for (int u = 0; u < KM; ++u) dot_parts(xs[u], ys[u], gr, gi);
-            gr = gsum(gr);
-            if (CX) gi = gsum(gi);
+            if (CX && G == 64) {
+                wave_sum2(gr, gi);
+            } else {
+                gr = gsum(gr);
+                if (CX) gi = gsum(gi);
+            }
             double c, sr, si, sn, gabs;
             bool big;
             if (!(al < ng || be < ng) && rotation_fast<CX>(al, be, gr, gi, tol, c, sr, si, sn, gabs, big)) {
@@ -1811,8 +1815,14 @@ __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__
                         ea += abs2_t(xs[u]);
                         eb += abs2_t(ys[u]);
                     }
-                    aln = gsum(ea);
-                    ben = gsum(eb);
+                    if (G == 64) {
+                        wave_sum2(ea, eb);
+                        aln = ea;
+                        ben = eb;
+                    } else {
+                        aln = gsum(ea);
+                        ben = gsum(eb);
+                    }
                 }
                 alk = aln;
                 if (gl == 0) {
