@@ -402,18 +402,25 @@ __device__ __forceinline__ double pb_gsum(double v) {
 
 // Rotation orthogonalising a column pair with |x|^2 = al, |y|^2 = be, x.y = g, from two reciprocal square roots:
 // cos 2t = |be - al| / h, h = sqrt((be - al)^2 + 4 g^2); c = sqrt((1 + cos 2t) / 2); s = |g| / (h c), signed by
-// (be - al).  Both come out to a few ulp with c^2 + s^2 = 1 to rounding (no V is accumulated here: the factors
-// are rebuilt from the normalised rotated columns).  Returns false when the pair passes |g| <= tol |x| |y|.
+// (be - al).  The chain sits on the critical path of every round of a lone wave, so the angle comes from the raw hardware
+// reciprocal square roots (~1e-8 relative: it only decides how completely this pair is annihilated, quadratic convergence
+// absorbs it) and unitarity is restored exactly: with eps = c0^2 + s0^2 - 1 both are scaled by
+// 1 / sqrt(1 + eps) = 1 - eps / 2 + 3 eps^2 / 8 + O(eps^3 < 1e-18).  (No V is accumulated here: the factors are rebuilt
+// from the normalised rotated columns.)  Returns false when the pair passes |g| <= tol |x| |y|.
 __device__ __forceinline__ bool pb_rotation(double al, double be, double g, double tol, double& c, double& s, bool& big) {
     const double g2 = g * g, ab = al * be;
     big = g2 > (kQuadraticOff * kQuadraticOff) * ab;
     if (!(g2 > tol * tol * ab) || g2 == 0.0) return false;
     const double d = be - al;
-    const double rh = rsqrt_refined(fma(d, d, 4.0 * g2));
+    const double rh = __builtin_amdgcn_rsq(fma(d, d, 4.0 * g2));
     const double c2 = fma(0.5 * fabs(d), rh, 0.5);
-    const double rc = rsqrt_refined(c2);
-    c = c2 * rc;
-    s = copysign(fabs(g) * rh * rc, d);
+    const double rc = __builtin_amdgcn_rsq(c2);
+    const double c0 = c2 * rc;
+    const double s0 = fabs(g) * rh * rc;
+    const double eps = fma(c0, c0, fma(s0, s0, -1.0));
+    const double f = fma(eps, fma(eps, 0.375, -0.5), 1.0);
+    c = c0 * f;
+    s = copysign(s0 * f, d);
     return true;
 }
 
