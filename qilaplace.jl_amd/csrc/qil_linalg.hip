@@ -986,12 +986,20 @@ __device__ __forceinline__ c64 hh_cmul(c64 a, c64 b) { return c64{a.re * b.re - 
 __device__ __forceinline__ double hh_wave_sum(double v) { return wave_sum(v); }
 __device__ __forceinline__ c64 hh_wave_sum(c64 v) { return c64{wave_sum(v.re), wave_sum(v.im)}; }
 
+// Row predicates are kept out of the instruction stream (a select around a load becomes a branch with a wait inside, one
+// per element): every column has a zero SINK row m behind its data, lanes beyond the matrix read and write that row, and
+// the staircase mask enters as a multiplication by 0 / 1 -- the update y -= f x then rewrites the rows above the staircase
+// with the values they already hold.
 template <class T, int KM>
-__global__ __launch_bounds__(1024) void hh_panel(T* __restrict__ P, long long lda, int m, int b, T* __restrict__ R,
-                                                 long long ldr, const double* __restrict__ ref_norm) {
-    constexpr int NW = 16;
+constexpr int hh_panel_waves() { return KM * (int)(sizeof(T) / 8) > 18 ? 8 : 16; }   // long columns: 256 registers per lane
+
+template <class T, int KM>
+__global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __restrict__ P, long long lda, int m, int b,
+                                                                         T* __restrict__ R, long long ldr,
+                                                                         const double* __restrict__ ref_norm) {
+    constexpr int NW = hh_panel_waves<T, KM>();
     extern __shared__ __attribute__((aligned(16))) char hp_smem[];
-    const int la = m | 1;
+    const int la = (m + 1) | 1;
     T* Ps = reinterpret_cast<T*>(hp_smem);
     double* kap = reinterpret_cast<double*>(Ps + (size_t)la * b);       // b: kappa of column j's reflector (0: none)
     double* dia = kap + 32;                                              // b: |R_jj|
@@ -999,20 +1007,17 @@ __global__ __launch_bounds__(1024) void hh_panel(T* __restrict__ P, long long ld
     T* pha = reinterpret_cast<T*>(refn + 32);                            // b: column phase making R_jj real positive
     int* rowof = reinterpret_cast<int*>(pha + 32);                       // b: staircase row of column j, -1 = dependent
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // stage: wave w owns columns w, w + 16
+    auto rowc = [&](int u) { return min(lane + 64 * u, m); };          // this lane's rows (sink row m beyond the matrix)
+    // stage: wave w owns columns w, w + 16 (all loads of a column in flight)
     for (int c = wave; c < b; c += NW) {
         const T* src = P + lda * c;
         T t0[KM];
 #pragma unroll
-        for (int u = 0; u < KM; ++u) {
-            const int r = lane + 64 * u;
-            t0[u] = r < m ? src[r] : T{};
-        }
+        for (int u = 0; u < KM; ++u) t0[u] = scale_t(src[rowc(u) < m ? rowc(u) : 0], rowc(u) < m ? 1.0 : 0.0);
         double nn = 0;
 #pragma unroll
         for (int u = 0; u < KM; ++u) {
-            const int r = lane + 64 * u;
-            if (r < m) Ps[r + (size_t)la * c] = t0[u];
+            Ps[rowc(u) + (size_t)la * c] = t0[u];                         // the sink row receives 0
             nn += abs2_t(t0[u]);
         }
         nn = wave_sum(nn);
@@ -1026,12 +1031,11 @@ __global__ __launch_bounds__(1024) void hh_panel(T* __restrict__ P, long long ld
         double s2 = 0;
 #pragma unroll
         for (int u = 0; u < KM; ++u) {
-            const int r = lane + 64 * u;
-            xs[u] = (r > rr && r < m) ? x[r] : T{};
+            xs[u] = scale_t(x[rowc(u)], (rowc(u) > rr && rowc(u) < m) ? 1.0 : 0.0);
             s2 += abs2_t(xs[u]);
         }
         s2 = wave_sum(s2);
-        const T alpha = rr < m ? x[rr] : T{};
+        const T alpha = x[rr < m ? rr : m];
         const double a2 = abs2_t(alpha);
         const double nrm = sqrt(a2 + s2);
         const double rn = refn[j];
@@ -1049,22 +1053,16 @@ __global__ __launch_bounds__(1024) void hh_panel(T* __restrict__ P, long long ld
                 T* y = Ps + (size_t)la * c;
                 T ys[KM];
 #pragma unroll
-                for (int u = 0; u < KM; ++u) {
-                    const int r = lane + 64 * u;
-                    ys[u] = (r > rr && r < m) ? y[r] : T{};
-                }
+                for (int u = 0; u < KM; ++u) ys[u] = y[rowc(u)];
                 const T yr = y[rr];
                 T w{};
 #pragma unroll
-                for (int u = 0; u < KM; ++u) w = add_t(w, hh_mul_conj(xs[u], ys[u]));
+                for (int u = 0; u < KM; ++u) w = add_t(w, hh_mul_conj(xs[u], ys[u]));      // xs is 0 above the staircase
                 w = hh_wave_sum(w);
                 w = add_t(w, hh_mul_conj(diff, yr));
                 const T f = scale_t(w, kappa);
 #pragma unroll
-                for (int u = 0; u < KM; ++u) {
-                    const int r = lane + 64 * u;
-                    if (r > rr && r < m) y[r] = sub_t(ys[u], hh_cmul(f, xs[u]));
-                }
+                for (int u = 0; u < KM; ++u) y[rowc(u)] = sub_t(ys[u], hh_cmul(f, xs[u]));
                 if (lane == 0) y[rr] = sub_t(yr, hh_cmul(f, diff));
             }
         }
@@ -1083,7 +1081,7 @@ __global__ __launch_bounds__(1024) void hh_panel(T* __restrict__ P, long long ld
     __syncthreads();
     // R block (b x b): row jj = conj(phase_jj) * staircase row rowof[jj]; zero rows for dependent columns
     if (R)
-        for (int t = tid; t < b * b; t += 1024) {
+        for (int t = tid; t < b * b; t += 64 * NW) {
             const int jj = t % b, c = t / b;
             T v{};
             const int ro = rowof[jj];
@@ -1113,8 +1111,7 @@ __global__ __launch_bounds__(1024) void hh_panel(T* __restrict__ P, long long ld
                 T w{};
 #pragma unroll
                 for (int u = 0; u < KM; ++u) {
-                    const int r = lane + 64 * u;
-                    xs[u] = (r >= rj && r < m) ? x[r] : T{};
+                    xs[u] = scale_t(x[rowc(u)], (rowc(u) >= rj && rowc(u) < m) ? 1.0 : 0.0);
                     w = add_t(w, hh_mul_conj(xs[u], q[u]));
                 }
                 w = hh_wave_sum(w);
@@ -1134,11 +1131,11 @@ __global__ __launch_bounds__(1024) void hh_panel(T* __restrict__ P, long long ld
 // true when the panel fits (LDS and rows-per-lane budget); launches it
 template <class T>
 bool hh_panel_fits(long long m, int b) {
-    return b <= 32 && m <= 64 * 19 && (size_t)(m | 1) * b * sizeof(T) + 1536 <= 150 * 1024;
+    return b <= 32 && m <= 64 * 19 && (size_t)((m + 1) | 1) * b * sizeof(T) + 1536 <= 150 * 1024;
 }
 template <class T>
 int hh_panel_launch(qil_context* ctx, T* P, long long lda, long long m, int b, T* R, long long ldr, const double* ref_norm) {
-    const size_t lds = (size_t)(m | 1) * b * sizeof(T) + 1536;
+    const size_t lds = (size_t)((m + 1) | 1) * b * sizeof(T) + 1536;
     const int km = (int)((m + 63) / 64);
 #define QIL_HHP(KMv)                                                                                                   \
     do {                                                                                                               \
@@ -1148,7 +1145,8 @@ int hh_panel_launch(qil_context* ctx, T* P, long long lda, long long m, int b, T
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                      \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((hh_panel<T, KMv>), dim3(1), dim3(1024), lds, ctx->stream, P, lda, (int)m, b, R, ldr, ref_norm); \
+        hipLaunchKernelGGL((hh_panel<T, KMv>), dim3(1), dim3(64 * hh_panel_waves<T, KMv>()), lds, ctx->stream, P, lda, (int)m, b, R, \
+                           ldr, ref_norm);                                                                             \
     } while (0)
     if (km <= 2) QIL_HHP(2);
     else if (km <= 4) QIL_HHP(4);

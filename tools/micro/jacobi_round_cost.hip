@@ -59,8 +59,11 @@ int main() {
     run<double, 8, 4, 64>(256, "f64");
     run<double, 8, 3, 64>(133, "f64");
     run<double, 16, 8, 32>(256, "f64");
+    run<double, 8, 8, 32>(256, "f64");
+    run<double, 4, 4, 64>(256, "f64");
     run<double, 8, 8, 64>(512, "f64");
     run<qil_dev::c64, 8, 4, 64>(256, "c64");
     run<qil_dev::c64, 16, 8, 32>(256, "c64");
+    run<qil_dev::c64, 8, 8, 32>(256, "c64");
     return 0;
 }
