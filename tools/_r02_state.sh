@@ -1,6 +1,10 @@
 #!/bin/bash
+cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python -m pytest $R/tests -x -q -m gpu -k "qr or svd or compress or canonical or trunc or rsvd or encode or signal" 2>&1 | tail -3
-python $R/tools/_compress_time.py 2>&1 | grep compress
-python $R/tools/_prof_encode30.py 2>&1 | tail -1
-python $R/tools/_truncate_block.py 2>&1 | tail -3
+O=$R/gpurun_out
+rm -rf $O/prof; mkdir -p $O/prof
+rocprofv3 --kernel-trace --stats -d $O/prof/c256 --output-format csv -- python3 $R/tools/_prof_compress.py 256 > $O/prof/c256.log 2>&1
+f=$(find $O/prof/c256 -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" $O/c256_kernel_stats.csv
+grep compress $O/prof/c256.log
+rm -rf $O/prof
