@@ -192,7 +192,8 @@ int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int6
                 int64_t ldu, double* S_host, void* Vh, int64_t ldvh, double negligible_rel = 0.0);
 // SVD with ONE isometric factor for the gauge sweeps: B (p x q; destroyed when *handled) = Uiso diag(S) V^H with
 // Uiso (p x k, k = min(p, q)) orthonormal columns in descending-S order, SVh (k x q) = diag(S) V^H (no division by S
-// anywhere).  Serves the mid-size regime (97 <= k < 640); *handled = 0 leaves B intact for the general qil_dev_svd.
+// anywhere).  Serves the mid-size regime (97 <= k < 640, and smaller operands that do not fit the single-workgroup iteration);
+// *handled = 0 leaves B intact for the general qil_dev_svd.
 int qil_dev_svd_left(qil_context* ctx, int dtype, int64_t p, int64_t q, void* B, int64_t ldb, void* Uiso, int64_t ldu,
                      double* S_host, void* SVh, int64_t ldsvh, double negligible_rel, int* handled);
 // Thin QR with non-negative real diagonal of R: A (m x n, m >= n) -> Q (m x n) in place; R (n x n) optional.

@@ -1895,7 +1895,7 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
 }
 
 // B (p x q, ldb; destroyed) = Uiso diag(S) V^H:  Uiso (p x k, k = min(p, q)) orthonormal columns sorted by descending
-// singular value, S on the host, SVh (k x q) = diag(S) V^H.  Serves 97 <= k < 640 with the columns resident in LDS;
+// singular value, S on the host, SVh (k x q) = diag(S) V^H.  Serves 97 <= k < 640 (and smaller k whose general path would not be LDS-resident) with the columns in LDS;
 // *handled = 0 (nothing touched beyond B's contents being intact) sends the caller to the general svd_impl.
 template <class T>
 int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb, T* Uiso, long long ldu, double* S_host,
@@ -1903,7 +1903,15 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     *handled = 0;
     const long long k = std::min(p, q);
     static const bool enabled = !(getenv("QIL_SVD_LEFT") && atoi(getenv("QIL_SVD_LEFT")) == 0);
-    if (!enabled || k < 97 || k >= 640) return QIL_OK;
+    if (!enabled || k < 17 || k >= 640) return QIL_OK;
+    if (k < 97) {
+        // small operands: the single-workgroup iteration of the general path (operand and V in LDS, no launches) wins
+        // whenever it fits; where it does not (complex 2 chi x chi sites with chi > 64, long rows) that path falls back to V
+        // in global memory (1.1 ms per SVD) or to per-round launches that carry V, and the one-factor route is 2x faster
+        const long long rows = std::max(p, q);
+        const size_t lds_av = (size_t)((rows | 1) * k + (k | 1) * k) * sizeof(T);
+        if (lds_av <= 150 * 1024 && rows * k <= (1LL << 19)) return QIL_OK;
+    }
     // Block / group shape (QIL_SVD_LEFT_MODE = 64 | 32, tuning aid).  A sweep over n columns is n - 1 inner rounds of n / 2
     // pairs whatever the blocking; an inner round is issue-bound on the wave that owns a pair, and every outer round pays a
     // launch plus the staging of its columns.  Mode 64 (default): one wave per pair, blocks of 8 columns, 512 threads = two
@@ -2005,6 +2013,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             if (G == 32) {
                 if constexpr (sizeof(T) == 8) {
                     switch (km) {
+                        case 1: QIL_NOV(16, 2, 32); break;
                         case 2: QIL_NOV(16, 4, 32); break;
                         case 3: QIL_NOV(16, 6, 32); break;
                         case 4: QIL_NOV(16, 8, 32); break;
@@ -2016,6 +2025,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
                     }
                 } else {
                     switch (km) {
+                        case 1: QIL_NOV(16, 2, 32); break;
                         case 2: QIL_NOV(16, 4, 32); break;
                         case 3: QIL_NOV(16, 6, 32); break;
                         default: QIL_NOV(16, 8, 32); break;
@@ -2023,6 +2033,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
                 }
             } else {
                 switch (km) {
+                    case 1: QIL_NOV(8, 1, 64); break;
                     case 2: QIL_NOV(8, 2, 64); break;
                     case 3: QIL_NOV(8, 3, 64); break;
                     case 4: QIL_NOV(8, 4, 64); break;

@@ -1,10 +1,7 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out
-rm -rf $O/prof; mkdir -p $O/prof
-rocprofv3 --kernel-trace --stats -d $O/prof/c256 --output-format csv -- python3 $R/tools/_prof_compress.py 256 > $O/prof/c256.log 2>&1
-f=$(find $O/prof/c256 -name '*kernel_stats.csv' | head -1)
-[ -n "$f" ] && cp "$f" $O/c256_kernel_stats.csv
-grep compress $O/prof/c256.log
-rm -rf $O/prof
+python -m pytest $R/tests -x -q -m gpu 2>&1 | tail -3
+python $R/tools/_truncate_block.py 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:(round(v,1) if isinstance(v,float) and v>1 else v) for k,v in d.items() if k.endswith('ms') or 'err' in k or 'bonds' in k})"
+python $R/tools/_compress_time.py 2>&1 | grep compress
+python $R/tools/_prof_encode30.py 2>&1 | tail -1
+python $R/tools/_fuzz_product_compress.py 60 2>&1 | tail -1
