@@ -306,7 +306,9 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     // few output tiles + long K (projections Q^H P, sketches of skinny panels): split K over the chip
     int splits = 1;
     static const long long split_min_k = getenv("QIL_GEMM_SPLIT_MIN_K") ? atoll(getenv("QIL_GEMM_SPLIT_MIN_K")) : 1024;   // tuning aid (512: exact compress! of the bond-1008 product 572 -> 534 ms, compress! 512 -> 256 330 -> 355 ms)
-    if (can_split && tiles * bt.count < 128 && k >= split_min_k)
+    // ... and from K = 512 when the output is at most 8 tiles (the CGS2 projections Q^H P of 1008-row complex panels:
+    // exact compress! of the bond-1008 product 476 -> 445 ms; splitting every K >= 512 product costs the small chains 5 %)
+    if (can_split && tiles * bt.count < 128 && (k >= split_min_k || (k >= 512 && tiles * bt.count <= 8)))
         splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / (tiles * bt.count)), 64);
     if (splits < 2) splits = 1;
     long long kchunk = k, cstride = 0, c_bs = bt.c_bs;
@@ -1606,8 +1608,8 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
 // The gauge sweeps (canonicalize!, compress!, the zip-up) keep only ONE factor of every SVD as a site tensor; the other
 // is multiplied into the neighbour.  Then no rotation matrix has to be accumulated: the isometric factor is the
 // normalised rotated work matrix itself and the other one is a GEMM with the operand (no division by singular
-// values).  Half the LDS per column => blocks of 16 columns instead of 8 (15 outer rounds per sweep at 256 columns
-// instead of 31), half the rotation work per pair, cached squared norms (one wave reduction per pair instead of three).
+// values).  Half the LDS per column, half the rotation work per pair, cached squared norms (one wave reduction per pair
+// instead of three).
 
 // Rotation of a column pair from |x|^2 = al, |y|^2 = be, x^H y = gr + i gi:  x' = c x - conj(sg) y,  y' = sg x + c y with
 // sg = s e^{i phi} = (sr, si), e^{i phi} = g / |g|, s signed by be - al; sabs = |sg|, gabs ~ |g|.
@@ -2548,11 +2550,11 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     static const bool hh_panels = !(getenv("QIL_QR_HH") && atoi(getenv("QIL_QR_HH")) == 0);                   // tuning aid
     // one launch for the whole factorisation: single panels, and anything whose slice fits one CU's LDS
     const bool fits_lds = ((size_t)2 * (n + (n & 1)) + (size_t)(m | 1) * n) * sizeof(T) <= 150 * 1024;
-    // panels go through the row-chunk tree from TALL rows on, and already from 1024 rows when a rows x 16 panel does
+    // panels go through the row-chunk tree from TALL rows on, and already from 640 rows when a rows x 16 panel does
     // not fit LDS (complex panels above ~580 rows): its 512-row chunks do, and a single workgroup factoring such a
-    // panel out of L2 takes ~290 us instead of three short launches
+    // panel out of L2 takes ~220-290 us instead of three short launches
     const bool panel16_fits = ((size_t)32 + (size_t)(m | 1) * 16) * sizeof(T) <= 150 * 1024;
-    static const long long tree_min = getenv("QIL_TSQR_NOFIT_ROWS") ? atoll(getenv("QIL_TSQR_NOFIT_ROWS")) : 1024;       // tuning aid (768: neutral)
+    static const long long tree_min = getenv("QIL_TSQR_NOFIT_ROWS") ? atoll(getenv("QIL_TSQR_NOFIT_ROWS")) : 640;        // tuning aid (1024 -> 600: exact compress! of the bond-1008 product 476 -> 455 ms, neutral elsewhere)
     const bool tree = m >= TALL || (!panel16_fits && m >= tree_min);
     if (n <= 16 || fits_lds) {
         if (tree && n <= 16) {
