@@ -1,6 +1,13 @@
 #!/bin/bash
+cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python $R/tools/_truncate_block.py 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:round(v,1) for k,v in d.items() if k in ('fused_apply_compress_ms','exact_compress_ms')})"
-python $R/tools/_compress_time.py 2>&1 | grep compress
-python $R/tools/_prof_encode30.py 2>&1 | tail -1
-python -m pytest $R/tests -x -q -m gpu 2>&1 | tail -2
+O=$R/gpurun_out
+rm -rf $O/prof; mkdir -p $O/prof
+rocprofv3 --kernel-trace --stats -d $O/prof/tb --output-format csv -- python3 $R/tools/_truncate_block.py > $O/prof/tb.log 2>&1
+echo rc=$?
+f=$(find $O/prof/tb -name '*kernel_stats.csv' | head -1)
+echo "stats: $f"
+[ -n "$f" ] && cp "$f" $O/r02_kernel_stats_truncate_block.csv
+grep -n "Check failed\|F2026\|terminate\|Segmentation\|Aborted" $O/prof/tb.log | head -5 | cut -c1-300
+find $O/prof/tb -type f | head
+rm -rf $O/prof
