@@ -223,6 +223,12 @@ int qil_mpo_compress_batch(qil_mpo* const* items, int64_t nb, int direction, dou
  * than the exact route on flat-spectrum operands; qil_apply + qil_compress is the exact route.            */
 int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
                        int64_t zip_maxdim, qil_mps** out);
+/* The same for nb independent (operator, state) pairs of one context -- the (signal, damping value) items of a sweep;
+ * Ws / psis entries may repeat (one operator on many signals, many operators on one signal).  outs[j] receives
+ * exactly qil_apply_compress(Ws[j], psis[j], ...); the chains run concurrently on the context's streams (see
+ * qil_compress_batch).  On failure the first failing item's status is returned and NO handle is handed out.      */
+int qil_apply_compress_batch(const qil_mpo* const* Ws, const qil_mps* const* psis, int64_t nb, int64_t maxdim,
+                             double tol, int sweeps, int64_t zip_maxdim, qil_mps** outs);
 
 /* ------------------------------------------------------------------ encode (E1-E4) */
 /* signal_mps(x; method, cutoff, maxdim, k, p, q, random_seed, mindim)

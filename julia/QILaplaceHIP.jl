@@ -272,6 +272,18 @@ function apply_compress(W::DeviceMPO, psi::DeviceMPS; maxdim::Int=typemax(Int), 
                 W.h, psi.h, maxdim == typemax(Int) ? 0 : maxdim, tol, sweeps, zip_maxdim, r))
     return finalizer(_free!, DeviceMPS(r[], copy(psi.sites), psi.paired))
 end
+# the same for independent (operator, state) pairs -- the (signal, damping value) items of a sweep -- run concurrently
+function apply_compress(Ws::AbstractVector{<:DeviceMPO}, psis::AbstractVector{<:DeviceMPS}; maxdim::Int=typemax(Int),
+                        tol::Float64=1e-12, sweeps::Int=1, zip_maxdim::Int=0)
+    length(Ws) == length(psis) || throw(ArgumentError("apply_compress: $(length(Ws)) operators for $(length(psis)) states"))
+    hw = Ptr{Cvoid}[W.h for W in Ws]
+    hp = Ptr{Cvoid}[p.h for p in psis]
+    outs = fill(Ptr{Cvoid}(C_NULL), length(psis))
+    check(ccall((:qil_apply_compress_batch, LIB), Cint,
+                (Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int64, Int64, Cdouble, Cint, Int64, Ptr{Ptr{Cvoid}}),
+                hw, hp, length(psis), maxdim == typemax(Int) ? 0 : maxdim, tol, sweeps, zip_maxdim, outs))
+    return [finalizer(_free!, DeviceMPS(h, copy(p.sites), p.paired)) for (h, p) in zip(outs, psis)]
+end
 # coefficient(apply(W, psi), cfg) for a batch of configurations (rows of `bits`) without forming W * psi
 function coefficient(W::DeviceMPO, psi::DeviceMPS, bits::AbstractMatrix{<:Integer})
     nb, L = size(bits)

@@ -122,6 +122,7 @@ PROTOTYPES = {
     "qil_compress_batch": [_pvp, _i64, _i64, _dbl, _int],
     "qil_mpo_compress_batch": [_pvp, _i64, _int, _dbl, _i64],
     "qil_apply_compress": [_vp, _vp, _i64, _dbl, _int, _i64, _pvp],
+    "qil_apply_compress_batch": [_pvp, _pvp, _i64, _i64, _dbl, _int, _i64, _pvp],
     "qil_signal_mps": [_vp, _vp, _i64, _int, _int, _dbl, _i64, _i64, _i64, _int, _u64, _i64, _pvp],
     "qil_signal_ztmps": [_vp, _vp, _i64, _int, _int, _dbl, _i64, _i64, _i64, _int, _u64, _i64, _pvp],
     "qil_rsvd": [_vp, _vp, _i64, _i64, _int, _i64, _i64, _int, _u64, _dbl, _i64, _i64, _pi64, _vp, _pdbl, _vp],

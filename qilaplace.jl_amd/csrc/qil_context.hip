@@ -427,16 +427,10 @@ static void chain_move(qil_chain* c, qil_context* to) {
     to->chains.insert(c);
 }
 
-int qil_run_batch(qil_chain* const* items, int64_t nb, const std::function<int(qil_chain*)>& fn) {
+int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int64_t, qil_context*)>& place,
+                     const std::function<int(int64_t, qil_context*)>& fn) {
     if (nb <= 0) return QIL_OK;
-    QIL_REQUIRE(items, QIL_EINVAL_ARG, "batch: null item array");
-    std::set<const qil_chain*> seen;
-    for (int64_t j = 0; j < nb; ++j) {
-        QIL_REQUIRE(items[j] && items[j]->ctx, QIL_EINVAL_ARG, "batch: item %lld is null or has no context", (long long)j);
-        QIL_REQUIRE(items[j]->ctx == items[0]->ctx, QIL_EINVAL_ARG, "batch: item %lld lives in another context", (long long)j);
-        QIL_REQUIRE(seen.insert(items[j]).second, QIL_EINVAL_ARG, "batch: item %lld appears twice", (long long)j);
-    }
-    qil_context* home = items[0]->ctx;
+    QIL_REQUIRE(home, QIL_EINVAL_ARG, "batch: null context");
     // One chain per hardware queue: the runtime multiplexes streams onto 4 queues, and streams that share one serialise
     // (measured with rocprofv3 --kernel-trace: a fifth stream lands on an occupied queue and its chain runs at half speed).
     // The calling thread drives the home stream itself, so nw chains use nw streams.
@@ -446,7 +440,7 @@ int qil_run_batch(qil_chain* const* items, int64_t nb, const std::function<int(q
         int first = QIL_OK;
         std::string msg;
         for (int64_t j = 0; j < nb; ++j) {
-            const int s = fn(items[j]);
+            const int s = fn(j, home);
             if (s != QIL_OK && first == QIL_OK) {
                 first = s;
                 msg = qil_last_error();
@@ -471,8 +465,9 @@ int qil_run_batch(qil_chain* const* items, int64_t nb, const std::function<int(q
         (void)hipEventDestroy(ready);
         return qil_fail(QIL_EHIP, "hipEventRecord failed: %s", hipGetErrorString(he));
     }
-    for (int64_t j = 0; j < nb; ++j)
-        if (j % nw) chain_move(items[j], slot_ctx((int)(j % nw)));
+    if (place)
+        for (int64_t j = 0; j < nb; ++j)
+            if (j % nw) place(j, slot_ctx((int)(j % nw)));
     home->lend_blocks.swap(home->free_blocks);               // lend the cache (free_blocks is now empty)
     home->lend_cached = home->bytes_cached;
     home->bytes_cached = 0;
@@ -487,7 +482,7 @@ int qil_run_batch(qil_chain* const* items, int64_t nb, const std::function<int(q
         if (k && (hipSetDevice(w->device) != hipSuccess || hipStreamWaitEvent(w->stream, ready, 0) != hipSuccess)) s0 = QIL_EHIP;
         for (int64_t j = k; j < nb; j += nw) {
             const auto tj0 = std::chrono::steady_clock::now();
-            const int s = s0 != QIL_OK ? s0 : fn(items[j]);
+            const int s = s0 != QIL_OK ? s0 : fn(j, w);
             if (batch_debug)
                 fprintf(stderr, "[batch] slot %d item %lld: start %.2f ms, took %.2f ms\n", k, (long long)j,
                         std::chrono::duration<double, std::milli>(tj0 - t_batch).count(),
@@ -505,9 +500,13 @@ int qil_run_batch(qil_chain* const* items, int64_t nb, const std::function<int(q
     drive(0);
     for (auto& t : threads) t.join();
     home->lending = false;
-    for (int64_t j = 0; j < nb; ++j)
-        if (j % nw) chain_move(items[j], home);
-    // every stream of the batch is idle: what is left of the lent blocks and the workers' caches go (back) to the home cache
+    // every stream of the batch is idle: the chains the workers hold (moved there or created there), what is left of the
+    // lent blocks and the workers' caches go (back) to the home context
+    for (int k = 1; k < nw; ++k) {
+        qil_context* w = slot_ctx(k);
+        const std::vector<qil_chain*> held(w->chains.begin(), w->chains.end());
+        for (qil_chain* c : held) chain_move(c, home);
+    }
     for (auto& kv : home->lend_blocks) home->free_blocks.emplace(kv.first, kv.second);
     home->bytes_cached += home->lend_cached;
     home->lend_blocks.clear();
@@ -524,6 +523,20 @@ int qil_run_batch(qil_chain* const* items, int64_t nb, const std::function<int(q
         if (status[(size_t)j] != QIL_OK)
             return qil_fail(status[(size_t)j], "%s (item %lld of the batch)", message[(size_t)j].c_str(), (long long)j);
     return QIL_OK;
+}
+
+int qil_run_batch(qil_chain* const* items, int64_t nb, const std::function<int(qil_chain*)>& fn) {
+    if (nb <= 0) return QIL_OK;
+    QIL_REQUIRE(items, QIL_EINVAL_ARG, "batch: null item array");
+    std::set<const qil_chain*> seen;
+    for (int64_t j = 0; j < nb; ++j) {
+        QIL_REQUIRE(items[j] && items[j]->ctx, QIL_EINVAL_ARG, "batch: item %lld is null or has no context", (long long)j);
+        QIL_REQUIRE(items[j]->ctx == items[0]->ctx, QIL_EINVAL_ARG, "batch: item %lld lives in another context", (long long)j);
+        QIL_REQUIRE(seen.insert(items[j]).second, QIL_EINVAL_ARG, "batch: item %lld appears twice", (long long)j);
+    }
+    return qil_run_batch_on(
+        items[0]->ctx, nb, [&](int64_t j, qil_context* slot) { chain_move(items[j], slot); },
+        [&](int64_t j, qil_context*) { return fn(items[j]); });
 }
 
 void qil_chain_bind(qil_chain* c, qil_context* ctx) {
@@ -638,15 +651,19 @@ extern "C" int qil_mpo_destroy(qil_mpo* W) {
     return QIL_OK;
 }
 
-extern "C" int qil_mps_clone(const qil_mps* psi, qil_mps** out) {
-    QIL_REQUIRE(psi && out, QIL_EINVAL_ARG, "qil_mps_clone: null argument");
-    QIL_TRY(chain_create<qil_mps>(psi->ctx, psi->n(), psi->dtype, psi->paired, 1, psi->dims.data() + 1,
+int qil_mps_clone_to(qil_context* ctx, const qil_mps* psi, qil_mps** out) {
+    QIL_TRY(chain_create<qil_mps>(ctx, psi->n(), psi->dtype, psi->paired, 1, psi->dims.data() + 1,
                                   psi->site_ids.data(), nullptr, out));
     (*out)->amplitude = psi->amplitude;
     for (int64_t i = 0; i < psi->n(); ++i)
         QIL_HIP(hipMemcpyAsync((*out)->site[(size_t)i], psi->site[(size_t)i], psi->site_bytes(i),
-                               hipMemcpyDeviceToDevice, psi->ctx->stream));
+                               hipMemcpyDeviceToDevice, ctx->stream));
     return QIL_OK;
+}
+
+extern "C" int qil_mps_clone(const qil_mps* psi, qil_mps** out) {
+    QIL_REQUIRE(psi && out, QIL_EINVAL_ARG, "qil_mps_clone: null argument");
+    return qil_mps_clone_to(psi->ctx, psi, out);
 }
 
 #define CHAIN_GETTERS(PFX, TYPE)                                                                        \

@@ -112,6 +112,13 @@ int qil_ctx_prof_end(qil_context* ctx);
 // each chain is exactly what fn(chain) does alone.  All chains must belong to the same context; nw = min(nb,
 // QIL_BATCH_WORKERS (default 8)).  Returns the first failing chain's status.
 int qil_run_batch(struct qil_chain* const* items, int64_t nb, const std::function<int(struct qil_chain*)>& fn);
+// The same for work that CREATES chains from read-only operands of the home context: fn(j, work) runs item j with `work`
+// as its working context (stream + pool; operands may be shared between items and stay where they are); every chain
+// bound to a worker when the batch ends -- moved there by place(j, slot) beforehand or created by fn -- returns to home.
+int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int64_t, qil_context*)>& place,
+                     const std::function<int(int64_t, qil_context*)>& fn);
+// device copy of psi owned by ctx (made on ctx's stream)
+int qil_mps_clone_to(qil_context* ctx, const struct qil_mps* psi, struct qil_mps** out);
 
 // ---------------------------------------------------------------- containers
 static inline size_t qil_elem_size(int dtype) { return dtype == QIL_C64 ? 16 : 8; }

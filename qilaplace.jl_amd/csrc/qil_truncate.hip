@@ -743,8 +743,10 @@ static int compress_impl(qil_mps* psi, int64_t maxdim, double tol, int sweeps, b
 //   3. the exact-gauge compress! (src/mps.jl:913-973) fixes the reference's post-conditions (bonds <= maxdim by the
 //      ITensors rule, unit norm in the tensors, norm moved into `amplitude`).
 // Cost O(n r D chi (D + chi + r)) instead of O(n (D chi)^3).
-extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
-                                  int64_t zip_maxdim, qil_mps** out) {
+// `ctx` = working context (stream + pool) of the call: psi's own, or a worker of it (qil_apply_compress_batch); the
+// operands are only read
+static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
+                             int64_t zip_maxdim, qil_mps** out) {
     QIL_REQUIRE(W && psi && out, QIL_EINVAL_ARG, "apply_compress: null argument");
     QIL_REQUIRE(W->ctx == psi->ctx, QIL_EINVAL_ARG, "apply: MPO and MPS belong to different contexts");
     QIL_REQUIRE(W->paired == psi->paired, QIL_EINVAL_ARG, "apply: cannot mix paired and single-register operands");
@@ -755,7 +757,6 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
     const int64_t N = psi->n();
     QIL_REQUIRE(N >= 2, QIL_EDOMAIN, "SignalMPS must have at least 2 sites.");
     QIL_REQUIRE(sweeps >= 1, QIL_EINVAL_ARG, "compress!: sweeps must be >= 1");
-    qil_context* ctx = psi->ctx;
     QIL_TRY(qil_ctx_activate(ctx));
     qil_call_scope call_scope(ctx);
     if (maxdim <= 0) maxdim = kNoCap;
@@ -767,7 +768,7 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
     const size_t e = qil_elem_size(odt);
     // right-canonical copy of psi: the zip's truncations then see (nearly) orthonormal environments
     qil_mps* phi = nullptr;
-    QIL_TRY(qil_mps_clone(psi, &phi));
+    QIL_TRY(qil_mps_clone_to(ctx, psi, &phi));
     qil_mps* res = nullptr;
     std::vector<void*> tmp;                          // every pool block this call owns outside a handle
     std::vector<void*> Asite((size_t)N), Wsite((size_t)N), Lenv((size_t)N, nullptr);
@@ -968,6 +969,33 @@ extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t 
     }
     *out = res;
     return QIL_OK;
+}
+
+extern "C" int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
+                                  int64_t zip_maxdim, qil_mps** out) {
+    QIL_REQUIRE(W && psi && out, QIL_EINVAL_ARG, "apply_compress: null argument");
+    return apply_compress_on(psi->ctx, W, psi, maxdim, tol, sweeps, zip_maxdim, out);
+}
+
+extern "C" int qil_apply_compress_batch(const qil_mpo* const* Ws, const qil_mps* const* psis, int64_t nb, int64_t maxdim,
+                                        double tol, int sweeps, int64_t zip_maxdim, qil_mps** outs) {
+    QIL_REQUIRE(nb >= 0 && ((Ws && psis && outs) || nb == 0), QIL_EINVAL_ARG, "apply_compress_batch: null argument");
+    if (nb == 0) return QIL_OK;
+    for (int64_t j = 0; j < nb; ++j) {
+        outs[j] = nullptr;
+        QIL_REQUIRE(Ws[j] && psis[j], QIL_EINVAL_ARG, "apply_compress_batch: item %lld is null", (long long)j);
+        QIL_REQUIRE(Ws[j]->ctx && Ws[j]->ctx == psis[0]->ctx && psis[j]->ctx == psis[0]->ctx, QIL_EINVAL_ARG,
+                    "apply_compress_batch: item %lld lives in another context", (long long)j);
+    }
+    const int st = qil_run_batch_on(psis[0]->ctx, nb, nullptr, [&](int64_t j, qil_context* work) {
+        return apply_compress_on(work, Ws[j], psis[j], maxdim, tol, sweeps, zip_maxdim, &outs[j]);
+    });
+    if (st != QIL_OK)                                   // all or nothing: a failed batch hands out no handles
+        for (int64_t j = 0; j < nb; ++j) {
+            if (outs[j]) qil_mps_destroy(outs[j]);
+            outs[j] = nullptr;
+        }
+    return st;
 }
 
 static int compress_impl(qil_mps* psi, int64_t maxdim, double tol, int sweeps, bool right_canonical);

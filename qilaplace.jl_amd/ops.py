@@ -304,6 +304,29 @@ def mpo_compress(W, direction="down", cutoff=1e-14, maxdim=None):
     return W
 
 
+def apply_compress_batch(Ws, psis, maxdim=None, tol=1e-12, sweeps=1, zip_maxdim=None):
+    """apply_compress(W, psi) for every (W, psi) pair -- the (signal, damping value) items of a sweep -- concurrently on the
+    context's streams.  `Ws` / `psis` may each be a single operand (used for every item) or a sequence; returns the list
+    of results."""
+    if hasattr(Ws, "handle"):
+        Ws = [Ws] * (len(psis) if not hasattr(psis, "handle") else 1)
+    if hasattr(psis, "handle"):
+        psis = [psis] * len(Ws)
+    Ws, psis = list(Ws), list(psis)
+    if len(Ws) != len(psis):
+        raise ValueError(f"apply_compress_batch: {len(Ws)} operators for {len(psis)} states")
+    for W, psi in zip(Ws, psis):
+        if W.paired != psi.paired:
+            raise TypeError("apply: PairedSiteMPO acts on ZTMPS, SingleSiteMPO on SignalMPS")
+    nb = len(Ws)
+    _, wa = _handle_array(Ws)
+    _, pa = _handle_array(psis)
+    outs = (C.c_void_p * max(nb, 1))()
+    L.check(L.lib.qil_apply_compress_batch(wa, pa, nb, _maxdim(maxdim), float(tol), int(sweeps),
+                                           0 if zip_maxdim is None else int(zip_maxdim), outs))
+    return [_wrap_like(psi, C.c_void_p(h)) for psi, h in zip(psis, outs[:nb])]
+
+
 def _handle_array(items):
     items = list(items)
     arr = (C.c_void_p * max(len(items), 1))(*[it.handle.value if isinstance(it.handle, C.c_void_p) else it.handle

@@ -1876,3 +1876,45 @@ def test_mpo_compress_batch_equals_item_by_item(qil):
                 assert np.array_equal(tr, tb)
     with pytest.raises(ValueError):
         qil.mpo_compress_batch(items, "sideways")
+
+
+def test_apply_compress_batch_equals_item_by_item(qil):
+    """qil_apply_compress_batch: (operator, state) pairs of a sweep -- one operator on several signals, several operators on
+    one signal, mixed dtypes -- give exactly the tensors of qil_apply_compress one pair at a time; operands are shared
+    between items and untouched; a failing item fails the call and hands out nothing."""
+    import gc
+    rng = np.random.default_rng(91)
+    ctx = qil.default_context()
+    gc.collect()
+    before = ctx.mem_info()["pool_in_use"]
+    L = 10
+    psis = [qil.SignalMPS(random_mps_data(saturated_profile(L, chi), rng, dtype=dt), amplitude=0.7 + j)
+            for j, (chi, dt) in enumerate([(8, np.float64), (16, np.complex128), (12, np.float64), (24, np.float64),
+                                           (8, np.complex128), (16, np.float64), (20, np.complex128)])]
+    Ws = [qil.SingleSiteMPO(random_mpo_data(saturated_profile(L, D, base=4), rng, dtype=dt))
+          for D, dt in [(6, np.complex128), (8, np.float64), (12, np.complex128)]]
+    host_before = [p.to_host() for p in psis]
+    # several operators x several signals: all 21 pairs in one call (more pairs than workers, operands repeated)
+    pairs = [(W, p) for W in Ws for p in psis]
+    ref = [qil.apply_compress(W, p, maxdim=12, tol=1e-8) for W, p in pairs]
+    got = qil.apply_compress_batch([W for W, _ in pairs], [p for _, p in pairs], maxdim=12, tol=1e-8)
+    assert len(got) == len(ref)
+    for r, g in zip(ref, got):
+        assert type(g) is type(r) and g.bond_dims == r.bond_dims and g.amplitude == r.amplitude
+        for tr, tg in zip(r.to_host(), g.to_host()):
+            assert np.array_equal(tr, tg)
+    for h, p in zip(host_before, psis):                                  # operands untouched
+        for th, tp in zip(h, p.to_host()):
+            assert np.array_equal(th, tp)
+    # single-operand broadcasting of the Python front end
+    one = qil.apply_compress_batch(Ws[0], psis, maxdim=12, tol=1e-8)
+    for r, g in zip(ref[:len(psis)], one):
+        assert g.bond_dims == r.bond_dims
+    # a mismatching pair (different lengths) fails the whole call
+    short = qil.SignalMPS(random_mps_data(saturated_profile(L - 2, 4), rng))
+    with pytest.raises(Exception, match="same number of sites"):
+        qil.apply_compress_batch([Ws[0]] * 3, [psis[0], short, psis[1]], maxdim=12)
+    assert ctx.unowned_bytes() == 0
+    del ref, got, one, pairs, psis, Ws, short, r, g, p, h
+    gc.collect()
+    assert ctx.mem_info()["pool_in_use"] == before
