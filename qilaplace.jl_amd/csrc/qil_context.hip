@@ -407,7 +407,8 @@ int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int pa
 }
 
 // ---------------------------------------------------------------- batches of independent chains
-static void ctx_transfer_block(qil_context* from, qil_context* to, void* p) {
+void qil_ctx_transfer(qil_context* from, qil_context* to, void* p) {
+    if (from == to || !p) return;
     auto it = from->live_blocks.find(p);
     if (it == from->live_blocks.end()) return;
     qil_context::live_block b = it->second;
@@ -421,7 +422,7 @@ static void ctx_transfer_block(qil_context* from, qil_context* to, void* p) {
 static void chain_move(qil_chain* c, qil_context* to) {
     qil_context* from = c->ctx;
     for (void* p : c->site)
-        if (p) ctx_transfer_block(from, to, p);
+        if (p) qil_ctx_transfer(from, to, p);
     from->chains.erase(c);
     c->ctx = to;
     to->chains.insert(c);

@@ -117,6 +117,8 @@ int qil_run_batch(struct qil_chain* const* items, int64_t nb, const std::functio
 // bound to a worker when the batch ends -- moved there by place(j, slot) beforehand or created by fn -- returns to home.
 int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int64_t, qil_context*)>& place,
                      const std::function<int(int64_t, qil_context*)>& fn);
+// hand a live pool block of `from` to `to` (bookkeeping only; the caller orders the streams)
+void qil_ctx_transfer(qil_context* from, qil_context* to, void* p);
 // device copy of psi owned by ctx (made on ctx's stream)
 int qil_mps_clone_to(qil_context* ctx, const struct qil_mps* psi, struct qil_mps** out);
 

@@ -310,6 +310,11 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     // exact compress! of the bond-1008 product 476 -> 445 ms; splitting every K >= 512 product costs the small chains 5 %)
     if (can_split && tiles * bt.count < 128 && (k >= split_min_k || (k >= 512 && tiles * bt.count <= 8)))
         splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / (tiles * bt.count)), 64);
+    // one wave of workgroups or less and a long K (the encoder's 16384 x 133 x 16384 sketches: 256 tiles): two to four K
+    // slices fill the second workgroup slot of every CU (37.7 -> see DESIGN 3.4)
+    static const bool fill_split = !(getenv("QIL_GEMM_FILL_SPLIT") && atoi(getenv("QIL_GEMM_FILL_SPLIT")) == 0);   // tuning aid
+    if (fill_split && splits < 2 && can_split && tiles * bt.count >= 128 && tiles * bt.count <= 384 && k >= 4096)
+        splits = (int)std::min<long long>(4, (767 / (tiles * bt.count)));
     if (splits < 2) splits = 1;
     long long kchunk = k, cstride = 0, c_bs = bt.c_bs;
     T* Cout = C;

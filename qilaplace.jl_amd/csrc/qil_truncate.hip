@@ -411,24 +411,39 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
         return QIL_OK;
     }
     void *Om = nullptr, *Y = nullptr, *Zq = nullptr, *Bt = nullptr;
+    const bool dbg = getenv("QIL_RSVD_DEBUG") != nullptr && m * n >= (getenv("QIL_RSVD_DEBUG_MIN") ? atoll(getenv("QIL_RSVD_DEBUG_MIN")) : (1LL << 24));
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rsvd] %lld x %lld, l = %lld: %s %.2f ms\n", (long long)m, (long long)n, (long long)l, what,
+                std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Om));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * l) * e, &Y));
     QIL_TRY(qil_dev_fill_normal(ctx, dt, Om, n * l, seed, 1.0));                        // rsvd.jl:74-76
+    lap("omega");
     QIL_TRY(qil_dev_gemm(ctx, dt, 1, 0, m, l, n, Z, n, Om, n, Y, m));                   // Y = M Omega (:79)
+    lap("Y = M Omega");
     // the basis that B = Q^H M and U = Q Uhat are built from (the last QR) must be orthonormal even when the sketch is
     // wider than the rank of M; the power iteration's intermediate bases only stabilise it
     QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0, q == 0));              // Q (:83)
+    lap("qr(Y)");
     if (q > 0) QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Zq));
     for (int it = 0; it < q; ++it) {                                                    // :86-95
         QIL_TRY(qil_dev_gemm(ctx, dt, 3, 0, n, l, m, Z, n, Y, m, Zq, n));               // M^H Q = conj(Z) Q
         QIL_TRY(qil_dev_qr_positive(ctx, dt, n, l, Zq, n, nullptr, 0));
         QIL_TRY(qil_dev_gemm(ctx, dt, 1, 0, m, l, n, Z, n, Zq, n, Y, m));               // M Qz
         QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0, it + 1 == q));
+        lap("power iteration (2 products + 2 QRs)");
     }
     qil_ctx_free(ctx, Om);
     if (Zq) qil_ctx_free(ctx, Zq);
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Bt));
     QIL_TRY(qil_dev_gemm(ctx, dt, 0, 3, n, l, m, Z, n, Y, m, Bt, n));                   // B^T = Z conj(Q) (:98)
+    lap("B^T = Z conj(Q)");
     // B^T = Ub Sb Vbh  =>  Uhat = Vbh^T,  (S V^h)^T = Ub Sb
     int64_t r = 0;
     void *UbS = nullptr, *Vbh = nullptr;
@@ -436,7 +451,9 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
     qil_ctx_free(ctx, Bt);
     void* L = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * m) * e, &L));
+    lap("svd(B^T)");
     QIL_TRY(qil_dev_gemm(ctx, dt, 0, 1, r, m, l, Vbh, r, Y, m, L, r));                  // U_M^T = Vbh Q^T (:114)
+    lap("U^T = Vbh Q^T");
     qil_ctx_free(ctx, Vbh);
     qil_ctx_free(ctx, Y);
     *rank = r;
@@ -459,8 +476,16 @@ struct EncodeParams {
 // with M's row index ordered (s_mid fastest, ..., s_first, lb) and its column index (rb fastest,
 // s_last, ..., s_mid+1).  Both children come out in the same chunk layout with no transposition:
 // left = U_M^T (k x rows), right = (S V^h)^T (cols x k).
+// Sub-trees of the bisection are independent: with `defer`, the children of the nodes at depth `defer_depth - 1` are not
+// descended into but recorded, and the caller runs them concurrently (qil_run_batch_on) -- below the first splits every
+// node is a short chain of small factorisations.
+struct TtTask {
+    void* X;
+    int64_t lb, rb, first, last;
+};
 int compress_tt(qil_context* ctx, int dt, void* X, int64_t lb, int64_t rb, int64_t first, int64_t last,
-                const EncodeParams& P, std::vector<void*>& sites, std::vector<int64_t>& dims) {
+                const EncodeParams& P, std::vector<void*>& sites, std::vector<int64_t>& dims, int depth = 0,
+                std::vector<TtTask>* defer = nullptr, int defer_depth = 0) {
     const size_t e = qil_elem_size(dt);
     if (first == last) {
         void* A = nullptr;
@@ -486,9 +511,70 @@ int compress_tt(qil_context* ctx, int dt, void* X, int64_t lb, int64_t rb, int64
     QIL_TRY(rsvd_rowmajor(ctx, dt, m, n, X, P.k, P.p, P.q, P.seed, P.cutoff, P.maxdim, P.mindim, &r, &L, &R,
                           nullptr));
     qil_ctx_free(ctx, X);
-    QIL_TRY(compress_tt(ctx, dt, L, lb, r, first, mid, P, sites, dims));
-    QIL_TRY(compress_tt(ctx, dt, R, r, rb, mid + 1, last, P, sites, dims));
+    if (defer && depth + 1 == defer_depth) {
+        defer->push_back(TtTask{L, lb, r, first, mid});
+        defer->push_back(TtTask{R, r, rb, mid + 1, last});
+        return QIL_OK;
+    }
+    QIL_TRY(compress_tt(ctx, dt, L, lb, r, first, mid, P, sites, dims, depth + 1, defer, defer_depth));
+    QIL_TRY(compress_tt(ctx, dt, R, r, rb, mid + 1, last, P, sites, dims, depth + 1, defer, defer_depth));
     return QIL_OK;
+}
+
+// The whole bisection.  The nodes of one level are independent, and so are the sub-trees below any level: the first
+// `par_depth` levels run level by level, the nodes of a level concurrently on the context's streams (qil_run_batch_on), and
+// the 2^par_depth sub-trees below them concurrently, each as a sequential recursion.  Same kernels on the same operands in
+// every order, so the MPS is bit-identical to the sequential recursion (QIL_ENCODE_PAR_DEPTH=0).
+static int compress_tt_root(qil_context* ctx, int dt, void* X, int64_t n, const EncodeParams& P, std::vector<void*>& sites,
+                            std::vector<int64_t>& dims) {
+    const int par_depth = getenv("QIL_ENCODE_PAR_DEPTH") ? atoi(getenv("QIL_ENCODE_PAR_DEPTH")) : 3;   // tuning aid (read per call); 0 = off
+    if (par_depth <= 0 || n < 16) return compress_tt(ctx, dt, X, 1, 1, 0, n - 1, P, sites, dims);
+    std::vector<TtTask> frontier{TtTask{X, 1, 1, 0, n - 1}};
+    int s = QIL_OK;
+    for (int level = 0; level <= par_depth && !frontier.empty() && s == QIL_OK; ++level) {
+        const bool whole = level == par_depth;               // last pass: every task is a whole sub-tree
+        const int64_t nt = (int64_t)frontier.size();
+        std::vector<qil_context*> where((size_t)nt, ctx);
+        std::vector<std::vector<int64_t>> tdims((size_t)nt, std::vector<int64_t>(dims.size(), 1));
+        std::vector<std::vector<TtTask>> kids((size_t)nt);
+        auto node = [&](int64_t j, qil_context* work) {
+            const TtTask& t = frontier[(size_t)j];
+            const int st = whole ? compress_tt(work, dt, t.X, t.lb, t.rb, t.first, t.last, P, sites, tdims[(size_t)j])
+                                 : compress_tt(work, dt, t.X, t.lb, t.rb, t.first, t.last, P, sites, tdims[(size_t)j], 0,
+                                               &kids[(size_t)j], 1);
+            if (st != QIL_OK) (void)qil_ctx_free(work, t.X);     // "unknown block" if the recursion released it already
+            return st;
+        };
+        if (nt == 1)
+            s = node(0, ctx);
+        else
+            s = qil_run_batch_on(
+                ctx, nt,
+                [&](int64_t j, qil_context* slot) {
+                    qil_ctx_transfer(ctx, slot, frontier[(size_t)j].X);
+                    where[(size_t)j] = slot;
+                },
+                node);
+        // everything the level produced comes home: finished sites, and the operands of the next level
+        std::vector<TtTask> next;
+        for (int64_t j = 0; j < nt; ++j) {
+            const TtTask& t = frontier[(size_t)j];
+            for (int64_t i = t.first; i <= t.last; ++i)
+                if (sites[(size_t)i] && (whole || t.first == t.last)) {
+                    qil_ctx_transfer(where[(size_t)j], ctx, sites[(size_t)i]);
+                    dims[(size_t)i] = tdims[(size_t)j][(size_t)i];
+                    dims[(size_t)i + 1] = tdims[(size_t)j][(size_t)i + 1];
+                }
+            for (const TtTask& c : kids[(size_t)j]) {
+                qil_ctx_transfer(where[(size_t)j], ctx, c.X);
+                next.push_back(c);
+            }
+        }
+        frontier.swap(next);
+    }
+    if (s != QIL_OK)
+        for (const TtTask& t : frontier) (void)qil_ctx_free(ctx, t.X);
+    return s;
 }
 
 // _tensor_to_mps_svd (SignalConverters.jl:77-98).  The carried tensor X[(s_n..s_i), alpha] is viewed
@@ -589,7 +675,7 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
     } else if (P.method == QIL_METHOD_SVD) {
         s = svd_sweep(ctx, dtype, X, n, P, sites, dims);
     } else {
-        s = compress_tt(ctx, dtype, X, 1, 1, 0, n - 1, P, sites, dims);
+        s = compress_tt_root(ctx, dtype, X, n, P, sites, dims);
     }
     if (s != QIL_OK) {
         for (void* p : sites)

@@ -1918,3 +1918,29 @@ def test_apply_compress_batch_equals_item_by_item(qil):
     del ref, got, one, pairs, psis, Ws, short, r, g, p, h
     gc.collect()
     assert ctx.mem_info()["pool_in_use"] == before
+
+
+def test_rsvd_encoder_concurrent_subtrees_equal_sequential(qil, monkeypatch):
+    """The bisection encoder runs the sub-trees below its first splits concurrently on the context's streams
+    (QIL_ENCODE_PAR_DEPTH, default 3): same kernels on the same operands, so the MPS is bit-identical to the sequential
+    recursion, for SignalMPS and ZTMPS, real and complex, at depths 1..3."""
+    rng = np.random.default_rng(123)
+    n = 18
+    x = rng.standard_normal(2 ** n) + 0.3 * np.sin(np.arange(2 ** n) * 0.01)
+    z = x + 1j * rng.standard_normal(2 ** n)
+    ctx = qil.default_context()
+    for sig, kw in ((x, dict(k=24, p=5, q=2)), (z, dict(k=16, p=4, q=1)), (x, dict(k=40, p=5, q=2, cutoff=1e-10, maxdim=32))):
+        monkeypatch.setenv("QIL_ENCODE_PAR_DEPTH", "0")
+        ref = qil.signal_mps(sig, method="rsvd", **kw)
+        refz = qil.signal_ztmps(sig, method="rsvd", **kw)
+        for depth in ("1", "2", "3", "5"):
+            monkeypatch.setenv("QIL_ENCODE_PAR_DEPTH", depth)
+            got = qil.signal_mps(sig, method="rsvd", **kw)
+            assert got.bond_dims == ref.bond_dims and got.amplitude == ref.amplitude
+            for tr, tg in zip(ref.to_host(), got.to_host()):
+                assert np.array_equal(tr, tg)
+            gotz = qil.signal_ztmps(sig, method="rsvd", **kw)
+            assert gotz.bond_dims == refz.bond_dims
+            for tr, tg in zip(refz.to_host(), gotz.to_host()):
+                assert np.array_equal(tr, tg)
+    assert ctx.unowned_bytes() == 0
