@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <system_error>
 #include <thread>
 
 // ---------------------------------------------------------------- errors
@@ -407,6 +408,8 @@ int qil_chain_alloc(qil_context* ctx, qil_chain* c, int64_t n, int dtype, int pa
 }
 
 // ---------------------------------------------------------------- batches of independent chains
+static void chain_move(qil_chain* c, qil_context* to);
+
 void qil_ctx_transfer(qil_context* from, qil_context* to, void* p) {
     if (from == to || !p) return;
     auto it = from->live_blocks.find(p);
@@ -418,6 +421,8 @@ void qil_ctx_transfer(qil_context* from, qil_context* to, void* p) {
     to->live_blocks.emplace(p, b);
     to->bytes_in_use += b.bytes;
 }
+
+void qil_chain_rebind(qil_chain* c, qil_context* to) { chain_move(c, to); }
 
 static void chain_move(qil_chain* c, qil_context* to) {
     qil_context* from = c->ctx;
@@ -497,8 +502,16 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     };
     std::vector<std::thread> threads;
     threads.reserve((size_t)nw - 1);
-    for (int k = 1; k < nw; ++k) threads.emplace_back(drive, k);
+    std::vector<int> inline_slots;                            // slots whose thread could not be started run here afterwards
+    for (int k = 1; k < nw; ++k) {
+        try {
+            threads.emplace_back(drive, k);
+        } catch (const std::system_error&) {
+            inline_slots.push_back(k);
+        }
+    }
     drive(0);
+    for (int k : inline_slots) drive(k);
     for (auto& t : threads) t.join();
     home->lending = false;
     // every stream of the batch is idle: the chains the workers hold (moved there or created there), what is left of the

@@ -119,6 +119,8 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
                      const std::function<int(int64_t, qil_context*)>& fn);
 // hand a live pool block of `from` to `to` (bookkeeping only; the caller orders the streams)
 void qil_ctx_transfer(qil_context* from, qil_context* to, void* p);
+// hand a whole chain (its site blocks and its registration) to another context of the same device
+void qil_chain_rebind(struct qil_chain* c, qil_context* to);
 // device copy of psi owned by ctx (made on ctx's stream)
 int qil_mps_clone_to(qil_context* ctx, const struct qil_mps* psi, struct qil_mps** out);
 

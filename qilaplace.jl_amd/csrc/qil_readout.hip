@@ -10,6 +10,9 @@
 // One workgroup owns one query and walks all sites inside ONE launch; each output entry is a
 // dot product along the contiguous alpha axis, reduced with wavefront shuffles.
 #include "qil_internal.h"
+#include <set>
+#include <mutex>
+#include <map>
 
 namespace {
 
@@ -482,13 +485,45 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
     QIL_TRY(upload_bits(ctx, nb, psi->n(), bits, &dbits, 1));
     void* dout = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nw * nb) * 16, &dout));
-    for (int64_t j = 0; j < nw; ++j) {
-        QIL_REQUIRE(Ws[j], QIL_EINVAL_ARG, "apply_coefficient_sweep: null operator %lld", (long long)j);
+    bool distinct = true;                                 // operators change context for the batch: each must be its own handle
+    {
+        std::set<const qil_mpo*> seen;
+        for (int64_t j = 0; j < nw; ++j) {
+            QIL_REQUIRE(Ws[j], QIL_EINVAL_ARG, "apply_coefficient_sweep: null operator %lld", (long long)j);
+            QIL_REQUIRE(Ws[j]->ctx == ctx, QIL_EINVAL_ARG, "apply: MPO and MPS belong to different contexts");
+            distinct = distinct && seen.insert(Ws[j]).second;
+        }
+    }
+    auto one = [&](const qil_mpo* W, const qil_mps* state, int64_t j) {
         qil_mps* prod = nullptr;
-        QIL_TRY(qil_apply(Ws[j], psi, &prod));
-        int st = coefficient_enqueue(prod, nb, dbits, static_cast<char*>(dout) + (size_t)(j * nb) * 16);
+        QIL_TRY(qil_apply(W, state, &prod));
+        const int st = coefficient_enqueue(prod, nb, dbits, static_cast<char*>(dout) + (size_t)(j * nb) * 16);
         qil_mps_destroy(prod);
+        return st;
+    };
+    static const bool concurrent = !(getenv("QIL_SWEEP_CONCURRENT") && atoi(getenv("QIL_SWEEP_CONCURRENT")) == 0);   // tuning aid
+    if (concurrent && distinct && nw >= 4) {
+        // every value's product + read-out is a chain of ~100 small launches: the values run concurrently on the context's
+        // streams.  The operators move to their slot for the duration of the call (bookkeeping only), every slot reads its
+        // own copy of the state (MBs), bits and results are shared device buffers.
+        std::map<qil_context*, qil_mps*> copy;            // slot -> its copy of psi, made by the slot's first item
+        std::mutex copy_mutex;
+        const int st = qil_run_batch_on(
+            ctx, nw, [&](int64_t j, qil_context* slot) { qil_chain_rebind(const_cast<qil_mpo*>(Ws[j]), slot); },
+            [&](int64_t j, qil_context* work) {
+                const qil_mps* state = psi;
+                if (work != ctx) {
+                    std::lock_guard<std::mutex> lock(copy_mutex);
+                    qil_mps*& c = copy[work];
+                    if (!c) QIL_TRY(qil_mps_clone_to(work, psi, &c));
+                    state = c;
+                }
+                return one(Ws[j], state, j);
+            });
+        for (auto& kv : copy) qil_mps_destroy(kv.second);      // back in the home context like every chain of the batch
         QIL_TRY(st);
+    } else {
+        for (int64_t j = 0; j < nw; ++j) QIL_TRY(one(Ws[j], psi, j));
     }
     QIL_HIP(hipMemcpyAsync(out, dout, (size_t)(nw * nb) * 16, hipMemcpyDeviceToHost, ctx->stream));
     QIL_HIP(hipStreamSynchronize(ctx->stream));
