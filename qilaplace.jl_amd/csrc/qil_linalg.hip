@@ -991,7 +991,10 @@ __device__ __forceinline__ c64 hh_mul_conj<c64>(c64 a, c64 b) {
 __device__ __forceinline__ double hh_cmul(double a, double b) { return a * b; }
 __device__ __forceinline__ c64 hh_cmul(c64 a, c64 b) { return c64{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ double hh_wave_sum(double v) { return wave_sum(v); }
-__device__ __forceinline__ c64 hh_wave_sum(c64 v) { return c64{wave_sum(v.re), wave_sum(v.im)}; }
+__device__ __forceinline__ c64 hh_wave_sum(c64 v) {     // both parts in one reduction tree; every call site has the whole wave active
+    wave_sum2(v.re, v.im);
+    return v;
+}
 
 // Row predicates are kept out of the instruction stream (a select around a load becomes a branch with a wait inside, one
 // per element): every column has a zero SINK row m behind its data, lanes beyond the matrix read and write that row, and
@@ -1043,19 +1046,25 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
         }
         s2 = wave_sum(s2);
         const T alpha = x[rr < m ? rr : m];
+        // the column's norm, |alpha| and kappa sit on the dependent chain of every column: reciprocal square roots and
+        // reciprocals with one Newton step (1-2 ulp) instead of the IEEE sqrt / divide sequences (~4 x 30 instructions)
         const double a2 = abs2_t(alpha);
-        const double nrm = sqrt(a2 + s2);
+        const double t2 = a2 + s2;
+        const double nrm = t2 > 0.0 ? t2 * rsqrt_refined(t2) : 0.0;
         const double rn = refn[j];
         const bool dep = rr >= m || !(nrm > 1e-13 * rn) || rn == 0.0;
         double kappa = 0.0, absa = 0.0;
         T pa{}, diff{};
         if (!dep) {
-            absa = sqrt(a2);
             // phase of alpha (1 if alpha == 0): beta = -phase * nrm, u_r = alpha - beta = phase (|alpha| + nrm)
             reinterpret_cast<double*>(&pa)[0] = 1.0;
-            if (absa > 0.0) pa = scale_t(alpha, 1.0 / absa);
+            if (a2 > 0.0) {
+                const double ra = rsqrt_refined(a2);
+                absa = a2 * ra;
+                pa = scale_t(alpha, ra);
+            }
             diff = scale_t(pa, absa + nrm);
-            kappa = 1.0 / (nrm * (nrm + absa));
+            kappa = rcp_refined(nrm * (nrm + absa));
             for (int c = j + 1 + ((wave - (j + 1)) % NW + NW) % NW; c < b; c += NW) {
                 T* y = Ps + (size_t)la * c;
                 T ys[KM];
