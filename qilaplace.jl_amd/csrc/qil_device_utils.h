@@ -193,6 +193,51 @@ __device__ __forceinline__ bool jacobi_rotation(double al, double be, double gr,
     return true;
 }
 
+// Rotation of a column pair from |x|^2 = al, |y|^2 = be, x^H y = gr + i gi:  x' = c x - conj(sg) y,  y' = sg x + c y with
+// sg = s e^{i phi} = (sr, si), e^{i phi} = g / |g|, s signed by be - al; sabs = |sg|, gabs ~ |g|.
+// The dependent chain of this computation sits on the critical path of every inner round, so it is kept short: the angle comes
+// from the raw hardware reciprocal square roots (relative error ~1e-8, which only decides how completely THIS pair is
+// annihilated -- quadratic convergence absorbs it), and unitarity, which must hold to rounding because the errors of
+// thousands of rotations add up in the singular values, is restored exactly afterwards: with eps = c0^2 + |sg0|^2 - 1
+// (|eps| < 1e-6) both are scaled by 1 / sqrt(1 + eps) = 1 - eps / 2 + 3 eps^2 / 8 + O(eps^3 < 1e-18).
+template <bool CX>
+__device__ __forceinline__ bool rotation_fast(double al, double be, double gr, double gi, double tol, double& c, double& sr,
+                                              double& si, double& sabs, double& gabs, bool& big) {
+    const double g2 = CX ? fma(gr, gr, gi * gi) : gr * gr;
+    const double ab = al * be;
+    big = g2 > kQuadraticOff * kQuadraticOff * ab;
+    if (!(g2 > tol * tol * ab) || g2 == 0.0) return false;
+    const double d = be - al;
+    const double rh = __builtin_amdgcn_rsq(fma(d, d, 4.0 * g2));
+    const double c2 = fma(0.5 * fabs(d), rh, 0.5);
+    const double rc = __builtin_amdgcn_rsq(c2);
+    const double c0 = c2 * rc;
+    const double q = copysign(rh * rc, d);            // sg0 = q g
+    const double sr0 = q * gr, si0 = CX ? q * gi : 0.0;
+    const double s02 = CX ? fma(sr0, sr0, si0 * si0) : sr0 * sr0;
+    const double eps = fma(c0, c0, s02 - 1.0);
+    const double f = fma(eps, fma(eps, 0.375, -0.5), 1.0);
+    c = c0 * f;
+    sr = sr0 * f;
+    si = si0 * f;
+    // |sg| and |g| only feed the carried norms (re-taken from the data at every staging): raw accuracy is enough
+    gabs = CX ? g2 * __builtin_amdgcn_rsq(g2) : fabs(gr);
+    sabs = fabs(q) * gabs * f;
+    return true;
+}
+__device__ __forceinline__ void rotate_pair_sg(double& x, double& y, double c, double sr, double) {
+    const double xn = fma(c, x, -sr * y), yn = fma(sr, x, c * y);
+    x = xn;
+    y = yn;
+}
+__device__ __forceinline__ void rotate_pair_sg(c64& x, c64& y, double c, double sr, double si) {
+    // x' = c x - conj(sg) y ;  y' = sg x + c y
+    const c64 xn{fma(c, x.re, -fma(sr, y.re, si * y.im)), fma(c, x.im, -fma(sr, y.im, -si * y.re))};
+    const c64 yn{fma(c, y.re, fma(sr, x.re, -si * x.im)), fma(c, y.im, fma(sr, x.im, si * x.re))};
+    x = xn;
+    y = yn;
+}
+
 // Whole one-sided Jacobi SVD iteration in ONE launch of ONE 1024-thread workgroup: V = I, sweeps of the
 // round-robin tournament until no pair rotates, then the column norms.  Each wave owns whole column
 // pairs (lanes stride over rows, shuffle reductions), pairs of a round are disjoint, rounds are
@@ -243,13 +288,13 @@ __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ld
                 gr = group_sum<G>(gr);
                 if (sizeof(T) == 16) gi = group_sum<G>(gi);
                 if (al < negligible || be < negligible) continue;     // rounding residue: see kNegligibleColumn
-                double c, sn, pr, pi;
+                double c, sr, si, sabs, gabs;
                 bool big;
-                if (!jacobi_rotation<sizeof(T) == 16>(al, be, gr, gi, tol, c, sn, pr, pi, big)) continue;
+                if (!rotation_fast<sizeof(T) == 16>(al, be, gr, gi, tol, c, sr, si, sabs, gabs, big)) continue;
                 if (lane == 0) atomicOr(s_rot, big ? 3 : 1);
                 for (int r = lane; r < m; r += G) {
                     T x = ap[r], y = aq[r];
-                    rotate_pair(x, y, c, sn, pr, pi);
+                    rotate_pair_sg(x, y, c, sr, si);
                     ap[r] = x;
                     aq[r] = y;
                 }
@@ -257,7 +302,7 @@ __device__ __forceinline__ void jacobi_sweeps(T* A, int lda, int m, T* V, int ld
                 T* vq = V + ldv * q;
                 for (int r = lane; r < n; r += G) {
                     T x = vp[r], y = vq[r];
-                    rotate_pair(x, y, c, sn, pr, pi);
+                    rotate_pair_sg(x, y, c, sr, si);
                     vp[r] = x;
                     vq[r] = y;
                 }

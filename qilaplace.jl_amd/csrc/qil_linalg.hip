@@ -1625,51 +1625,6 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
 // values).  Half the LDS per column, half the rotation work per pair, cached squared norms (one wave reduction per pair
 // instead of three).
 
-// Rotation of a column pair from |x|^2 = al, |y|^2 = be, x^H y = gr + i gi:  x' = c x - conj(sg) y,  y' = sg x + c y with
-// sg = s e^{i phi} = (sr, si), e^{i phi} = g / |g|, s signed by be - al; sabs = |sg|, gabs ~ |g|.
-// The dependent chain of this computation sits on the critical path of every inner round, so it is kept short: the angle comes
-// from the raw hardware reciprocal square roots (relative error ~1e-8, which only decides how completely THIS pair is
-// annihilated -- quadratic convergence absorbs it), and unitarity, which must hold to rounding because the errors of
-// thousands of rotations add up in the singular values, is restored exactly afterwards: with eps = c0^2 + |sg0|^2 - 1
-// (|eps| < 1e-6) both are scaled by 1 / sqrt(1 + eps) = 1 - eps / 2 + 3 eps^2 / 8 + O(eps^3 < 1e-18).
-template <bool CX>
-__device__ __forceinline__ bool rotation_fast(double al, double be, double gr, double gi, double tol, double& c, double& sr,
-                                              double& si, double& sabs, double& gabs, bool& big) {
-    const double g2 = CX ? fma(gr, gr, gi * gi) : gr * gr;
-    const double ab = al * be;
-    big = g2 > kQuadraticOff * kQuadraticOff * ab;
-    if (!(g2 > tol * tol * ab) || g2 == 0.0) return false;
-    const double d = be - al;
-    const double rh = __builtin_amdgcn_rsq(fma(d, d, 4.0 * g2));
-    const double c2 = fma(0.5 * fabs(d), rh, 0.5);
-    const double rc = __builtin_amdgcn_rsq(c2);
-    const double c0 = c2 * rc;
-    const double q = copysign(rh * rc, d);            // sg0 = q g
-    const double sr0 = q * gr, si0 = CX ? q * gi : 0.0;
-    const double s02 = CX ? fma(sr0, sr0, si0 * si0) : sr0 * sr0;
-    const double eps = fma(c0, c0, s02 - 1.0);
-    const double f = fma(eps, fma(eps, 0.375, -0.5), 1.0);
-    c = c0 * f;
-    sr = sr0 * f;
-    si = si0 * f;
-    // |sg| and |g| only feed the carried norms (re-taken from the data at every staging): raw accuracy is enough
-    gabs = CX ? g2 * __builtin_amdgcn_rsq(g2) : fabs(gr);
-    sabs = fabs(q) * gabs * f;
-    return true;
-}
-__device__ __forceinline__ void rotate_pair_sg(double& x, double& y, double c, double sr, double) {
-    const double xn = fma(c, x, -sr * y), yn = fma(sr, x, c * y);
-    x = xn;
-    y = yn;
-}
-__device__ __forceinline__ void rotate_pair_sg(c64& x, c64& y, double c, double sr, double si) {
-    // x' = c x - conj(sg) y ;  y' = sg x + c y
-    const c64 xn{fma(c, x.re, -fma(sr, y.re, si * y.im)), fma(c, x.im, -fma(sr, y.im, -si * y.re))};
-    const c64 yn{fma(c, y.re, fma(sr, x.re, -si * x.im)), fma(c, y.im, fma(sr, x.im, si * x.re))};
-    x = xn;
-    y = yn;
-}
-
 // One outer round of the block tournament without V: workgroup i holds the column blocks (P, Q) of this round in LDS and
 // orthogonalises their column pairs in BB (cross pairs; AP: all 2 BB - 1 rounds of all pairs) inner rounds.
 // G lanes per column pair (64 = one wave per pair, 32 = two pairs per wave sharing the instruction stream of the rotation),
