@@ -1944,3 +1944,31 @@ def test_rsvd_encoder_concurrent_subtrees_equal_sequential(qil, monkeypatch):
             for tr, tg in zip(refz.to_host(), gotz.to_host()):
                 assert np.array_equal(tr, tg)
     assert ctx.unowned_bytes() == 0
+
+
+def test_batches_on_a_second_context_and_one_worker(qil, monkeypatch):
+    """The batch runner belongs to the items' context, not to the default one: the same calls on a second context give the
+    same tensors, and that context can be destroyed (with its worker contexts) while another keeps working."""
+    rng = np.random.default_rng(321)
+    data = [random_mps_data(saturated_profile(9, chi), rng) for chi in (12, 20, 16, 24, 8, 30)]
+    ref = [qil.compress(qil.SignalMPS([t.copy() for t in a]), maxdim=7, tol=1e-9) for a in data]
+    other = qil.Context(0)
+    items = [qil.SignalMPS([t.copy() for t in a], ctx=other) for a in data]
+    qil.compress_batch(items, maxdim=7, tol=1e-9)
+    for r, b in zip(ref, items):
+        assert b.bond_dims == r.bond_dims
+        for tr, tb in zip(r.to_host(), b.to_host()):
+            assert np.array_equal(tr, tb)
+    x = rng.standard_normal(2 ** 16)
+    e_ref = qil.signal_mps(x, method="rsvd", k=20, p=5, q=2)
+    e_other = qil.signal_mps(x, method="rsvd", k=20, p=5, q=2, ctx=other)
+    for tr, tb in zip(e_ref.to_host(), e_other.to_host()):
+        assert np.array_equal(tr, tb)
+    assert other.unowned_bytes() == 0
+    del items, e_other
+    import gc
+    gc.collect()
+    other.close()                                   # destroys its worker contexts with it
+    again = qil.compress_batch([qil.SignalMPS([t.copy() for t in a]) for a in data], maxdim=7, tol=1e-9)
+    for r, b in zip(ref, again):
+        assert b.bond_dims == r.bond_dims
