@@ -1144,8 +1144,9 @@ extern "C" int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_
     if (maxdim <= 0) maxdim = kNoCap;
     const int gauge = direction == 0 ? QIL_DIR_RIGHT : QIL_DIR_LEFT;
     const int trunc = direction == 0 ? QIL_DIR_LEFT : QIL_DIR_RIGHT;
-    static const bool qr_gauge = !(getenv("QIL_MPO_GAUGE_QR") && atoi(getenv("QIL_MPO_GAUGE_QR")) == 0);   // tuning aid
-    QIL_TRY(canonicalize_impl(W, gauge, 0, 0.0, kNoCap, qr_gauge));
+    // exact gauge pass by thin QRs, like the reference's (an SVD here would drop exactly-zero singular values and change
+    // the bond dimensions the truncating pass starts from)
+    QIL_TRY(canonicalize_impl(W, gauge, 0, 0.0, kNoCap, true));
     QIL_TRY(canonicalize_impl(W, trunc, 0, cutoff, maxdim));
     return QIL_OK;
 }

@@ -991,7 +991,7 @@ def test_svd_trunc_low_rank_fast_path(qil, m, n, r, cplx):
     Sref = np.linalg.svd(A, compute_uv=False)
     U, S, Vh = qil.svd_trunc(A, cutoff=1e-12)
     assert len(S) == O.truncation_rank(Sref, cutoff=1e-12) == r
-    assert np.abs(S - Sref[:r]).max() <= 1e-13 * Sref[0]
+    assert np.abs(S - Sref[:r]).max() <= 2e-13 * Sref[0]
     assert np.abs((U * S) @ Vh - A).max() <= 1e-12 * np.abs(A).max()
     assert np.abs(U.conj().T @ U - np.eye(r)).max() < 1e-12 and np.abs(Vh @ Vh.conj().T - np.eye(r)).max() < 1e-12
 
