@@ -310,6 +310,11 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     // exact compress! of the bond-1008 product 476 -> 445 ms; splitting every K >= 512 product costs the small chains 5 %)
     if (can_split && tiles * bt.count < 128 && (k >= split_min_k || (k >= 512 && tiles * bt.count <= 8)))
         splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / (tiles * bt.count)), 64);
+    // one to four output tiles (complex: a 64 x 64 tile is 0.85 us of MFMA per 16 k on ITS ONE CU -- the projections and
+    // environment products of the truncation chains spend 20-40 us there): slices of 64 k from K = 128 on
+    static const long long tiny_k = getenv("QIL_GEMM_TINY_SPLIT_K") ? atoll(getenv("QIL_GEMM_TINY_SPLIT_K")) : 128;   // tuning aid; 0 = off (fused apply-compress 263 -> 244 ms, exact route 439 -> 417 ms)
+    if (tiny_k > 0 && can_split && tiles * bt.count <= 4 && k >= tiny_k)
+        splits = std::max<int>(splits, (int)std::min<long long>(k / 64, 32));
     // one wave of workgroups or less and a long K (the encoder's 16384 x 133 x 16384 sketches: 256 tiles): two to four K
     // slices fill the second workgroup slot of every CU (37.7 -> see DESIGN 3.4)
     static const bool fill_split = !(getenv("QIL_GEMM_FILL_SPLIT") && atoi(getenv("QIL_GEMM_FILL_SPLIT")) == 0);   // tuning aid
