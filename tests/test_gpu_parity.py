@@ -930,6 +930,16 @@ def test_quickstart_example_runs(qil):
     assert r.stdout.strip().endswith("OK")
 
 
+def test_damping_sweep_example_runs(qil):
+    """examples/damping_sweep.py: the batch entry points on a small damping sweep against the closed form."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "damping_sweep.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("OK")
+
+
 # ---------------------------------------------------------------- QR / RSVD on numerically rank-deficient inputs
 @pytest.mark.parametrize("m,l", [(32, 8), (32, 17), (32, 30), (100, 30), (5000, 30), (300, 64)])
 @pytest.mark.parametrize("dt", [np.float64, np.complex128])

@@ -1,7 +1,8 @@
 #!/bin/bash
+cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-t() { echo "== $*"; env "$@" python $R/tools/_truncate_block.py 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:round(v,1) for k,v in d.items() if k in ('fused_apply_compress_ms','exact_compress_ms','compress_chi256_to_128_24_sites_ms')})"; env "$@" python $R/tools/_prof_compress.py 64 2>&1 | tail -1; }
-t QIL_QR_HH_SINGLE_MIN=17
-t QIL_QR_HH_SINGLE_MIN=100
-t QIL_QR_HH_SINGLE_MIN=9
-python -m pytest $R/tests -x -q -m gpu -k "qr or svd" 2>&1 | tail -2
+rm -rf /tmp/prof_h; mkdir -p /tmp/prof_h
+rocprofv3 --hip-trace --kernel-trace --stats -d /tmp/prof_h --output-format csv -- python3 $R/tools/_prof_compress.py 256 > /tmp/prof_h/log 2>&1
+grep compress /tmp/prof_h/log
+f=$(find /tmp/prof_h -name '*hip_api_stats.csv' | head -1)
+echo "$f"; head -14 "$f" | cut -c1-150
