@@ -241,6 +241,15 @@ int qil_signal_mps(qil_context* ctx, const void* x, int64_t len, int dtype, int 
 int qil_signal_ztmps(qil_context* ctx, const void* x, int64_t len, int dtype, int method,
                      double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed,
                      int64_t mindim, qil_mps** out);
+/* nb signals of one length and dtype encoded concurrently on the context's streams -- the serial loop over signal kinds
+ * of scripts/benchmark/zt_full_runtime.jl:151-221.  outs[j] receives exactly qil_signal_mps / qil_signal_ztmps(xs[j], ...).
+ * On failure the first failing signal's status is returned and NO handle is handed out.                            */
+int qil_signal_mps_batch(qil_context* ctx, const void* const* xs, int64_t nb, int64_t len, int dtype, int method,
+                         double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed, int64_t mindim,
+                         qil_mps** outs);
+int qil_signal_ztmps_batch(qil_context* ctx, const void* const* xs, int64_t nb, int64_t len, int dtype, int method,
+                           double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed, int64_t mindim,
+                           qil_mps** outs);
 /* rsvd(A, Linds...; k, p, q, random_seed, cutoff, maxdim, mindim) src/linalg/rsvd.jl:38-121
  * on the matricised operand A (m x n, host, column-major).  Outputs (host, caller
  * allocated for rank min(k+p, m, n)): U m x r, S r, Vh r x n; *rank = r kept.        */

@@ -229,6 +229,32 @@ function signal_mps_device(x::AbstractVector{<:Number}; method::Symbol=:svd, cut
     return finalizer(_free!, DeviceMPS(r[], sites, paired))
 end
 
+# several signals of one length encoded concurrently (the loop over signal kinds of scripts/benchmark/zt_full_runtime.jl:151-221)
+function signal_mps_device(xs::AbstractVector{<:AbstractVector{<:Number}}; method::Symbol=:svd, cutoff::Real=1e-15,
+                           maxdim::Int=typemax(Int), k::Int=20, p::Int=10, q::Int=0, random_seed::Int=1234,
+                           mindim::Int=1, paired::Bool=false)
+    method in (:svd, :rsvd) || throw(ArgumentError("tensor_to_mps: unknown method $method. Use :svd or :rsvd."))
+    T = any(x -> eltype(x) <: Complex, xs) ? ComplexF64 : Float64
+    host = [Vector{T}(x) for x in xs]
+    all(x -> length(x) == length(host[1]), host) || throw(ArgumentError("signal batch: all signals must have one length"))
+    ptrs = Ptr{Cvoid}[pointer(x) for x in host]
+    outs = fill(Ptr{Cvoid}(C_NULL), length(host))
+    meth = method == :svd ? 0 : 1
+    GC.@preserve host begin
+        if paired
+            check(ccall((:qil_signal_ztmps_batch, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int64, Int64, Cint, Cint, Cdouble, Int64, Int64, Int64, Cint, UInt64, Int64, Ptr{Ptr{Cvoid}}),
+                ctx().h, ptrs, length(host), length(host[1]), _code(T), meth, cutoff, maxdim, k, p, q, random_seed, mindim, outs))
+        else
+            check(ccall((:qil_signal_mps_batch, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int64, Int64, Cint, Cint, Cdouble, Int64, Int64, Int64, Cint, UInt64, Int64, Ptr{Ptr{Cvoid}}),
+                ctx().h, ptrs, length(host), length(host[1]), _code(T), meth, cutoff, maxdim, k, p, q, random_seed, mindim, outs))
+        end
+    end
+    n = max(1, round(Int, log2(length(host[1]))))
+    return [finalizer(_free!, DeviceMPS(h, [Index(2; tags="site-$i") for i in 1:(paired ? 2n : n)], paired)) for h in outs]
+end
+
 # ---------------------------------------------------------------- back to the reference's host types
 # Site tensors come back in the canonical order (left bond, s, right bond); fresh bond Indices are made
 # (the reference does the same after every apply: apply.jl:105-119) and the site Indices are the shared ones.

@@ -16,7 +16,8 @@ from .containers import (Context, default_context, set_default_context, device_c
                          SignalMPS, ZTMPS, SingleSiteMPO, PairedSiteMPO)
 from .ops import (apply, apply_compress, apply_compress_batch, mpo_compress, compress_batch, mpo_compress_batch, mps_block, coefficient, coefficient_batch, apply_coefficient_batch, apply_coefficient_sweep,  # noqa: F401
                   marginal_batch, coefficient_grid, laplace_values,
-                  mps_to_vector, norm, canonicalize, compress, signal_mps, signal_ztmps, rsvd,
+                  mps_to_vector, norm, canonicalize, compress, signal_mps, signal_ztmps, signal_mps_batch,
+                  signal_ztmps_batch, rsvd,
                   svd_trunc, gemm, gemm_device_time, qr_positive)
 from .builders import (build_qft_mpo, build_dt_mpo, build_zt_mpo, qft_mpo_tensors,  # noqa: F401
                        dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many, build_dt_mpo_batch,
@@ -28,7 +29,7 @@ __all__ = [
     "Context", "default_context", "set_default_context", "device_count",
     "SignalMPS", "ZTMPS", "SingleSiteMPO", "PairedSiteMPO",
     "apply", "apply_compress", "apply_compress_batch", "coefficient", "coefficient_batch", "apply_coefficient_batch", "apply_coefficient_sweep", "marginal_batch", "coefficient_grid", "laplace_values", "mps_to_vector", "norm",
-    "canonicalize", "compress", "signal_mps", "signal_ztmps", "rsvd", "svd_trunc", "gemm",
+    "canonicalize", "compress", "signal_mps", "signal_ztmps", "signal_mps_batch", "signal_ztmps_batch", "rsvd", "svd_trunc", "gemm",
     "build_qft_mpo", "build_dt_mpo", "build_zt_mpo", "qft_mpo_tensors", "dt_mpo_tensors", "zt_mpo_tensors",
     "dt_mpo_tensors_many", "build_dt_mpo_batch", "build_zt_mpo_batch", "zt_qft_chain_tensors", "mpo_compress", "compress_batch", "mpo_compress_batch", "mps_block",
     "save", "load",

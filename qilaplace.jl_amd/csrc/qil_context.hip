@@ -441,7 +441,9 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     // (measured with rocprofv3 --kernel-trace: a fifth stream lands on an occupied queue and its chain runs at half speed).
     // The calling thread drives the home stream itself, so nw chains use nw streams.
     static const int max_workers = getenv("QIL_BATCH_WORKERS") ? atoi(getenv("QIL_BATCH_WORKERS")) : 8;   // tuning aid (8 streams on the 4 queues: 2.09x single for 8 chains, 4 streams: 2.22x)
-    const int nw = (int)std::min<int64_t>(nb, std::max(1, max_workers));
+    // a context that is already one slot of a running batch (the home context during its own batch, or a worker) runs
+    // nested batches inline: the slots are taken, and the batch mutex is held by the outer call
+    const int nw = (home->lending || home->parent) ? 1 : (int)std::min<int64_t>(nb, std::max(1, max_workers));
     if (nw <= 1) {
         int first = QIL_OK;
         std::string msg;

@@ -528,7 +528,8 @@ int compress_tt(qil_context* ctx, int dt, void* X, int64_t lb, int64_t rb, int64
 static int compress_tt_root(qil_context* ctx, int dt, void* X, int64_t n, const EncodeParams& P, std::vector<void*>& sites,
                             std::vector<int64_t>& dims) {
     const int par_depth = getenv("QIL_ENCODE_PAR_DEPTH") ? atoi(getenv("QIL_ENCODE_PAR_DEPTH")) : 3;   // tuning aid (read per call); 0 = off
-    if (par_depth <= 0 || n < 16) return compress_tt(ctx, dt, X, 1, 1, 0, n - 1, P, sites, dims);
+    // (a context that is already one slot of a batch -- qil_signal_mps_batch -- encodes sequentially)
+    if (par_depth <= 0 || n < 16 || ctx->parent || ctx->lending) return compress_tt(ctx, dt, X, 1, 1, 0, n - 1, P, sites, dims);
     std::vector<TtTask> frontier{TtTask{X, 1, 1, 0, n - 1}};
     int s = QIL_OK;
     for (int level = 0; level <= par_depth && !frontier.empty() && s == QIL_OK; ++level) {
@@ -1297,4 +1298,39 @@ extern "C" int qil_signal_ztmps(qil_context* ctx, const void* x, int64_t len, in
     }
     *out = zt;
     return QIL_OK;
+}
+
+// nb signals of one length encoded concurrently (the serial loop over signal kinds of
+// scripts/benchmark/zt_full_runtime.jl:151-221): outs[j] = signal_mps / signal_ztmps(xs[j]; ...), each encoder on one slot
+// of the context's streams.  All or nothing on failure.
+static int signal_batch(qil_context* ctx, const void* const* xs, int64_t nb, int64_t len, int dtype, int method, double cutoff,
+                        int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed, int64_t mindim, int paired,
+                        qil_mps** outs) {
+    QIL_REQUIRE(ctx && nb >= 0 && ((xs && outs) || nb == 0), QIL_EINVAL_ARG, "signal batch: null argument");
+    for (int64_t j = 0; j < nb; ++j) {
+        outs[j] = nullptr;
+        QIL_REQUIRE(xs[j], QIL_EINVAL_ARG, "signal batch: signal %lld is null", (long long)j);
+    }
+    const int st = qil_run_batch_on(ctx, nb, nullptr, [&](int64_t j, qil_context* work) {
+        return paired ? qil_signal_ztmps(work, xs[j], len, dtype, method, cutoff, maxdim, k, p, q, seed, mindim, &outs[j])
+                      : qil_signal_mps(work, xs[j], len, dtype, method, cutoff, maxdim, k, p, q, seed, mindim, &outs[j]);
+    });
+    if (st != QIL_OK)
+        for (int64_t j = 0; j < nb; ++j) {
+            if (outs[j]) qil_mps_destroy(outs[j]);
+            outs[j] = nullptr;
+        }
+    return st;
+}
+
+extern "C" int qil_signal_mps_batch(qil_context* ctx, const void* const* xs, int64_t nb, int64_t len, int dtype, int method,
+                                    double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed, int64_t mindim,
+                                    qil_mps** outs) {
+    return signal_batch(ctx, xs, nb, len, dtype, method, cutoff, maxdim, k, p, q, seed, mindim, 0, outs);
+}
+
+extern "C" int qil_signal_ztmps_batch(qil_context* ctx, const void* const* xs, int64_t nb, int64_t len, int dtype, int method,
+                                      double cutoff, int64_t maxdim, int64_t k, int64_t p, int q, uint64_t seed,
+                                      int64_t mindim, qil_mps** outs) {
+    return signal_batch(ctx, xs, nb, len, dtype, method, cutoff, maxdim, k, p, q, seed, mindim, 1, outs);
 }

@@ -404,6 +404,40 @@ def _encode(fn, cls, x, method, cutoff, maxdim, k, p, q, random_seed, mindim, ct
     return cls(ctx=ctx, _handle=h)
 
 
+def _encode_batch(fn, cls, xs, method, cutoff, maxdim, k, p, q, random_seed, mindim, ctx):
+    if method not in ("svd", "rsvd"):
+        raise ValueError(f"tensor_to_mps: unknown method {method}. Use :svd or :rsvd.")
+    ctx = ctx or default_context()
+    xs = [np.asarray(x) for x in xs]
+    if not xs:
+        return []
+    code = L.QIL_C64 if any(np.iscomplexobj(x) for x in xs) else L.QIL_F64
+    keep = [np.ascontiguousarray(x, dtype=_np_dtype(code)) for x in xs]
+    N = len(keep[0])
+    if any(x.ndim != 1 or len(x) != N for x in keep):
+        raise ValueError("signal batch: all signals must be 1-D and of one length")
+    n = max(1, int(round(np.log2(max(N, 1)))))
+    if N < 2 ** n:
+        warnings.warn(f"_array_to_tensor: input length {N} is not a power of 2; zero-filling to {2**n}")
+    ptrs = (C.c_void_p * len(keep))(*[x.ctypes.data for x in keep])
+    outs = (C.c_void_p * len(keep))()
+    L.check(fn(ctx.handle, ptrs, len(keep), N, code,
+               L.QIL_METHOD_SVD if method == "svd" else L.QIL_METHOD_RSVD, float(cutoff), _maxdim(maxdim),
+               int(k), int(p), int(q), C.c_uint64(random_seed), int(mindim), outs))
+    return [cls(ctx=ctx, _handle=C.c_void_p(h)) for h in outs]
+
+
+def signal_mps_batch(xs, method="svd", cutoff=1e-15, maxdim=None, k=20, p=10, q=0, random_seed=1234, mindim=1, ctx=None):
+    """signal_mps for several signals of one length (the signal kinds of a benchmark sweep), encoded concurrently on the
+    context's streams; item j is exactly signal_mps(xs[j]; ...)."""
+    return _encode_batch(L.lib.qil_signal_mps_batch, SignalMPS, xs, method, cutoff, maxdim, k, p, q, random_seed, mindim, ctx)
+
+
+def signal_ztmps_batch(xs, cutoff=1e-10, maxdim=None, method="svd", k=20, p=10, q=0, random_seed=1234, mindim=1, ctx=None):
+    """signal_ztmps for several signals of one length, encoded concurrently; item j is exactly signal_ztmps(xs[j]; ...)."""
+    return _encode_batch(L.lib.qil_signal_ztmps_batch, ZTMPS, xs, method, cutoff, maxdim, k, p, q, random_seed, mindim, ctx)
+
+
 def signal_mps(x, method="svd", cutoff=1e-15, maxdim=None, k=20, p=10, q=0, random_seed=1234, mindim=1,
                ctx=None):
     """signal_mps(x; method=:svd, cutoff, maxdim, k, p, q, random_seed, mindim)."""

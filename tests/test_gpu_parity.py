@@ -1982,3 +1982,32 @@ def test_batches_on_a_second_context_and_one_worker(qil, monkeypatch):
     again = qil.compress_batch([qil.SignalMPS([t.copy() for t in a]) for a in data], maxdim=7, tol=1e-9)
     for r, b in zip(ref, again):
         assert b.bond_dims == r.bond_dims
+
+
+def test_signal_batch_encoders_equal_item_by_item(qil):
+    """qil_signal_mps_batch / qil_signal_ztmps_batch: the signals of a sweep encoded concurrently give the tensors of the
+    one-at-a-time encoders (SVD and RSVD, real and complex, more signals than slots); all or nothing on failure."""
+    rng = np.random.default_rng(404)
+    n = 17                                                       # >= 16 sites: the single encoder itself runs concurrent sub-trees
+    t = np.arange(2 ** n) / 2 ** n
+    xs = [np.sin(2 * np.pi * (2 + j) * t) * np.exp(-(1 + 0.3 * j) * t) + 0.1 * rng.standard_normal(2 ** n) for j in range(11)]
+    for kw in (dict(method="svd", cutoff=1e-10, maxdim=24), dict(method="rsvd", k=12, p=4, q=1, cutoff=1e-12)):
+        ref = [qil.signal_mps(x, **kw) for x in xs]
+        got = qil.signal_mps_batch(xs, **kw)
+        refz = [qil.signal_ztmps(x, **kw) for x in xs]
+        gotz = qil.signal_ztmps_batch(xs, **kw)
+        for r, g in list(zip(ref, got)) + list(zip(refz, gotz)):
+            assert type(g) is type(r) and g.bond_dims == r.bond_dims and g.amplitude == r.amplitude
+            for tr, tg in zip(r.to_host(), g.to_host()):
+                assert np.array_equal(tr, tg)
+    zs = [x + 1j * np.roll(x, 7) for x in xs[:5]]
+    for r, g in zip([qil.signal_mps(z, method="svd") for z in zs], qil.signal_mps_batch(zs, method="svd")):
+        for tr, tg in zip(r.to_host(), g.to_host()):
+            assert np.array_equal(tr, tg)
+    assert qil.signal_mps_batch([]) == []
+    with pytest.raises(ValueError, match="one length"):
+        qil.signal_mps_batch([xs[0], xs[1][:100]])
+    bad = [xs[0], np.zeros(2 ** n), xs[1]]                       # a zero signal has no norm: the whole call fails
+    with pytest.raises(ValueError, match="zero or non-finite norm"):
+        qil.signal_mps_batch(bad)
+    assert qil.default_context().unowned_bytes() == 0
