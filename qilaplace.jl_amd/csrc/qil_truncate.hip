@@ -130,6 +130,9 @@ static int svd_trunc_lowrank(qil_context* ctx, int dtype, int64_t m, int64_t n, 
                                              (long long)m, (long long)n, (long long)k, tot > 0 ? rho / tot : 0.0, cutoff);
         if (!(rho <= 1e-8 * cutoff * tot)) {
             release();
+            // a sketch twice as wide cannot help an operand that is nowhere near low rank (flat spectra leave > 50 % of
+            // the weight outside 128 columns): only residuals that are already small earn the second attempt
+            if (rho > 1e-4 * tot) break;
             continue;
         }
         int64_t r = 0;
