@@ -205,8 +205,16 @@ int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int6
 // Uiso (p x k, k = min(p, q)) orthonormal columns in descending-S order, SVh (k x q) = diag(S) V^H (no division by S
 // anywhere).  Serves the mid-size regime (97 <= k < 640, and smaller operands that do not fit the single-workgroup iteration);
 // *handled = 0 leaves B intact for the general qil_dev_svd.
+// cert_cutoff > 0: the caller truncates by that cutoff only and ignores S_host; when the triangular factor certifies that no
+// singular value can be dropped, the thin QR is returned as the gauge step (*handled = 2, S_host untouched).
 int qil_dev_svd_left(qil_context* ctx, int dtype, int64_t p, int64_t q, void* B, int64_t ldb, void* Uiso, int64_t ldu,
-                     double* S_host, void* SVh, int64_t ldsvh, double negligible_rel, int* handled);
+                     double* S_host, void* SVh, int64_t ldsvh, double negligible_rel, int* handled, double cert_cutoff = 0.0);
+// The same certificate for operands of any size: thin QR of A (m >= n) or A^H (m < n) into Qout (max(m, n) x k, packed) and
+// Rout (k x k, packed); *certified says whether a truncation at `cutoff` can drop anything.  A is left intact.
+int qil_dev_qr_certified(qil_context* ctx, int dtype, int64_t m, int64_t n, const void* A, int64_t lda, double cutoff, void* Qout,
+                         void* Rout, bool* certified);
+// V (n x n, ldv) = I (the diagonal is written; the caller zeroes the rest)
+int qil_dev_set_identity(qil_context* ctx, int dtype, void* V, int64_t ldv, int64_t n);
 // Thin QR with non-negative real diagonal of R: A (m x n, m >= n) -> Q (m x n) in place; R (n x n) optional.
 // orthonormal = true: Q^H Q is measured afterwards and Q re-factored while it is not the identity (numerically
 // rank-deficient operands; one small GEMM and one stream synchronisation when nothing needs doing).

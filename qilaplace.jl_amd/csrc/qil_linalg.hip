@@ -1623,6 +1623,155 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
     return QIL_OK;
 }
 
+// ------------------------------------------------------------------ "nothing can be truncated" certificate
+// A gauge sweep that truncates with a cutoff (canonicalize!(cutoff = 1e-12), the first pass of compress!) pays a full SVD
+// per site even where no singular value can go: the rule drops a tail only while sum(sigma_dropped^2) <= cutoff sum(sigma^2),
+// so nothing is dropped whenever sigma_min^2 > cutoff |A|_F^2.  With the triangular factor R of the site's thin QR at hand,
+// sigma_min(R) >= 1 / |R^-1|_2 >= 1 / |R^-1|_F, and R^-1 is a blocked triangular inversion (64 x 64 diagonal blocks by back
+// substitution, the rest MFMA GEMMs): a rigorous bound for the price of a few small launches.  Where it holds, the thin QR
+// IS the gauge step (the kept space is the whole space; Q differs from the SVD's U by a unitary on the bond, which no
+// gauge-invariant quantity sees) and the Jacobi iteration is skipped.  Rank-deficient operands -- every product bond of
+// the signal pipelines -- fail the first test (sigma_min <= min |r_ii|) before anything is inverted.
+template <class T>
+__global__ __launch_bounds__(256) void tri_stats(const T* __restrict__ R, long long ldr, int k, int upper_only,
+                                                 double* __restrict__ out /* per block: [fro2, min |r_ii|^2] */) {
+    __shared__ double red[8];
+    double f = 0, d = 1e300;
+    for (long long t = blockIdx.x * 256LL + threadIdx.x; t < (long long)k * k; t += 256LL * gridDim.x) {
+        const int i = (int)(t % k), j = (int)(t / k);
+        if (upper_only && i > j) continue;
+        const double a = abs2_t(R[i + ldr * j]);
+        f += a;
+        if (i == j) d = fmin(d, a);
+    }
+    f = wave_sum(f);
+    for (int off = 32; off; off >>= 1) d = fmin(d, __shfl_xor(d, off));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave] = f;
+        red[4 + wave] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        out[2 * blockIdx.x + 1] = fmin(fmin(red[4], red[5]), fmin(red[6], red[7]));
+    }
+}
+
+__device__ __forceinline__ double inv_t(double u) { return 1.0 / u; }
+__device__ __forceinline__ c64 inv_t(c64 u) {
+    const double s = 1.0 / (u.re * u.re + u.im * u.im);
+    return c64{u.re * s, -u.im * s};
+}
+__device__ __forceinline__ double mul_t(double a, double b) { return a * b; }
+__device__ __forceinline__ c64 mul_t(c64 a, c64 b) { return c64{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ double neg_t(double a) { return -a; }
+__device__ __forceinline__ c64 neg_t(c64 a) { return c64{-a.re, -a.im}; }
+
+// X (column block b of the k x k result) = inverse of the 64 x 64 (or smaller, last) upper-triangular diagonal block b of R:
+// thread j solves U x_j = e_j by back substitution, the block in LDS
+template <class T>
+__global__ __launch_bounds__(64) void trtri_diag(const T* __restrict__ R, long long ldr, int k, T* __restrict__ X, long long ldx) {
+    __shared__ T U[64 * 65];
+    const int b0 = blockIdx.x * 64, nb = min(64, k - b0), j = threadIdx.x;
+    for (int c = 0; c < nb; ++c)
+        if (j < nb) U[j + 65 * c] = (j <= c) ? R[(b0 + j) + ldr * (long long)(b0 + c)] : T{};
+    __syncthreads();
+    if (j >= nb) return;
+    // x_jj = 1 / u_jj; x_ij = -(sum_{l = i + 1 .. j} u_il x_lj) / u_ii.  The solved entries live in the output column and are
+    // read back from there (a dynamically indexed register array would go to scratch; the column is 64 entries in L1)
+    T* out = X + b0 + ldx * (long long)(b0 + j);
+    out[j] = inv_t(U[j + 65 * j]);
+    for (int i = j - 1; i >= 0; --i) {
+        T acc{};
+        for (int l = i + 1; l <= j; ++l) acc = fma_t(U[i + 65 * l], out[l], acc);
+        out[i] = neg_t(mul_t(acc, inv_t(U[i + 65 * i])));
+    }
+}
+
+template <class T>
+__global__ void negate_block(T* __restrict__ A, long long lda, int m, int n) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < (long long)m * n; t += (long long)gridDim.x * blockDim.x)
+        A[(t % m) + lda * (t / m)] = neg_t(A[(t % m) + lda * (t / m)]);
+}
+
+// Xinv (k x k, ld k, zero below the diagonal) = R^-1 for upper-triangular R
+template <class T>
+int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
+    QIL_HIP(hipMemsetAsync(Xinv, 0, (size_t)k * k * sizeof(T), ctx->stream));
+    const int nb = (k + 63) / 64;
+    hipLaunchKernelGGL(trtri_diag<T>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, R, ldr, k, Xinv, (long long)k);
+    QIL_HIP(hipGetLastError());
+    // merge neighbouring inverted diagonal blocks level by level: [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1]
+    struct Blk { int start, size; };
+    std::vector<Blk> cur;
+    for (int b = 0; b < nb; ++b) cur.push_back(Blk{b * 64, std::min(64, k - b * 64)});
+    void* tmp = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * k * sizeof(T), &tmp));
+    T* Tm = static_cast<T*>(tmp);
+    while (cur.size() > 1) {
+        std::vector<Blk> next;
+        for (size_t i = 0; i + 1 < cur.size(); i += 2) {
+            const int a0 = cur[i].start, sa = cur[i].size, c0 = cur[i + 1].start, sc = cur[i + 1].size;
+            // T = B C^-1 (sa x sc), X12 = -(A^-1 T)
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sa, sc, sc, R + a0 + ldr * (long long)c0, ldr, Xinv + c0 + (long long)k * c0, k, Tm, sa));
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sa, sc, sa, Xinv + a0 + (long long)k * a0, k, Tm, sa, Xinv + a0 + (long long)k * c0, k));
+            hipLaunchKernelGGL(negate_block<T>, dim3((unsigned)std::min<long long>(((long long)sa * sc + 255) / 256, 1024)), dim3(256), 0,
+                               ctx->stream, Xinv + a0 + (long long)k * c0, (long long)k, sa, sc);
+            next.push_back(Blk{a0, sa + sc});
+        }
+        if (cur.size() & 1) next.push_back(cur.back());
+        cur.swap(next);
+    }
+    QIL_HIP(hipGetLastError());
+    qil_ctx_free(ctx, tmp);
+    return QIL_OK;
+}
+
+// *certified = true iff no singular value of the operand whose thin-QR factor is R can be dropped at `cutoff`
+template <class T>
+int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, double cutoff, bool* certified) {
+    *certified = false;
+    const bool enabled = !(getenv("QIL_SVD_CERT") && atoi(getenv("QIL_SVD_CERT")) == 0);   // tuning aid (read per call: the tests toggle it)
+    if (!enabled || !(cutoff > 0.0) || k < 2) return QIL_OK;
+    void *st = nullptr, *xinv = nullptr;
+    constexpr int NB = 64;
+    QIL_TRY(qil_ctx_alloc(ctx, 2 * NB * sizeof(double), &st));
+    double hb[2 * NB];
+    double h[2];
+    auto stats = [&](const T* M, long long ldm) -> int {
+        hipLaunchKernelGGL(tri_stats<T>, dim3(NB), dim3(256), 0, ctx->stream, M, ldm, k, 1, (double*)st);
+        QIL_HIP(hipMemcpyAsync(hb, st, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        h[0] = 0;
+        h[1] = 1e300;
+        for (int b = 0; b < NB; ++b) {          // fixed order
+            h[0] += hb[2 * b];
+            h[1] = std::min(h[1], hb[2 * b + 1]);
+        }
+        return QIL_OK;
+    };
+    QIL_TRY(stats(R, ldr));
+    const double fro2 = h[0];
+    // sigma_min <= min |r_ii|: a small diagonal entry settles it the other way without inverting anything
+    if (!(fro2 > 0.0) || !std::isfinite(fro2) || !(h[1] > 16.0 * cutoff * fro2 * k)) {
+        qil_ctx_free(ctx, st);
+        return QIL_OK;
+    }
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * k * sizeof(T), &xinv));
+    QIL_TRY(trtri_upper<T>(ctx, R, ldr, k, static_cast<T*>(xinv)));
+    QIL_TRY(stats(static_cast<const T*>(xinv), (long long)k));
+    qil_ctx_free(ctx, xinv);
+    qil_ctx_free(ctx, st);
+    const double inv2 = h[0];
+    // sigma_min^2 >= 1 / |R^-1|_F^2 must exceed cutoff |R|_F^2; the factor 4 covers the rounding of the inversion
+    *certified = std::isfinite(inv2) && inv2 > 0.0 && 4.0 * cutoff * fro2 * inv2 < 1.0;
+    if (getenv("QIL_SVD_DEBUG"))
+        fprintf(stderr, "[svd-cert] k = %d: cutoff |R|_F^2 |R^-1|_F^2 = %.3e -> %s\n", k, cutoff * fro2 * inv2,
+                *certified ? "nothing can be truncated: QR gauge" : "SVD");
+    return QIL_OK;
+}
+
 // ------------------------------------------------------------------ mid-size SVD with ONE isometric factor
 // The gauge sweeps (canonicalize!, compress!, the zip-up) keep only ONE factor of every SVD as a site tensor; the other
 // is multiplied into the neighbour.  Then no rotation matrix has to be accumulated: the isometric factor is the
@@ -1875,7 +2024,7 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
 // *handled = 0 (nothing touched beyond B's contents being intact) sends the caller to the general svd_impl.
 template <class T>
 int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb, T* Uiso, long long ldu, double* S_host,
-                 T* SVh, long long ldsvh, double negl_rel, int* handled) {
+                 T* SVh, long long ldsvh, double negl_rel, int* handled, double cert_cutoff) {
     *handled = 0;
     const long long k = std::min(p, q);
     static const bool enabled = !(getenv("QIL_SVD_LEFT") && atoi(getenv("QIL_SVD_LEFT")) == 0);
@@ -1971,6 +2120,31 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         hipLaunchKernelGGL(conj_transpose<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)R, k, k, k, X, k);
     }
     lap("QR");
+    if (cert_cutoff > 0.0) {
+        // the caller truncates by cutoff only and does not read the singular values: if nothing can be dropped, the thin
+        // QR is the gauge step (*handled = 2, S_host untouched)
+        bool certified = false;
+        QIL_TRY(certify_no_truncation<T>(ctx, R, k, (int)k, cert_cutoff, &certified));
+        if (certified) {
+            if (tall) {                                  // B = Q R: Uiso = Q (in B), S V^H = R
+                QIL_HIP(hipMemcpy2DAsync(Uiso, (size_t)ldu * sizeof(T), Qm, (size_t)ldq * sizeof(T), (size_t)p * sizeof(T), (size_t)k,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+                QIL_HIP(hipMemcpy2DAsync(SVh, (size_t)ldsvh * sizeof(T), R, (size_t)k * sizeof(T), (size_t)k * sizeof(T), (size_t)q,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+            } else {                                     // p < q: the whole row space is kept: Uiso = I, S V^H = B
+                QIL_HIP(hipMemset2DAsync(Uiso, (size_t)ldu * sizeof(T), 0, (size_t)k * sizeof(T), (size_t)k, ctx->stream));
+                hipLaunchKernelGGL(set_identity<T>, dim3(gk), dim3(256), 0, ctx->stream, Uiso, ldu, (int)k);
+                QIL_HIP(hipMemcpy2DAsync(SVh, (size_t)ldsvh * sizeof(T), B, (size_t)ldb * sizeof(T), (size_t)p * sizeof(T), (size_t)q,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            QIL_HIP(hipGetLastError());
+            lap("certificate: QR gauge");
+            release();
+            *handled = 2;
+            return QIL_OK;
+        }
+        lap("certificate: declined");
+    }
     QIL_TRY(qil_ctx_alloc(ctx, 256, &flag));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * sizeof(double), &nrm));
     if (negl_rel > 0.0) {
@@ -2758,12 +2932,48 @@ int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int6
 }
 
 int qil_dev_svd_left(qil_context* ctx, int dtype, int64_t p, int64_t q, void* B, int64_t ldb, void* Uiso, int64_t ldu,
-                     double* S_host, void* SVh, int64_t ldsvh, double negligible_rel, int* handled) {
+                     double* S_host, void* SVh, int64_t ldsvh, double negligible_rel, int* handled, double cert_cutoff) {
     if (dtype == QIL_C64)
         return svd_left_mid<c64>(ctx, p, q, static_cast<c64*>(B), ldb, static_cast<c64*>(Uiso), ldu, S_host,
-                                 static_cast<c64*>(SVh), ldsvh, negligible_rel, handled);
+                                 static_cast<c64*>(SVh), ldsvh, negligible_rel, handled, cert_cutoff);
     return svd_left_mid<double>(ctx, p, q, static_cast<double*>(B), ldb, static_cast<double*>(Uiso), ldu, S_host,
-                                static_cast<double*>(SVh), ldsvh, negligible_rel, handled);
+                                static_cast<double*>(SVh), ldsvh, negligible_rel, handled, cert_cutoff);
+}
+
+// thin QR of the tall orientation + the certificate, for operands outside the one-factor SVD's range (>= 640 columns):
+// A (m x n, lda) is left intact; on success (*certified) Qout (rows x k, ld rows) / Rout (k x k, ld k) hold the factors of A
+// (m >= n) or of A^H (m < n), rows = max(m, n), k = min(m, n)
+template <class T>
+static int qr_certified_t(qil_context* ctx, long long m, long long n, const T* A, long long lda, double cutoff, T* Qout, T* Rout,
+                          bool* certified) {
+    const long long rows = std::max(m, n), k = std::min(m, n);
+    if (m >= n)
+        QIL_HIP(hipMemcpy2DAsync(Qout, (size_t)rows * sizeof(T), A, (size_t)lda * sizeof(T), (size_t)m * sizeof(T), (size_t)n,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    else
+        hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)), dim3(256), 0,
+                           ctx->stream, A, lda, m, n, Qout, rows);
+    QIL_TRY(qr_impl<T>(ctx, rows, k, Qout, rows, Rout, k));
+    bool ok = true;
+    QIL_TRY(qr_reorthogonalise<T>(ctx, rows, k, Qout, rows, Rout, k, false, &ok));
+    *certified = false;
+    if (!ok) return QIL_OK;
+    return certify_no_truncation<T>(ctx, Rout, k, (int)k, cutoff, certified);
+}
+int qil_dev_set_identity(qil_context* ctx, int dtype, void* V, int64_t ldv, int64_t n) {
+    const unsigned g = (unsigned)std::min<long long>((n * n + 255) / 256, 65536);
+    if (dtype == QIL_C64) hipLaunchKernelGGL(set_identity<c64>, dim3(g), dim3(256), 0, ctx->stream, static_cast<c64*>(V), ldv, (int)n);
+    else hipLaunchKernelGGL(set_identity<double>, dim3(g), dim3(256), 0, ctx->stream, static_cast<double*>(V), ldv, (int)n);
+    QIL_HIP(hipGetLastError());
+    return QIL_OK;
+}
+int qil_dev_qr_certified(qil_context* ctx, int dtype, int64_t m, int64_t n, const void* A, int64_t lda, double cutoff, void* Qout,
+                         void* Rout, bool* certified) {
+    if (dtype == QIL_C64)
+        return qr_certified_t<c64>(ctx, m, n, static_cast<const c64*>(A), lda, cutoff, static_cast<c64*>(Qout),
+                                   static_cast<c64*>(Rout), certified);
+    return qr_certified_t<double>(ctx, m, n, static_cast<const double*>(A), lda, cutoff, static_cast<double*>(Qout),
+                                  static_cast<double*>(Rout), certified);
 }
 
 int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* R,

@@ -163,6 +163,51 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
                   void** Vh_out, std::vector<double>* S_out) {
     const int64_t r0 = std::min(m, n);
     const size_t e = qil_elem_size(dtype);
+    // Gauge sweeps that truncate by cutoff only and do not read the singular values (canonicalize!(cutoff), the first pass of
+    // compress!): where the site's triangular factor certifies that nothing can be dropped, the thin QR is the gauge step
+    // (qil_linalg.hip, "nothing can be truncated" certificate).  97..639 columns: inside the one-factor SVD, which has the QR
+    // at hand; from 640 columns on: here, before the GEMM-shaped block Jacobi.
+    const double cert_cutoff = (!S_out && use_cutoff && cutoff > 0.0 && r0 <= maxdim && (absorb == 1 || absorb == 2)) ? cutoff : 0.0;
+    if (cert_cutoff > 0.0 && r0 >= 640) {
+        const int64_t rows = std::max(m, n);
+        void *Qb = nullptr, *Rb = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(rows * r0) * e, &Qb));
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r0 * r0) * e, &Rb));
+        bool certified = false;
+        QIL_TRY(qil_dev_qr_certified(ctx, dtype, m, n, A, lda, cert_cutoff, Qb, Rb, &certified));
+        if (certified) {
+            void *U = nullptr, *Vh = nullptr;
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * r0) * e, &U));
+            QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r0 * n) * e, &Vh));
+            if (absorb == 2) {                       // U isometric, the rest absorbed
+                if (m >= n) {                        // A = Q R
+                    QIL_TRY(copy_2d(ctx, dtype, m, r0, Qb, rows, U, m));
+                    QIL_TRY(copy_2d(ctx, dtype, r0, n, Rb, r0, Vh, r0));
+                } else {                             // every row direction is kept: U = I, the rest = A
+                    QIL_HIP(hipMemsetAsync(U, 0, (size_t)(m * r0) * e, ctx->stream));
+                    QIL_TRY(qil_dev_set_identity(ctx, dtype, U, m, r0));
+                    QIL_TRY(copy_2d(ctx, dtype, m, n, A, lda, Vh, r0));
+                }
+            } else {                                 // Vh isometric, U S absorbed
+                if (m <= n) {                        // A^H = Q R  =>  A = R^H Q^H
+                    QIL_TRY(qil_dev_transpose(ctx, dtype, 1, rows, r0, Qb, rows, Vh, r0));
+                    QIL_TRY(qil_dev_transpose(ctx, dtype, 1, r0, r0, Rb, r0, U, m));
+                } else {                             // every column direction is kept: Vh = I, U S = A
+                    QIL_HIP(hipMemsetAsync(Vh, 0, (size_t)(r0 * n) * e, ctx->stream));
+                    QIL_TRY(qil_dev_set_identity(ctx, dtype, Vh, r0, r0));
+                    QIL_TRY(copy_2d(ctx, dtype, m, n, A, lda, U, m));
+                }
+            }
+            qil_ctx_free(ctx, Qb);
+            qil_ctx_free(ctx, Rb);
+            *rank = r0;
+            *U_out = U;
+            *Vh_out = Vh;
+            return QIL_OK;
+        }
+        qil_ctx_free(ctx, Qb);
+        qil_ctx_free(ctx, Rb);
+    }
     if (use_cutoff) {
         int done = 0;
         QIL_TRY(svd_trunc_lowrank(ctx, dtype, m, n, A, lda, cutoff, maxdim, mindim, absorb, rank, U_out, Vh_out, S_out, &done));
@@ -178,14 +223,14 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
     // that accumulates no rotation matrix (qil_dev_svd_left) serves them; everything else takes the general SVD.
     int handled = 0;
     if (absorb == 2) {            // U isometric, S Vh absorbed
-        QIL_TRY(qil_dev_svd_left(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0, negl_rel, &handled));
+        QIL_TRY(qil_dev_svd_left(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0, negl_rel, &handled, cert_cutoff));
     } else if (absorb == 1) {     // Vh isometric, U S absorbed: the same problem on A^H
         void *At = nullptr, *Vi = nullptr, *SU = nullptr;
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &At));
         QIL_TRY(qil_dev_transpose(ctx, dtype, 1, m, n, A, lda, At, n));                         // A^H (n x m)
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * r0) * e, &Vi));
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r0 * m) * e, &SU));
-        QIL_TRY(qil_dev_svd_left(ctx, dtype, n, m, At, n, Vi, n, S.data(), SU, r0, negl_rel, &handled));
+        QIL_TRY(qil_dev_svd_left(ctx, dtype, n, m, At, n, Vi, n, S.data(), SU, r0, negl_rel, &handled, cert_cutoff));
         if (handled) {
             QIL_TRY(qil_dev_transpose(ctx, dtype, 1, n, r0, Vi, n, Vh, r0));                    // Vh = V^H   (r0 x n)
             QIL_TRY(qil_dev_transpose(ctx, dtype, 1, r0, m, SU, r0, U, m));                     // U S = (S U^H)^H
@@ -195,7 +240,8 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
         qil_ctx_free(ctx, SU);
     }
     if (!handled) QIL_TRY(qil_dev_svd(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0, negl_rel));
-    const int64_t r = qil_truncation_rank(S.data(), r0, cutoff, use_cutoff, maxdim, mindim);
+    // handled == 2: certified that nothing can be truncated (S was not computed)
+    const int64_t r = handled == 2 ? r0 : qil_truncation_rank(S.data(), r0, cutoff, use_cutoff, maxdim, mindim);
     if (!handled && absorb == 1) QIL_TRY(qil_dev_scale(ctx, dtype, 1, m, r, U, m, S.data()));
     if (!handled && absorb == 2) QIL_TRY(qil_dev_scale(ctx, dtype, 0, r, n, Vh, r0, S.data()));
     if (r < r0) {  // compact Vh rows to leading dimension r

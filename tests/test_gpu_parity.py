@@ -2011,3 +2011,80 @@ def test_signal_batch_encoders_equal_item_by_item(qil):
     with pytest.raises(ValueError, match="zero or non-finite norm"):
         qil.signal_mps_batch(bad)
     assert qil.default_context().unowned_bytes() == 0
+
+
+# ---------------------------------------------------------------- "nothing can be truncated" certificate
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_gauge_sweep_certificate_keeps_the_oracles_bonds(qil, dtype, monkeypatch):
+    """canonicalize!(cutoff) / compress! skip the SVD of a site whose triangular factor certifies that no singular value
+    can be dropped (|R|_F |R^-1|_F bound) and take the thin QR as the gauge step.  The decisions must be the reference's:
+    a chain with planted tails -- one bond whose smallest Schmidt weights sit BELOW the cutoff (must be truncated: the
+    certificate has to decline) and one whose tail sits just ABOVE it (must be kept) -- gives the oracle's bond dimensions
+    and, gauge-invariantly, the oracle's state, with the certificate on and off."""
+    rng = np.random.default_rng(2024)
+    L, chi = 12, 128
+    a = random_mps_data(saturated_profile(L, chi), rng, dtype=dtype)
+
+    def plant(i, ntail, level):                  # scale ntail right-bond directions of site i by `level`
+        A = a[i]
+        cl, _, cr = A.shape
+        Q, _ = np.linalg.qr(rng.standard_normal((cr, cr)) + (1j * rng.standard_normal((cr, cr)) if dtype == np.complex128 else 0))
+        s = np.ones(cr)
+        s[-ntail:] = level
+        a[i] = np.einsum("asb,bc->asc", A, (Q * s) @ Q.conj().T).astype(dtype)
+
+    plant(4, 9, 1e-8)                            # Schmidt weights ~1e-16 relative: below cutoff 1e-12 -> truncated
+    plant(7, 6, 3e-5)                            # ~1e-9 relative: above the cutoff -> kept
+    bits = rng.integers(0, 2, size=(96, L))
+    ref = O.SignalMPS([t.copy() for t in a], amplitude=1.0)
+    O.canonicalize(ref, "left", cutoff=1e-12)
+    want = O.coefficient_batch(ref, bits)
+    assert min(ref.bond_dims) >= 2 and ref.bond_dims[4] < chi       # the planted tail is really cut in the oracle
+    results = {}
+    for cert in ("1", "0"):
+        monkeypatch.setenv("QIL_SVD_CERT", cert)
+        psi = qil.SignalMPS([t.copy() for t in a], amplitude=1.0)
+        qil.canonicalize(psi, "left", cutoff=1e-12)
+        assert psi.bond_dims == ref.bond_dims, cert
+        got = qil.coefficient_batch(psi, bits)
+        assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max(), cert
+        # left-canonical form: every site but the first is a right isometry
+        for t in psi.to_host()[1:]:
+            m = t.reshape(t.shape[0], -1)
+            assert np.abs(m @ m.conj().T - np.eye(m.shape[0])).max() < 1e-11
+        phi = qil.SignalMPS([t.copy() for t in a], amplitude=1.0)
+        qil.compress(phi, maxdim=40, tol=1e-7)
+        results[cert] = (phi.bond_dims, qil.coefficient_batch(phi, bits))
+    assert results["1"][0] == results["0"][0]
+    assert np.abs(results["1"][1] - results["0"][1]).max() <= 1e-10 * np.abs(want).max()
+    oc = O.SignalMPS([t.copy() for t in a], amplitude=1.0)
+    O.compress(oc, maxdim=40, tol=1e-7)
+    assert results["1"][0] == oc.bond_dims
+
+
+def test_gauge_sweep_certificate_on_wide_bonds_and_products(qil, monkeypatch):
+    """The same through the >= 640-column route (thin QR + certificate before the block Jacobi) and on a rank-deficient
+    product (every bond must be declined and truncated as the oracle does)."""
+    rng = np.random.default_rng(77)
+    L = 14
+    a = random_mps_data(saturated_profile(L, 700), rng)               # bonds up to 128 only reach 2^7: widen by hand
+    a = random_mps_data([2, 4, 8, 16, 32, 64, 700, 64, 32, 16, 8, 4, 2], rng)
+    bits = rng.integers(0, 2, size=(64, L))
+    ref = O.SignalMPS([t.copy() for t in a])
+    O.canonicalize(ref, "left", cutoff=1e-12)
+    psi = qil.SignalMPS([t.copy() for t in a])
+    qil.canonicalize(psi, "left", cutoff=1e-12)
+    assert psi.bond_dims == ref.bond_dims
+    got, want = qil.coefficient_batch(psi, bits), O.coefficient_batch(ref, bits)
+    assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+    # rank-deficient product: bonds D chi, numerical rank far below
+    b = random_mps_data(saturated_profile(10, 12), rng)
+    w = random_mpo_data(saturated_profile(10, 12, base=4), rng, dtype=np.complex128)
+    prod_o = O.apply(O.SingleSiteMPO(w), O.SignalMPS([t.copy() for t in b]))
+    prod = qil.SingleSiteMPO(w) * qil.SignalMPS([t.copy() for t in b])
+    O.canonicalize(prod_o, "left", cutoff=1e-12)
+    qil.canonicalize(prod, "left", cutoff=1e-12)
+    assert prod.bond_dims == prod_o.bond_dims
+    bb = rng.integers(0, 2, size=(64, 10))
+    g, wv = qil.coefficient_batch(prod, bb), O.coefficient_batch(prod_o, bb)
+    assert np.abs(g - wv).max() <= 1e-8 * np.abs(wv).max()

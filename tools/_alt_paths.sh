@@ -33,3 +33,4 @@ run QIL_BATCH_WORKERS=1 QIL_ENCODE_PAR_DEPTH=0 QIL_SWEEP_CONCURRENT=0
 run QIL_BATCH_WORKERS=3 QIL_ENCODE_PAR_DEPTH=5
 run QIL_DT_BUILDER=launches QIL_ZIP_SKETCH=0
 run QIL_DT_DCAP=24
+run QIL_SVD_CERT=0
