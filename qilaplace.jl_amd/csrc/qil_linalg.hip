@@ -1672,21 +1672,26 @@ __device__ __forceinline__ c64 neg_t(c64 a) { return c64{-a.re, -a.im}; }
 // thread j solves U x_j = e_j by back substitution, the block in LDS
 template <class T>
 __global__ __launch_bounds__(64) void trtri_diag(const T* __restrict__ R, long long ldr, int k, T* __restrict__ X, long long ldx) {
-    __shared__ T U[64 * 65];
+    extern __shared__ __attribute__((aligned(16))) char trtri_smem[];
+    T* U = reinterpret_cast<T*>(trtri_smem);
+    T* Xs = U + 64 * 65;
     const int b0 = blockIdx.x * 64, nb = min(64, k - b0), j = threadIdx.x;
     for (int c = 0; c < nb; ++c)
         if (j < nb) U[j + 65 * c] = (j <= c) ? R[(b0 + j) + ldr * (long long)(b0 + c)] : T{};
     __syncthreads();
-    if (j >= nb) return;
-    // x_jj = 1 / u_jj; x_ij = -(sum_{l = i + 1 .. j} u_il x_lj) / u_ii.  The solved entries live in the output column and are
-    // read back from there (a dynamically indexed register array would go to scratch; the column is 64 entries in L1)
-    T* out = X + b0 + ldx * (long long)(b0 + j);
-    out[j] = inv_t(U[j + 65 * j]);
-    for (int i = j - 1; i >= 0; --i) {
-        T acc{};
-        for (int l = i + 1; l <= j; ++l) acc = fma_t(U[i + 65 * l], out[l], acc);
-        out[i] = neg_t(mul_t(acc, inv_t(U[i + 65 * i])));
+    if (j < nb) {
+        // x_jj = 1 / u_jj; x_ij = -(sum_{l = i + 1 .. j} u_il x_lj) / u_ii; the solved entries of column j stay in LDS
+        T* x = Xs + 65 * j;
+        x[j] = inv_t(U[j + 65 * j]);
+        for (int i = j - 1; i >= 0; --i) {
+            T acc{};
+            for (int l = i + 1; l <= j; ++l) acc = fma_t(U[i + 65 * l], x[l], acc);
+            x[i] = neg_t(mul_t(acc, inv_t(U[i + 65 * i])));
+        }
     }
+    __syncthreads();
+    for (int c = 0; c < nb; ++c)
+        if (j < nb && j <= c) X[(b0 + j) + ldx * (long long)(b0 + c)] = Xs[j + 65 * c];
 }
 
 template <class T>
@@ -1700,7 +1705,14 @@ template <class T>
 int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
     QIL_HIP(hipMemsetAsync(Xinv, 0, (size_t)k * k * sizeof(T), ctx->stream));
     const int nb = (k + 63) / 64;
-    hipLaunchKernelGGL(trtri_diag<T>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, R, ldr, k, Xinv, (long long)k);
+    constexpr size_t diag_lds = (size_t)2 * 64 * 65 * sizeof(T);
+    static bool attr = false;
+    if (!attr) {
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trtri_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)diag_lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(trtri_diag<T>, dim3((unsigned)nb), dim3(64), diag_lds, ctx->stream, R, ldr, k, Xinv, (long long)k);
     QIL_HIP(hipGetLastError());
     // merge neighbouring inverted diagonal blocks level by level: [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1]
     struct Blk { int start, size; };
