@@ -216,7 +216,7 @@ int qil_mpo_compress_batch(qil_mpo* const* items, int64_t nb, int direction, dou
 
 /* Fused apply-and-truncate: the result of compress!(apply(W, psi); maxdim, tol, sweeps)
  * (apply.jl:75-122 followed by mps.jl:913-973) without materialising the (D chi)^2 product: a zip-up sweep
- * with intermediate bond cap zip_maxdim (<= 0: 2 maxdim) followed by the exact-gauge compress!.  Same error
+ * with intermediate bond cap zip_maxdim (<= 0: max(1.5 maxdim, maxdim + 16)) followed by the exact-gauge compress!.  Same error
  * codes as qil_apply / qil_compress.  Not a reference entry point (the reference's apply ignores its
  * cutoff/maxdim kwargs); qil_apply keeps that behaviour.  Accuracy: as for every zip-up, the intermediate
  * truncations are near-optimal for decaying spectra (transform MPOs on encoded signals) and can lose more

@@ -19,7 +19,7 @@ for case in range(ncase):
     wdt = np.complex128 if rng.random() < 0.6 else np.float64
     a = random_mps_data(saturated_profile(L, chi), rng, dtype=adt)
     w = random_mpo_data(saturated_profile(L, D, base=4), rng, dtype=wdt)
-    maxdim = int(rng.choice([8, 16, 32, 64]))
+    maxdim = int(rng.choice([8, 16, 32, 64, 128] if os.environ.get("QIL_FUZZ_WIDE") else [8, 16, 32, 64]))
     tol = float(rng.choice([1e-6, 1e-8, 1e-10]))
     psi, W = qil.SignalMPS(a, amplitude=1.7), qil.SingleSiteMPO(w)
     ref = O.apply(O.SingleSiteMPO(w), O.SignalMPS([t.copy() for t in a], amplitude=1.7))
