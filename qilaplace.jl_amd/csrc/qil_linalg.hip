@@ -1318,19 +1318,30 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
                     rpi[tid] = pi;
                 }
                 __syncthreads();
-                {   // phase B: columns p, q of G and of J
+                {   // phase B: columns p, q of G and of J (all of a lane's loads first: a rolled loop pays one LDS
+                    // latency per trip)
                     const int p = rp[grp], q = rq[grp];
                     const double c = rc[grp], sn = rs[grp], pr = rpr[grp], pi = rpi[grp];
                     if (sn != 0.0) {
-                        for (int r = lane; r < N; r += 16) {
-                            T x = Aw[r + LD * p], y = Aw[r + LD * q];
-                            rotate_pair(x, y, c, sn, pr, pi);
-                            Aw[r + LD * p] = x;
-                            Aw[r + LD * q] = y;
-                            T u = Vw[r + LD * p], w = Vw[r + LD * q];
-                            rotate_pair(u, w, c, sn, pr, pi);
-                            Vw[r + LD * p] = u;
-                            Vw[r + LD * q] = w;
+                        constexpr int NR = N / 16;
+                        T x[NR], y[NR], u[NR], w[NR];
+#pragma unroll
+                        for (int t = 0; t < NR; ++t) {
+                            const int r = lane + 16 * t;
+                            x[t] = Aw[r + LD * p];
+                            y[t] = Aw[r + LD * q];
+                            u[t] = Vw[r + LD * p];
+                            w[t] = Vw[r + LD * q];
+                        }
+#pragma unroll
+                        for (int t = 0; t < NR; ++t) {
+                            const int r = lane + 16 * t;
+                            rotate_pair(x[t], y[t], c, sn, pr, pi);
+                            rotate_pair(u[t], w[t], c, sn, pr, pi);
+                            Aw[r + LD * p] = x[t];
+                            Aw[r + LD * q] = y[t];
+                            Vw[r + LD * p] = u[t];
+                            Vw[r + LD * q] = w[t];
                         }
                     }
                 }
@@ -1339,11 +1350,20 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
                     const int p = rp[grp], q = rq[grp];
                     const double c = rc[grp], sn = rs[grp], pr = rpr[grp], pi = rpi[grp];
                     if (sn != 0.0) {
-                        for (int cc = lane; cc < N; cc += 16) {
-                            T x = Aw[p + LD * cc], y = Aw[q + LD * cc];
-                            rotate_pair(x, y, c, sn, pr, -pi);
-                            Aw[p + LD * cc] = x;
-                            Aw[q + LD * cc] = y;
+                        constexpr int NR = N / 16;
+                        T x[NR], y[NR];
+#pragma unroll
+                        for (int t = 0; t < NR; ++t) {
+                            const int cc = lane + 16 * t;
+                            x[t] = Aw[p + LD * cc];
+                            y[t] = Aw[q + LD * cc];
+                        }
+#pragma unroll
+                        for (int t = 0; t < NR; ++t) {
+                            const int cc = lane + 16 * t;
+                            rotate_pair(x[t], y[t], c, sn, pr, -pi);
+                            Aw[p + LD * cc] = x[t];
+                            Aw[q + LD * cc] = y[t];
                         }
                     }
                 }

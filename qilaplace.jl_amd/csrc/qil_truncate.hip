@@ -175,6 +175,9 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r0 * r0) * e, &Rb));
         bool certified = false;
         QIL_TRY(qil_dev_qr_certified(ctx, dtype, m, n, A, lda, cert_cutoff, Qb, Rb, &certified));
+        if (getenv("QIL_SVD_DEBUG"))
+            fprintf(stderr, "[svd-cert] %lld x %lld (lda %lld), absorb %d: %s\n", (long long)m, (long long)n, (long long)lda, absorb,
+                    certified ? "QR gauge" : "declined");
         if (certified) {
             void *U = nullptr, *Vh = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * r0) * e, &U));
@@ -189,7 +192,7 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
                     QIL_TRY(copy_2d(ctx, dtype, m, n, A, lda, Vh, r0));
                 }
             } else {                                 // Vh isometric, U S absorbed
-                if (m <= n) {                        // A^H = Q R  =>  A = R^H Q^H
+                if (m < n) {                         // A^H = Q R  =>  A = R^H Q^H   (m == n: the factor is of A itself)
                     QIL_TRY(qil_dev_transpose(ctx, dtype, 1, rows, r0, Qb, rows, Vh, r0));
                     QIL_TRY(qil_dev_transpose(ctx, dtype, 1, r0, r0, Rb, r0, U, m));
                 } else {                             // every column direction is kept: Vh = I, U S = A

@@ -2088,3 +2088,18 @@ def test_gauge_sweep_certificate_on_wide_bonds_and_products(qil, monkeypatch):
     bb = rng.integers(0, 2, size=(64, 10))
     g, wv = qil.coefficient_batch(prod, bb), O.coefficient_batch(prod_o, bb)
     assert np.abs(g - wv).max() <= 1e-8 * np.abs(wv).max()
+
+
+def test_signal_mps_svd_wide_bonds_reconstruct(qil):
+    """signal_mps(:svd) of a random signal (bonds to 2^(n/2): every gauge step is full rank, so the certificate route of
+    the >= 640-column SVDs is taken, including the SQUARE 1024 x 1024 site that an orientation mix-up once turned into
+    garbage) reconstructs the signal; bond dimensions equal the full-rank profile."""
+    rng = np.random.default_rng(3)
+    for n in (16, 20):
+        x = rng.standard_normal(2 ** n)
+        psi = qil.signal_mps(x, method="svd")
+        assert psi.bond_dims == [min(2 ** (i + 1), 2 ** (n - 1 - i)) for i in range(n - 1)]
+        assert np.abs(qil.mps_to_vector(psi) - x).max() < 1e-11 * np.abs(x).max()
+    z = rng.standard_normal(2 ** 20) + 1j * rng.standard_normal(2 ** 20)
+    psi = qil.signal_mps(z, method="svd")
+    assert np.abs(qil.mps_to_vector(psi) - z).max() < 1e-11 * np.abs(z).max()
