@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 2 : 1)) void gemm_mfma
                                                  long long a_bs, long long b_bs, long long c_bs,
                                                  const int* __restrict__ cmap, int cmap_blk,
                                                  const uint8_t* __restrict__ b_sel, long long b_sel_step,
-                                                 long long b_sel_stride) {
+                                                 long long b_sel_stride, int subtract) {
     constexpr bool CX = sizeof(T) == 16;
     constexpr int NP = CX ? 2 : 1;
     constexpr int LA = BM + GPAD, LB = BN + GPAD;   // +2 doubles: <= 2-way LDS conflicts for both the k-major
@@ -249,7 +249,14 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 2 : 1)) void gemm_mfma
                 if (gr < m && gc < n) {
                     const long long oc = cmap ? (long long)cmap[gc / cmap_blk] * cmap_blk + gc % cmap_blk : gc;
                     double* cp = reinterpret_cast<double*>(C + gr + ldc * oc);
-                    if (CX) {
+                    if (subtract) {
+                        if (CX) {
+                            cp[0] -= rr[ti][tj][r] - ii[ti][tj][r];
+                            cp[1] -= ri[ti][tj][r];
+                        } else {
+                            cp[0] -= rr[ti][tj][r];
+                        }
+                    } else if (CX) {
                         cp[0] = rr[ti][tj][r] - ii[ti][tj][r];
                         cp[1] = ri[ti][tj][r];
                     } else {
@@ -261,12 +268,13 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 2 : 1)) void gemm_mfma
 
 template <class T>
 __global__ void splitk_reduce(const T* __restrict__ W, long long cstride, int splits, long long m, long long n,
-                              T* __restrict__ C, long long ldc) {
+                              T* __restrict__ C, long long ldc, int subtract) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < m * n;
          t += (long long)gridDim.x * blockDim.x) {
         T acc = W[t];
         for (int z = 1; z < splits; ++z) acc = add_t(acc, W[t + z * cstride]);
-        C[(t % m) + ldc * (t / m)] = acc;
+        T* cp = C + (t % m) + ldc * (t / m);
+        *cp = subtract ? sub_t(*cp, acc) : acc;
     }
 }
 
@@ -278,6 +286,7 @@ struct gemm_batch {
     int cmap_blk = 1;
     const uint8_t* b_sel = nullptr;
     long long b_sel_step = 0, b_sel_stride = 0;
+    int subtract = 0;                   // 1: C <- C - op(A) op(B)  (the projection step of the blocked QR, no temporary)
 };
 
 template <class T, int BM, int BN, int WM, int WN, bool PIPE>
@@ -289,7 +298,7 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     const bool arc = a_rs == 1, bkc = b_ks == 1;
     using kern_t = void (*)(long long, long long, long long, const T*, long long, long long, int, const T*, long long,
                             long long, int, T*, long long, long long, long long, int, int, int, long long, long long,
-                            long long, const int*, int, const uint8_t*, long long, long long);
+                            long long, const int*, int, const uint8_t*, long long, long long, int);
     const kern_t kern = arc ? (bkc ? (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, true, true>
                                    : (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, true, false>)
                             : (bkc ? (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, false, true>
@@ -339,12 +348,12 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     const int col_fastest = (tiles_n <= 8 ? 1 : 0) | (xcd_order ? 0 : 2);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits), dim3(256), lds, ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo,
                        kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,
-                       bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride);
+                       bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride, splits > 1 ? 0 : bt.subtract);
     QIL_HIP(hipGetLastError());
     if (splits > 1) {
         // a packed batch reduces as one m x (n * count) matrix
         hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)std::min<long long>((cstride + 255) / 256, 2048)), dim3(256),
-                           0, ctx->stream, (const T*)Cout, cstride, splits, m, n * bt.count, C, ldc);
+                           0, ctx->stream, (const T*)Cout, cstride, splits, m, n * bt.count, C, ldc, bt.subtract);
         QIL_HIP(hipGetLastError());
         qil_ctx_free(ctx, wsp);
     }
@@ -977,10 +986,10 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long l
 
 // ------------------------------------------------------------------ Householder panel (in LDS)
 // Thin QR of one panel P (m x b, b <= 32) resident in LDS, the intra-panel step of the blocked QR below (r02; it
-// replaces the CGS2 panel kernel gs_fused there: ~110-150 us per 512 x 32 panel -> ~15 us).  Householder reflectors
-// (every wave derives the reflector of column j redundantly from its registers and updates the trailing columns it
-// owns: one barrier per column), explicit Q formed barrier-free (one column per wave, held in registers), positive
-// real diagonal of R by a column phase.  Staircase form for numerically dependent columns -- residual below 1e-13 of
+// replaces the CGS2 panel kernel gs_fused there).  Householder reflectors (every wave updates the trailing columns it
+// owns, two at a time; the owner of the NEXT column updates that one first and derives its reflector while the others
+// are still updating: one barrier per column), explicit Q formed barrier-free (columns held in registers, two per wave at
+// a time), positive real diagonal of R by a column phase.  Staircase form for numerically dependent columns -- residual below 1e-13 of
 // the column's ORIGINAL norm (ref_norm: measured by the blocked driver before its projections): such a column gets no
 // reflector and no row, comes out as a ZERO column of Q with a zero row of R, and P = Q R still holds (its components
 // along the earlier reflectors' rows stay in R) -- the contract the CGS2 kernel established for rank-deficient
@@ -1001,6 +1010,12 @@ __device__ __forceinline__ c64 hh_wave_sum(c64 v) {     // both parts in one red
     return v;
 }
 
+__device__ __forceinline__ void hh_wave_sum_pair(double& a, double& b) { wave_sum2(a, b); }
+__device__ __forceinline__ void hh_wave_sum_pair(c64& a, c64& b) {
+    wave_sum2(a.re, a.im);
+    wave_sum2(b.re, b.im);
+}
+
 // Row predicates are kept out of the instruction stream (a select around a load becomes a branch with a wait inside, one
 // per element): every column has a zero SINK row m behind its data, lanes beyond the matrix read and write that row, and
 // the staircase mask enters as a multiplication by 0 / 1 -- the update y -= f x then rewrites the rows above the staircase
@@ -1008,11 +1023,15 @@ __device__ __forceinline__ c64 hh_wave_sum(c64 v) {     // both parts in one red
 template <class T, int KM>
 constexpr int hh_panel_waves() { return KM * (int)(sizeof(T) / 8) > 18 ? 8 : 16; }   // long columns: 256 registers per lane
 
-template <class T, int KM>
+template <class T, int KM, bool PROF = false>
 __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __restrict__ P, long long lda, int m, int b,
                                                                          T* __restrict__ R, long long ldr,
-                                                                         const double* __restrict__ ref_norm) {
+                                                                         const double* __restrict__ ref_norm,
+                                                                         long long* __restrict__ prof = nullptr) {
     constexpr int NW = hh_panel_waves<T, KM>();
+    long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;          // PROF: s_memtime stamps (tools/micro/hh_panel_cost.hip)
+    if (PROF) tp0 = __builtin_amdgcn_s_memtime();
+    constexpr bool PAIR = KM * (int)(sizeof(T) / 8) <= 8;   // register budget: 128 per lane with 16 waves (longer columns would spill)
     extern __shared__ __attribute__((aligned(16))) char hp_smem[];
     const int la = (m + 1) | 1;
     T* Ps = reinterpret_cast<T*>(hp_smem);
@@ -1020,7 +1039,8 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
     double* dia = kap + 32;                                              // b: |R_jj|
     double* refn = dia + 32;                                             // b: reference norms
     T* pha = reinterpret_cast<T*>(refn + 32);                            // b: column phase making R_jj real positive
-    int* rowof = reinterpret_cast<int*>(pha + 32);                       // b: staircase row of column j, -1 = dependent
+    T* dif = pha + 32;                                                   // b: first entry of u_j
+    int* rowof = reinterpret_cast<int*>(dif + 32);                       // b: staircase row of column j, -1 = dependent
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto rowc = [&](int u) { return min(lane + 64 * u, m); };          // this lane's rows (sink row m beyond the matrix)
     // stage: wave w owns columns w, w + 16 (all loads of a column in flight)
@@ -1039,25 +1059,26 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
         if (lane == 0) refn[c] = ref_norm ? ref_norm[c] : sqrt(nn);
     }
     __syncthreads();
-    int rr = 0;                                            // staircase row: identical in every thread
-    for (int j = 0; j < b; ++j) {
-        const T* x = Ps + (size_t)la * j;
-        T xs[KM];
+    if (PROF) tp1 = __builtin_amdgcn_s_memtime();
+    // Reflector of column jn from the column's current values yv (the calling wave's registers; the staircase entry is read
+    // back from LDS).  ONE wave runs this -- the owner of the column, right after it has applied the previous reflector to it
+    // and while the other waves are still updating theirs; everybody picks kappa, the first entry of u and the staircase row
+    // up after the barrier.  (Every wave deriving every reflector redundantly made the column loop ISSUE-bound: four waves
+    // per SIMD x ~90 instructions of reductions and reciprocal square roots per column, 3 200 cycles per column measured
+    // with tools/micro/hh_panel_cost.hip whatever the column length.)
+    auto derive = [&](int jn, int rrn, const T(&yv)[KM]) {
         double s2 = 0;
 #pragma unroll
-        for (int u = 0; u < KM; ++u) {
-            xs[u] = scale_t(x[rowc(u)], (rowc(u) > rr && rowc(u) < m) ? 1.0 : 0.0);
-            s2 += abs2_t(xs[u]);
-        }
+        for (int u = 0; u < KM; ++u) s2 += (rowc(u) > rrn && rowc(u) < m) ? abs2_t(yv[u]) : 0.0;
         s2 = wave_sum(s2);
-        const T alpha = x[rr < m ? rr : m];
+        const T alpha = Ps[(rrn < m ? rrn : m) + (size_t)la * jn];
         // the column's norm, |alpha| and kappa sit on the dependent chain of every column: reciprocal square roots and
         // reciprocals with one Newton step (1-2 ulp) instead of the IEEE sqrt / divide sequences (~4 x 30 instructions)
         const double a2 = abs2_t(alpha);
         const double t2 = a2 + s2;
         const double nrm = t2 > 0.0 ? t2 * rsqrt_refined(t2) : 0.0;
-        const double rn = refn[j];
-        const bool dep = rr >= m || !(nrm > 1e-13 * rn) || rn == 0.0;
+        const double rn = refn[jn];
+        const bool dep = rrn >= m || !(nrm > 1e-13 * rn) || rn == 0.0;
         double kappa = 0.0, absa = 0.0;
         T pa{}, diff{};
         if (!dep) {
@@ -1070,7 +1091,96 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
             }
             diff = scale_t(pa, absa + nrm);
             kappa = rcp_refined(nrm * (nrm + absa));
-            for (int c = j + 1 + ((wave - (j + 1)) % NW + NW) % NW; c < b; c += NW) {
+        }
+        if (lane == 0) {
+            kap[jn] = kappa;
+            rowof[jn] = dep ? -1 : rrn;
+            if (!dep) {
+                dia[jn] = nrm;
+                pha[jn] = scale_t(pa, -1.0);                 // beta / |beta|
+                dif[jn] = diff;
+                Ps[rrn + (size_t)la * jn] = diff;            // first entry of u_jn (nobody reads alpha again)
+            }
+        }
+    };
+    if (wave == 0) {
+        T y0[KM];
+#pragma unroll
+        for (int u = 0; u < KM; ++u) y0[u] = Ps[rowc(u)];
+        derive(0, 0, y0);
+    }
+    __syncthreads();
+    int rr = 0;                                            // staircase row: identical in every thread
+    for (int j = 0; j < b; ++j) {
+        const T* x = Ps + (size_t)la * j;
+        const double kappa = kap[j];
+        const bool dep = rowof[j] < 0;
+        const int rrn = dep ? rr : rr + 1;                 // staircase row of the next column
+        T diff{};
+        if (!dep) diff = dif[j];
+        T xs[KM];
+#pragma unroll
+        for (int u = 0; u < KM; ++u) xs[u] = scale_t(x[rowc(u)], (rowc(u) > rr && rowc(u) < m) ? 1.0 : 0.0);
+        int c = j + 1 + ((wave - (j + 1)) % NW + NW) % NW;
+        if (c == j + 1 && c < b) {                         // owner of the next column: update it first, then its reflector
+            T* y = Ps + (size_t)la * c;
+            T ys[KM];
+#pragma unroll
+            for (int u = 0; u < KM; ++u) ys[u] = y[rowc(u)];
+            if (!dep) {
+                const T yr = y[rr];
+                T w{};
+#pragma unroll
+                for (int u = 0; u < KM; ++u) w = add_t(w, hh_mul_conj(xs[u], ys[u]));
+                w = hh_wave_sum(w);
+                w = add_t(w, hh_mul_conj(diff, yr));
+                const T f = scale_t(w, kappa);
+#pragma unroll
+                for (int u = 0; u < KM; ++u) {
+                    ys[u] = sub_t(ys[u], hh_cmul(f, xs[u]));
+                    y[rowc(u)] = ys[u];
+                }
+                if (lane == 0) y[rr] = sub_t(yr, hh_cmul(f, diff));
+            }
+            derive(c, rrn, ys);
+            c += NW;
+        }
+        if (!dep) {
+            if constexpr (PAIR) {
+                // two of this wave's trailing columns at a time: one set of LDS round trips and ONE reduction tree for
+                // both dot products instead of two dependent passes
+                for (; c + NW < b; c += 2 * NW) {
+                    T* y0 = Ps + (size_t)la * c;
+                    T* y1 = y0 + (size_t)la * NW;
+                    T ya[KM], yb[KM];
+#pragma unroll
+                    for (int u = 0; u < KM; ++u) {
+                        ya[u] = y0[rowc(u)];
+                        yb[u] = y1[rowc(u)];
+                    }
+                    const T ra = y0[rr], rb = y1[rr];
+                    T wa{}, wb{};
+#pragma unroll
+                    for (int u = 0; u < KM; ++u) {
+                        wa = add_t(wa, hh_mul_conj(xs[u], ya[u]));
+                        wb = add_t(wb, hh_mul_conj(xs[u], yb[u]));
+                    }
+                    hh_wave_sum_pair(wa, wb);
+                    wa = add_t(wa, hh_mul_conj(diff, ra));
+                    wb = add_t(wb, hh_mul_conj(diff, rb));
+                    const T fa = scale_t(wa, kappa), fb = scale_t(wb, kappa);
+#pragma unroll
+                    for (int u = 0; u < KM; ++u) {
+                        y0[rowc(u)] = sub_t(ya[u], hh_cmul(fa, xs[u]));
+                        y1[rowc(u)] = sub_t(yb[u], hh_cmul(fb, xs[u]));
+                    }
+                    if (lane == 0) {
+                        y0[rr] = sub_t(ra, hh_cmul(fa, diff));
+                        y1[rr] = sub_t(rb, hh_cmul(fb, diff));
+                    }
+                }
+            }
+            for (; c < b; c += NW) {
                 T* y = Ps + (size_t)la * c;
                 T ys[KM];
 #pragma unroll
@@ -1088,18 +1198,10 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            kap[j] = kappa;
-            rowof[j] = dep ? -1 : rr;
-            if (!dep) {
-                dia[j] = nrm;
-                pha[j] = scale_t(pa, -1.0);                 // beta / |beta|
-                Ps[rr + (size_t)la * j] = diff;             // first entry of u_j (nobody reads alpha again)
-            }
-        }
-        if (!dep) ++rr;
+        rr = rrn;
     }
     __syncthreads();
+    if (PROF) tp2 = __builtin_amdgcn_s_memtime();
     // R block (b x b): row jj = conj(phase_jj) * staircase row rowof[jj]; zero rows for dependent columns
     if (R)
         for (int t = tid; t < b * b; t += 64 * NW) {
@@ -1112,8 +1214,58 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
             }
             R[jj + ldr * c] = v;
         }
+    if (PROF) tp3 = __builtin_amdgcn_s_memtime();
     // explicit Q: column c = phase_c * H_{j0} ... H_{jk} e_{rowof[c]} over the independent columns j <= c, last first
-    for (int c = wave; c < b; c += NW) {
+    int cq = wave;
+    if constexpr (PAIR) {
+        // columns c and c + NW of this wave together: the reflectors j in (c, c + NW] act on the second one only, the
+        // rest on both with one LDS read of the reflector and one reduction tree
+        for (; cq + NW < b; cq += 2 * NW) {
+            const int c0 = cq, c1 = cq + NW;
+            const int r0 = rowof[c0], r1 = rowof[c1];
+            T qa[KM], qb[KM];
+#pragma unroll
+            for (int u = 0; u < KM; ++u) {
+                qa[u] = T{};
+                qb[u] = T{};
+                if (lane + 64 * u == r0) reinterpret_cast<double*>(&qa[u])[0] = 1.0;
+                if (lane + 64 * u == r1) reinterpret_cast<double*>(&qb[u])[0] = 1.0;
+            }
+            for (int j = c1; j >= 0; --j) {
+                const double kappa = kap[j];
+                const int rj = rowof[j];
+                if (kappa == 0.0 || rj < 0) continue;
+                const T* x = Ps + (size_t)la * j;
+                T xs[KM];
+                T wa{}, wb{};
+#pragma unroll
+                for (int u = 0; u < KM; ++u) {
+                    xs[u] = scale_t(x[rowc(u)], (rowc(u) >= rj && rowc(u) < m) ? 1.0 : 0.0);
+                    wa = add_t(wa, hh_mul_conj(xs[u], qa[u]));
+                    wb = add_t(wb, hh_mul_conj(xs[u], qb[u]));
+                }
+                hh_wave_sum_pair(wa, wb);
+                const T fa = scale_t(wa, (j <= c0 && r0 >= 0) ? kappa : 0.0), fb = scale_t(wb, r1 >= 0 ? kappa : 0.0);
+#pragma unroll
+                for (int u = 0; u < KM; ++u) {
+                    qa[u] = sub_t(qa[u], hh_cmul(fa, xs[u]));
+                    qb[u] = sub_t(qb[u], hh_cmul(fb, xs[u]));
+                }
+            }
+            const T pa = r0 >= 0 ? pha[c0] : T{}, pb = r1 >= 0 ? pha[c1] : T{};
+            T* d0 = P + lda * c0;
+            T* d1 = P + lda * c1;
+#pragma unroll
+            for (int u = 0; u < KM; ++u) {
+                const int r = lane + 64 * u;
+                if (r < m) {
+                    d0[r] = r0 >= 0 ? hh_cmul(qa[u], pa) : T{};
+                    d1[r] = r1 >= 0 ? hh_cmul(qb[u], pb) : T{};
+                }
+            }
+        }
+    }
+    for (int c = cq; c < b; c += NW) {
         T* dst = P + lda * c;
         const int ro = rowof[c];
         T q[KM];
@@ -1147,16 +1299,27 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
             if (r < m) dst[r] = ro >= 0 ? hh_cmul(q[u], ph) : T{};
         }
     }
+    if (PROF) {
+        __syncthreads();
+        if (tid == 0) {
+            const long long tp4 = __builtin_amdgcn_s_memtime();
+            atomicAdd((unsigned long long*)prof + 0, (unsigned long long)(tp1 - tp0));
+            atomicAdd((unsigned long long*)prof + 1, (unsigned long long)(tp2 - tp1));
+            atomicAdd((unsigned long long*)prof + 2, (unsigned long long)(tp3 - tp2));
+            atomicAdd((unsigned long long*)prof + 3, (unsigned long long)(tp4 - tp3));
+            atomicAdd((unsigned long long*)prof + 4, 1ull);
+        }
+    }
 }
 
 // true when the panel fits (LDS and rows-per-lane budget); launches it
 template <class T>
 bool hh_panel_fits(long long m, int b) {
-    return b <= 32 && m <= 64 * 19 && (size_t)((m + 1) | 1) * b * sizeof(T) + 1536 <= 150 * 1024;
+    return b <= 32 && m <= 64 * 19 && (size_t)((m + 1) | 1) * b * sizeof(T) + 2048 <= 150 * 1024;
 }
 template <class T>
 int hh_panel_launch(qil_context* ctx, T* P, long long lda, long long m, int b, T* R, long long ldr, const double* ref_norm) {
-    const size_t lds = (size_t)((m + 1) | 1) * b * sizeof(T) + 1536;
+    const size_t lds = (size_t)((m + 1) | 1) * b * sizeof(T) + 2048;
     const int km = (int)((m + 63) / 64);
 #define QIL_HHP(KMv)                                                                                                   \
     do {                                                                                                               \
@@ -1167,11 +1330,12 @@ int hh_panel_launch(qil_context* ctx, T* P, long long lda, long long m, int b, T
             attr = true;                                                                                               \
         }                                                                                                              \
         hipLaunchKernelGGL((hh_panel<T, KMv>), dim3(1), dim3(64 * hh_panel_waves<T, KMv>()), lds, ctx->stream, P, lda, (int)m, b, R, \
-                           ldr, ref_norm);                                                                             \
+                           ldr, ref_norm, (long long*)nullptr);                                                                             \
     } while (0)
     if (km <= 2) QIL_HHP(2);
     else if (km <= 4) QIL_HHP(4);
     else if (km <= 6) QIL_HHP(6);
+    else if (km <= 8) QIL_HHP(8);
     else if (km <= 9) QIL_HHP(9);
     else if (km <= 13) QIL_HHP(13);
     else QIL_HHP(19);
@@ -2610,17 +2774,6 @@ __global__ void add_block(T* __restrict__ R, long long ldr, const T* __restrict_
         R[i + ldr * j] = add_t(R[i + ldr * j], C[i + ldc * j]);
     }
 }
-// P -= D  (m x b)
-template <class T>
-__global__ void sub_block(T* __restrict__ P, long long ldp, const T* __restrict__ D, long long ldd, long long m,
-                          int b) {
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < m * b;
-         t += (long long)gridDim.x * blockDim.x) {
-        const long long i = t % m, j = t / m;
-        P[i + ldp * j] = sub_t(P[i + ldp * j], D[i + ldd * j]);
-    }
-}
-
 // Column norms of a tall matrix: partial sums of squares per (chunk, column), then one small reduction.
 template <class T>
 __global__ __launch_bounds__(256) void col_sumsq_chunks(const T* __restrict__ A, long long lda, long long m,
@@ -2722,7 +2875,7 @@ int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, 
 // Thin QR with non-negative diagonal (qr(...; positive=true), rsvd.jl:83,90,94).
 //   * small panels: ONE launch (gs_fused);
 //   * otherwise blocked CGS2: panels of 16 columns are projected against all previous columns with two
-//     MFMA GEMMs per pass (C = Q^H P, P -= Q C) and orthonormalised internally by gs_fused -- the work is
+//     MFMA GEMMs per pass (C = Q^H P, then P -= Q C in the second GEMM's epilogue) and orthonormalised internally by gs_fused -- the work is
 //     spread over the chip by the GEMMs and the launch count drops from ~5 n to ~7 n / 16.
 template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
@@ -2752,23 +2905,21 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     const bool wide = pb_max >= 32 && !tree && ((size_t)64 + (size_t)(m | 1) * 32) * sizeof(T) <= 150 * 1024;
     const int PB = wide ? 32 : 16;
     if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
-    void *cbuf = nullptr, *dbuf = nullptr, *nbuf = nullptr;
+    void *cbuf = nullptr, *nbuf = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nbuf));
     // original column norms, measured before any projection (reference for the dependence test)
     QIL_TRY(col_norms_any<T>(ctx, A, lda, m, n, (double*)nbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * PB) * sizeof(T), &cbuf));
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * PB) * sizeof(T), &dbuf));
     T* C = static_cast<T*>(cbuf);
-    T* D = static_cast<T*>(dbuf);
     const int opH = sizeof(T) == 16 ? 2 : 1;
     for (long long j0 = 0; j0 < n; j0 += PB) {
         const int b = (int)std::min<long long>(PB, n - j0);
         T* P = A + lda * j0;
         for (int pass = 0; pass < 2 && j0 > 0; ++pass) {
             QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, j0, b, m, A, lda, P, lda, C, n));      // C = Q^H P
-            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, b, j0, A, lda, C, n, D, m));          // D = Q C
-            hipLaunchKernelGGL(sub_block<T>, dim3((unsigned)std::min<long long>((m * b + 255) / 256, 4096)),
-                               dim3(256), 0, ctx->stream, P, lda, (const T*)D, m, m, b);
+            gemm_batch proj;
+            proj.subtract = 1;
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, b, j0, A, lda, C, n, P, lda, proj));  // P -= Q C
             if (R)
                 hipLaunchKernelGGL(add_block<T>, dim3(8), dim3(256), 0, ctx->stream, R + ldr * j0, ldr, (const T*)C,
                                    n, (int)j0, b);
@@ -2784,7 +2935,6 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     }
     QIL_HIP(hipGetLastError());
     qil_ctx_free(ctx, cbuf);
-    qil_ctx_free(ctx, dbuf);
     qil_ctx_free(ctx, nbuf);
     return QIL_OK;
 }
