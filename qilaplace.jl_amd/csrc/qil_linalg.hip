@@ -2225,7 +2225,8 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     const long long k = std::min(p, q);
     static const bool enabled = !(getenv("QIL_SVD_LEFT") && atoi(getenv("QIL_SVD_LEFT")) == 0);
     if (!enabled || k < 17 || k >= 640) return QIL_OK;
-    if (k < 97) {
+    static const long long fused_below = getenv("QIL_SVD_LEFT_MIN") ? atoll(getenv("QIL_SVD_LEFT_MIN")) : 49;   // tuning aid (97 -> 49: compress! chi 64 -> 32 31.6 -> 28 ms, 128 -> 64 52.6 -> 50 ms)
+    if (k < fused_below) {
         // small operands: the single-workgroup iteration of the general path (operand and V in LDS, no launches) wins
         // whenever it fits; where it does not (complex 2 chi x chi sites with chi > 64, long rows) that path falls back to V
         // in global memory (1.1 ms per SVD) or to per-round launches that carry V, and the one-factor route is 2x faster
@@ -2889,7 +2890,14 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     const bool panel16_fits = ((size_t)32 + (size_t)(m | 1) * 16) * sizeof(T) <= 150 * 1024;
     static const long long tree_min = getenv("QIL_TSQR_NOFIT_ROWS") ? atoll(getenv("QIL_TSQR_NOFIT_ROWS")) : 640;        // tuning aid (1024 -> 600: exact compress! of the bond-1008 product 476 -> 455 ms, neutral elsewhere)
     const bool tree = m >= TALL || (!panel16_fits && m >= tree_min);
-    if (n <= 16 || fits_lds) {
+    // up to `fused_max` columns the CGS2 kernel does the whole factorisation in one launch; beyond, whenever a Householder
+    // panel fits, one panel launch (n <= 32) or the blocked route below is faster even where the operand fits one CU's LDS
+    // (128 x 64: 274 -> ~140 us -- the CGS2 kernel pays ~4 us per column, the Householder panel ~1.5; compress! chi 64 -> 32
+    // 28 -> 24.5 ms, 128 -> 64 50 -> 42 ms; narrower panels measured equal within noise either way)
+    static const long long fused_max = getenv("QIL_QR_FUSED_MAX_N") ? atoll(getenv("QIL_QR_FUSED_MAX_N")) : 16;   // tuning aid
+    const bool hh_ok = hh_panels && !tree && n > fused_max && hh_panel_fits<T>(m, (int)std::min<long long>(n, 32));
+    if (hh_ok && n <= 32) return hh_panel_launch<T>(ctx, A, lda, m, (int)n, R, ldr, (const double*)nullptr);
+    if (n <= 16 || (fits_lds && !hh_ok)) {
         if (tree && n <= 16) {
             void* nb0 = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nb0));

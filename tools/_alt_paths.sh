@@ -34,3 +34,4 @@ run QIL_BATCH_WORKERS=3 QIL_ENCODE_PAR_DEPTH=5
 run QIL_DT_BUILDER=launches QIL_ZIP_SKETCH=0
 run QIL_DT_DCAP=24
 run QIL_SVD_CERT=0
+run QIL_QR_FUSED_MAX_N=100000 QIL_SVD_LEFT_MIN=97
