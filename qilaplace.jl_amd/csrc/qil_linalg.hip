@@ -1214,8 +1214,25 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
             }
             R[jj + ldr * c] = v;
         }
+    // the reflectors, cleaned for the Q loop below: zeros above the staircase row (those entries were R's, just written
+    // out) and in dependent columns, so that the loop reads them without a mask
+    __syncthreads();
+    for (int c = wave; c < b; c += NW) {
+        const int ro = rowof[c];
+        T* x = Ps + (size_t)la * c;
+        if (ro < 0) {
+#pragma unroll
+            for (int u = 0; u < KM; ++u) x[rowc(u)] = T{};
+        } else if (lane < ro) {
+            x[lane] = T{};                                   // ro <= c < 32
+        }
+    }
+    __syncthreads();
     if (PROF) tp3 = __builtin_amdgcn_s_memtime();
-    // explicit Q: column c = phase_c * H_{j0} ... H_{jk} e_{rowof[c]} over the independent columns j <= c, last first
+    // explicit Q: column c = phase_c * H_{j0} ... H_{jk} e_{rowof[c]} over the independent columns j <= c, last first.
+    // (A compact-WY formation -- Gram matrix by MFMA, T by back substitution, Q = E - V T W by MFMA tiles -- was built and
+    // measured slower: the 32 dependent rows of the triangular solve cost ~650 cycles each between barriers, 39 k cycles
+    // against this loop's 34 k for a 256 x 32 f64 panel, 73 k against 79 k for a complex one.)
     int cq = wave;
     if constexpr (PAIR) {
         // columns c and c + NW of this wave together: the reflectors j in (c, c + NW] act on the second one only, the
@@ -1240,7 +1257,7 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
                 T wa{}, wb{};
 #pragma unroll
                 for (int u = 0; u < KM; ++u) {
-                    xs[u] = scale_t(x[rowc(u)], (rowc(u) >= rj && rowc(u) < m) ? 1.0 : 0.0);
+                    xs[u] = x[rowc(u)];
                     wa = add_t(wa, hh_mul_conj(xs[u], qa[u]));
                     wb = add_t(wb, hh_mul_conj(xs[u], qb[u]));
                 }
@@ -1284,7 +1301,7 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
                 T w{};
 #pragma unroll
                 for (int u = 0; u < KM; ++u) {
-                    xs[u] = scale_t(x[rowc(u)], (rowc(u) >= rj && rowc(u) < m) ? 1.0 : 0.0);
+                    xs[u] = x[rowc(u)];
                     w = add_t(w, hh_mul_conj(xs[u], q[u]));
                 }
                 w = hh_wave_sum(w);
