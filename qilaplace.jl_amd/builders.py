@@ -353,9 +353,13 @@ def zt_qft_chain_tensors(n, cutoff=1e-14, maxdim=1000):
     of control_Hphase_ztmps_mpo blocks.  Depends on n only, so sweeps over the damping build it once."""
     key = (int(n), float(cutoff), maxdim)
     if key not in _ZT_Q_CACHE:
-        Q = _zt_block(1)
-        for k in range(2, n + 1):
+        # the chain for n is the chain for n - 1 zipped with one more block: start from the longest cached prefix and keep
+        # every intermediate (a later call with a smaller or slightly larger n costs nothing or a few steps)
+        k0 = max((m for (m, c, d) in _ZT_Q_CACHE if c == key[1] and d == maxdim and m < n), default=1)
+        Q = _ZT_Q_CACHE[(k0, key[1], maxdim)] if k0 > 1 else _zt_block(1)
+        for k in range(k0 + 1, n + 1):
             Q = _compress_lr(_zip_lr(_pad_pair(Q, np.complex128), _zt_block(k)), cutoff, maxdim)
+            _ZT_Q_CACHE[(k, key[1], maxdim)] = Q
         _ZT_Q_CACHE[key] = Q
     return _ZT_Q_CACHE[key]
 

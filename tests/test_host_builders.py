@@ -53,3 +53,19 @@ def test_builder_argument_errors(qil):
         qil.dt_mpo_tensors(0, 1.0)
     with pytest.raises(ValueError):
         qil.zt_mpo_tensors(0, 1.0)
+
+
+def test_zt_qft_half_is_built_from_cached_prefixes():
+    """The damping-independent half of build_zt_mpo for n is the one for n - 1 zipped with one more block
+    (zt_transformer.jl:78-98): every intermediate chain is cached, a chain continued from a cached prefix equals the one
+    built from scratch bit for bit, and the cached prefixes are not modified by the continuation."""
+    from qilaplace_jl_amd import builders as B
+    B._ZT_Q_CACHE.clear()
+    scratch = [t.copy() for t in B.zt_qft_chain_tensors(7)]
+    B._ZT_Q_CACHE.clear()
+    five = B.zt_qft_chain_tensors(5)
+    keep = [t.copy() for t in five]
+    cont = B.zt_qft_chain_tensors(7)
+    assert len(cont) == 14 and all(np.array_equal(a, b) for a, b in zip(scratch, cont))
+    assert all(np.array_equal(a, b) for a, b in zip(five, keep))
+    assert (6, 1e-14, 1000) in B._ZT_Q_CACHE and len(B.zt_qft_chain_tensors(6)) == 12
