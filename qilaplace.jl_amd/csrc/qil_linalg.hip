@@ -2001,11 +2001,32 @@ int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, do
 // cross rounds group `grp` keeps column p = grp of the lower block in registers over all BB inner rounds; only its partner
 // travels through LDS.  (Measured, tools/micro/jacobi_round_cost.hip, k = 256 f64: the predicated version spent 1.07 us per
 // inner round -- ~40 exec-mask branches -- of a 12.1 us round.)
+// Batched form (items != nullptr, gridDim.y operands of one kernel class -- independent chains of a batch whose sweeps the
+// combiner of qil_context.hip has put into one launch): workgroup (x, y) takes its operand from items[y] and leaves when that
+// operand has fewer block pairs than the grid is wide.  The arithmetic is the single-operand kernel's, bit for bit.
 template <class T, int BB, int KM, int G, bool AP, bool PROF = false>
-__global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__ A, long long lda, int m, int n, int nb,
-                                                                 int round, double tol, int* __restrict__ rotated,
-                                                                 const double* __restrict__ negligible,
-                                                                 long long* __restrict__ prof = nullptr) {
+__global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__ A_, long long lda_, int m_, int n_, int nb_,
+                                                                 int round, double tol_, int* __restrict__ rotated_,
+                                                                 const double* __restrict__ negligible_,
+                                                                 long long* __restrict__ prof = nullptr,
+                                                                 const qil_round_item* __restrict__ items = nullptr) {
+    T* __restrict__ A = A_;
+    long long lda = lda_;
+    int m = m_, n = n_, nb = nb_;
+    int* __restrict__ rotated = rotated_;
+    const double* __restrict__ negligible = negligible_;
+    double tol = tol_;
+    if (items) {
+        const qil_round_item it = items[blockIdx.y];
+        if ((int)blockIdx.x >= it.nblk / 2 || round >= it.nblk - 1) return;   // narrower operand: fewer pairs, fewer rounds
+        A = static_cast<T*>(it.X);
+        lda = it.ldx;
+        m = n = it.k;
+        nb = it.nblk;
+        rotated = it.flag;
+        negligible = it.negl;
+        tol = it.tol;
+    }
     // PROF (tools/micro/jacobi_round_cost.hip only): shader-clock stamps start / staged / rotated / stored + the 100 MHz clock
     long long st[5];
     if (PROF) {
@@ -2212,7 +2233,7 @@ constexpr size_t block_round_nov_lds() {
 
 template <class T, int BB, int KM, int G>
 int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nblk, int round, double tol, int* flag,
-                           const double* negl) {
+                           const double* negl, const qil_round_item* items = nullptr, int count = 1) {
     constexpr size_t lds = block_round_nov_lds<T, BB, KM, G>();
     static_assert(lds <= 156 * 1024, "column blocks must fit the LDS");
     static bool attr = false;
@@ -2224,11 +2245,11 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
         attr = true;
     }
     if (round == 0)
-        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
-                           k, nblk, round, tol, flag, negl);
+        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true>), dim3(nblk / 2, count), dim3(BB * G), lds, ctx->stream, X, ldx, k,
+                           k, nblk, round, tol, flag, negl, (long long*)nullptr, items);
     else
-        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, false>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
-                           k, nblk, round, tol, flag, negl);
+        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, false>), dim3(nblk / 2, count), dim3(BB * G), lds, ctx->stream, X, ldx, k,
+                           k, nblk, round, tol, flag, negl, (long long*)nullptr, items);
     return QIL_OK;
 }
 
@@ -2370,10 +2391,32 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     const double tol = std::max(1e-15, 4.0 * 1.1e-16 * std::sqrt((double)k));
     const int nblk = (int)(((k + bb - 1) / bb + 1) / 2 * 2);
     int sweeps = 0;
-    for (; sweeps < 40; ++sweeps) {
-        QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
-        for (int round = 0; round < nblk - 1; ++round) {
-#define QIL_NOV(BBv, KMv, Gv) QIL_TRY((launch_block_round_nov<T, BBv, KMv, Gv>(ctx, X, k, (int)k, nblk, round, tol, (int*)flag, (const double*)negl)))
+    // inside a batch the sweeps of the chains go through the combiner: one launch train for all operands of this kernel class
+    qil_sweep_combiner* const cb = qil_sweep_combiner_of(ctx);
+    const int cls = (int)sizeof(T) * 1000000 + G * 10000 + bb * 100 + km;
+    struct sweeper_scope {
+        qil_sweep_combiner* cb;
+        int cls;
+        sweeper_scope(qil_sweep_combiner* c, int k) : cb(c), cls(k) {
+            if (cb) {
+                std::lock_guard<std::mutex> g(cb->mu);
+                ++cb->sweepers[cls];
+            }
+        }
+        void leave() {                                  // right after the last sweep: the others must not wait for this chain
+            if (cb) {
+                std::lock_guard<std::mutex> g(cb->mu);
+                --cb->sweepers[cls];
+                cb->cv.notify_all();
+                cb = nullptr;
+            }
+        }
+        ~sweeper_scope() { leave(); }
+    } sweeping(cb, cls);
+    // the rounds of one sweep: over this chain's operand alone, or (items) over `count` operands of the class
+    auto launch_rounds = [&](const qil_round_item* items, int count, int nblk_max) -> int {
+        for (int round = 0; round < nblk_max - 1; ++round) {
+#define QIL_NOV(BBv, KMv, Gv) QIL_TRY((launch_block_round_nov<T, BBv, KMv, Gv>(ctx, X, k, (int)k, items ? nblk_max : nblk, round, tol, (int*)flag, (const double*)negl, items, count)))
             if (G == 32) {
                 if constexpr (sizeof(T) == 8) {
                     switch (km) {
@@ -2413,12 +2456,25 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             }
 #undef QIL_NOV
         }
+        return QIL_OK;
+    };
+    for (; sweeps < 40; ++sweeps) {
+        QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
+        if (cb) {
+            qil_sweep_request req;
+            req.item = qil_round_item{X, k, (int)k, nblk, (int*)flag, (const double*)negl, tol};
+            req.cls = cls;
+            QIL_TRY(qil_combined_sweep(ctx, cb, req, launch_rounds));
+        } else {
+            QIL_TRY(launch_rounds(nullptr, 1, nblk));
+        }
         int hv[2] = {0, 0};
         QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         QIL_HIP(hipStreamSynchronize(ctx->stream));
         if (dbg) fprintf(stderr, "[svd-left] sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[0], hv[1]);
         if (!hv[1]) break;
     }
+    sweeping.leave();
     lap("sweeps");
     hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)k), dim3(256), 0, ctx->stream, (const T*)X, k, k, (double*)nrm);
     std::vector<double> sig((size_t)k);

@@ -2103,3 +2103,25 @@ def test_signal_mps_svd_wide_bonds_reconstruct(qil):
     z = rng.standard_normal(2 ** 20) + 1j * rng.standard_normal(2 ** 20)
     psi = qil.signal_mps(z, method="svd")
     assert np.abs(qil.mps_to_vector(psi) - z).max() < 1e-11 * np.abs(z).max()
+
+
+def test_combined_sweeps_of_a_batch_are_bit_identical(qil, monkeypatch):
+    """QIL_BATCH_COMBINE=1: the chains of a running batch hand their Jacobi sweeps to a rendezvous that launches the block
+    rounds of all operands of one kernel class as ONE train (one operand per gridDim.y slice, narrower operands leave the
+    rounds they do not have).  The arithmetic is the single-operand kernel's: every tensor equals the item-by-item result
+    bit for bit -- mixed widths inside one class (130 / 150 / 190 columns), several classes, both dtypes."""
+    rng = np.random.default_rng(4242)
+    specs = [(9, 130, np.float64), (9, 150, np.float64), (10, 190, np.float64), (9, 130, np.float64), (9, 100, np.complex128),
+             (9, 120, np.complex128), (10, 64, np.float64), (10, 256, np.float64), (10, 256, np.float64), (9, 130, np.complex128)]
+    data = [random_mps_data(saturated_profile(L, chi), rng, dtype=dt) for L, chi, dt in specs]
+    ref = [qil.compress(qil.SignalMPS([t.copy() for t in a]), maxdim=48, tol=1e-9) for a in data]
+    for wait in ("50", "1000"):
+        monkeypatch.setenv("QIL_BATCH_COMBINE", "1")
+        monkeypatch.setenv("QIL_BATCH_COMBINE_WAIT_US", wait)
+        items = [qil.SignalMPS([t.copy() for t in a]) for a in data]
+        qil.compress_batch(items, maxdim=48, tol=1e-9)
+        for r, b in zip(ref, items):
+            assert b.bond_dims == r.bond_dims and b.amplitude == r.amplitude
+            for tr, tb in zip(r.to_host(), b.to_host()):
+                assert np.array_equal(tr, tb)
+    assert qil.default_context().unowned_bytes() == 0

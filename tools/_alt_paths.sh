@@ -35,3 +35,5 @@ run QIL_DT_BUILDER=launches QIL_ZIP_SKETCH=0
 run QIL_DT_DCAP=24
 run QIL_SVD_CERT=0
 run QIL_QR_FUSED_MAX_N=100000 QIL_SVD_LEFT_MIN=97
+run QIL_BATCH_COMBINE=1
+run QIL_BATCH_COMBINE=1 QIL_BATCH_COMBINE_WAIT_US=1000
