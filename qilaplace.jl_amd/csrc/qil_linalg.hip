@@ -2004,7 +2004,7 @@ int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, do
 // Batched form (items != nullptr, gridDim.y operands of one kernel class -- independent chains of a batch whose sweeps the
 // combiner of qil_context.hip has put into one launch): workgroup (x, y) takes its operand from items[y] and leaves when that
 // operand has fewer block pairs than the grid is wide.  The arithmetic is the single-operand kernel's, bit for bit.
-template <class T, int BB, int KM, int G, bool AP, bool PROF = false>
+template <class T, int BB, int KM, int G, bool AP, bool PROF = false, bool BATCHED = false>
 __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__ A_, long long lda_, int m_, int n_, int nb_,
                                                                  int round, double tol_, int* __restrict__ rotated_,
                                                                  const double* __restrict__ negligible_,
@@ -2016,9 +2016,11 @@ __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__
     int* __restrict__ rotated = rotated_;
     const double* __restrict__ negligible = negligible_;
     double tol = tol_;
-    if (items) {
+    if constexpr (BATCHED) {                        // its own instantiation: the single-operand code stays as it was
         const qil_round_item it = items[blockIdx.y];
         if ((int)blockIdx.x >= it.nblk / 2 || round >= it.nblk - 1) return;   // narrower operand: fewer pairs, fewer rounds
+        // (as a run-time branch of the one kernel this cost the complex single-operand path 12-16 %: its register arrays
+        // went to scratch)
         A = static_cast<T*>(it.X);
         lda = it.ldx;
         m = n = it.k;
@@ -2244,12 +2246,29 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr = true;
     }
+    if (items) {
+        static bool battr = false;
+        if (!battr) {
+            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, true, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, false, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            battr = true;
+        }
+        if (round == 0)
+            hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true, false, true>), dim3(nblk / 2, count), dim3(BB * G), lds,
+                               ctx->stream, X, ldx, k, k, nblk, round, tol, flag, negl, (long long*)nullptr, items);
+        else
+            hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, false, false, true>), dim3(nblk / 2, count), dim3(BB * G), lds,
+                               ctx->stream, X, ldx, k, k, nblk, round, tol, flag, negl, (long long*)nullptr, items);
+        return QIL_OK;
+    }
     if (round == 0)
-        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true>), dim3(nblk / 2, count), dim3(BB * G), lds, ctx->stream, X, ldx, k,
-                           k, nblk, round, tol, flag, negl, (long long*)nullptr, items);
+        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
+                           k, nblk, round, tol, flag, negl);
     else
-        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, false>), dim3(nblk / 2, count), dim3(BB * G), lds, ctx->stream, X, ldx, k,
-                           k, nblk, round, tol, flag, negl, (long long*)nullptr, items);
+        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, false>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
+                           k, nblk, round, tol, flag, negl);
     return QIL_OK;
 }
 

@@ -17,6 +17,10 @@ def run(nb, chi):
     ctx = qil.default_context()
     def sat(L, chi, base=2): return [int(min(base ** (i + 1), base ** (L - 1 - i), chi)) for i in range(L - 1)]
     def make(i): return qil.SignalMPS.alloc(sat(24, chi), dtype=np.float64).fill_random(5 + i)
+    # one chain alone first: every kernel of the chain is loaded from ONE thread (eight threads hitting the first launch of
+    # the same kernels at once crashed inside the tracer's interception layer in one run of four; never without the tracer)
+    qil.compress(make(99), maxdim=chi // 2, tol=1e-10)
+    ctx.synchronize()
     for rep in range(2):
         items = [make(i) for i in range(nb)]
         qil.compress_batch(items, maxdim=chi // 2, tol=1e-10)
