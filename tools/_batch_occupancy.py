@@ -17,8 +17,9 @@ def run(nb, chi):
     ctx = qil.default_context()
     def sat(L, chi, base=2): return [int(min(base ** (i + 1), base ** (L - 1 - i), chi)) for i in range(L - 1)]
     def make(i): return qil.SignalMPS.alloc(sat(24, chi), dtype=np.float64).fill_random(5 + i)
-    # one chain alone first: every kernel of the chain is loaded from ONE thread (eight threads hitting the first launch of
-    # the same kernels at once crashed inside the tracer's interception layer in one run of four; never without the tracer)
+    # one chain alone first (warm pool, code objects).  NOTE: under rocprofv3 this multi-threaded workload dies with a SIGSEGV
+    # inside the tracer's interception layer in roughly one run of three -- with this library and with the one from before
+    # the batched kernels alike (A/B, 6 runs each), never without the tracer (8 of 8 untraced processes) -- re-run it.
     qil.compress(make(99), maxdim=chi // 2, tol=1e-10)
     ctx.synchronize()
     for rep in range(2):
