@@ -2347,7 +2347,34 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         Qm = B;
         ldq = ldb;
         qrows = p;
-        if (second_qr) {
+        // Which triangular factor to rotate.  On a GRADED operand (singular values over several decades: the first
+        // truncating SVD of a sweep, whose site carries the whole untruncated Schmidt spectrum of its bond; products before
+        // truncation) one-sided Jacobi on the columns of R crawls -- 24-40 sweeps against 11-12 on the rows, i.e. on the
+        // columns of the lower-triangular factor of a second QR (Drmac-Veselic; numpy: 256 columns, 6 / 12 decades; measured
+        // here: the first 256-column SVD of compress! chi 256 -> 128 took 35 sweeps, the later, truncated ones 13).  On flat
+        // spectra the two orientations need the same sweeps and the second QR (~0.8 ms at 256 columns) is not worth it.  The
+        // grading shows in R's diagonal: mean |r_ii|^2 against min |r_ii|^2 (measured on the truncated sites of the same
+        // sweep, ratio ~1e5: 13 sweeps on R, 9 after the second QR).
+        bool qr2 = second_qr;
+        static const double grade = getenv("QIL_SVD_LEFT_QR2_GRADE") ? atof(getenv("QIL_SVD_LEFT_QR2_GRADE")) : 1e3;   // tuning aid; 0 = never (1e3: compress! chi 256 -> 128 85.8 -> 73.4 ms, 512 -> 256 211 -> 197 ms, complex 112 -> 104 ms, exact compress!(apply) 389 -> 348 ms; 1e5 / 1e8: 77 / 75 ms)
+        if (!qr2 && grade > 0.0) {
+            void* st = nullptr;
+            constexpr int NB = 16;
+            QIL_TRY(qil_ctx_alloc(ctx, 2 * NB * sizeof(double), &st));
+            double hb[2 * NB];
+            hipLaunchKernelGGL(tri_stats<T>, dim3(NB), dim3(256), 0, ctx->stream, (const T*)R, k, (int)k, 1, (double*)st);
+            QIL_HIP(hipMemcpyAsync(hb, st, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            qil_ctx_free(ctx, st);
+            double fro2 = 0, dmin = 1e300;
+            for (int bI = 0; bI < NB; ++bI) {
+                fro2 += hb[2 * bI];
+                dmin = std::min(dmin, hb[2 * bI + 1]);
+            }
+            qr2 = std::isfinite(fro2) && fro2 > grade * (double)k * dmin;
+            if (dbg) fprintf(stderr, "[svd-left] %lld x %lld: mean / min |r_ii|^2 = %.3g -> %s\n", p, q, fro2 / ((double)k * std::max(dmin, 1e-300)), qr2 ? "second QR" : "rotate R");
+        }
+        if (qr2) {
             // R^H = Q1 R1; the columns of X = R1^H are rotated (R = X Q1^H has the same left singular vectors)
             void* r1 = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * k) * sizeof(T), &r1));

@@ -37,3 +37,5 @@ run QIL_SVD_CERT=0
 run QIL_QR_FUSED_MAX_N=100000 QIL_SVD_LEFT_MIN=97
 run QIL_BATCH_COMBINE=1
 run QIL_BATCH_COMBINE=1 QIL_BATCH_COMBINE_WAIT_US=1000
+run QIL_SVD_LEFT_QR2_GRADE=0
+run QIL_SVD_LEFT_QR2_GRADE=1e8
