@@ -39,3 +39,4 @@ run QIL_BATCH_COMBINE=1
 run QIL_BATCH_COMBINE=1 QIL_BATCH_COMBINE_WAIT_US=1000
 run QIL_SVD_LEFT_QR2_GRADE=0
 run QIL_SVD_LEFT_QR2_GRADE=1e8
+run QIL_SVD_LEFT_QR2_GRADE_MAX=1e300
