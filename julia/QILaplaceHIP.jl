@@ -17,7 +17,7 @@ using ..Mpo: SingleSiteMPO, PairedSiteMPO
 using ..ApplyMPO: _as_single_site_mpo
 
 export DeviceMPS, DeviceMPO, to_device, to_host, signal_mps_device, marginal, mps_block, apply_compress,
-    compress_mpo!, build_dt_mpo_batch, apply_coefficient_sweep
+    compress_mpo!, build_dt_mpo_batch, apply_coefficient_sweep, apply!, rsvd_device, svd_device
 
 const LIB = get(ENV, "QILHIP_LIB", "libqilhip.so")
 
@@ -56,12 +56,16 @@ mutable struct DeviceMPS{I}
     h::Ptr{Cvoid}
     sites::Vector{I}          # for ZTMPS: interleaved main_1, copy_1, ...
     paired::Bool
+    ctx::Context              # keeps the context reachable for as long as the handle is (finalizer order is unspecified)
 end
 mutable struct DeviceMPO{I}
     h::Ptr{Cvoid}
     sites::Vector{I}
     paired::Bool
+    ctx::Context
 end
+DeviceMPS(h::Ptr{Cvoid}, sites::Vector{I}, paired::Bool) where {I} = DeviceMPS{I}(h, sites, paired, ctx())
+DeviceMPO(h::Ptr{Cvoid}, sites::Vector{I}, paired::Bool) where {I} = DeviceMPO{I}(h, sites, paired, ctx())
 _free!(x::DeviceMPS) = ccall((:qil_mps_destroy, LIB), Cint, (Ptr{Cvoid},), x.h)
 _free!(x::DeviceMPO) = ccall((:qil_mpo_destroy, LIB), Cint, (Ptr{Cvoid},), x.h)
 
@@ -80,6 +84,10 @@ end
 
 _code(::Type{<:Real}) = Cint(0)
 _code(::Type{<:Complex}) = Cint(1)
+# Index identity -> the ABI's Int64 site label: the low 63 bits of the Index hash (always non-negative; no
+# UInt64 / Int64 mixing in the arithmetic)
+_site_id(s)::Int64 = reinterpret(Int64, hash(s) & 0x7fffffffffffffff)
+_site_ids(sites) = Int64[_site_id(s) for s in sites]
 
 function to_device(psi::SignalMPS; paired::Bool=false)
     n = length(psi.data)
@@ -87,7 +95,7 @@ function to_device(psi::SignalMPS; paired::Bool=false)
     host = [Array{T}(_dense_site(psi.data[i], i == 1 ? nothing : psi.bonds[i-1], (psi.sites[i],),
                                  i == n ? nothing : psi.bonds[i])) for i in 1:n]
     bonds = Int64[dim(b) for b in psi.bonds]
-    ids = Int64.(hash.(psi.sites) .% typemax(Int64))      # Index identity -> site id
+    ids = _site_ids(psi.sites)
     ptrs = Ptr{Cvoid}[pointer(a) for a in host]
     r = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve host check(ccall((:qil_mps_create, LIB), Cint,
@@ -103,7 +111,7 @@ function to_device(W::SingleSiteMPO; paired::Bool=false)
     host = [Array{T}(_dense_site(W.data[i], i == 1 ? nothing : W.bonds[i-1], (W.sites[i]', W.sites[i]),
                                  i == n ? nothing : W.bonds[i])) for i in 1:n]   # (a, s' = in, s = out, b)
     bonds = Int64[dim(b) for b in W.bonds]
-    ids = Int64.(hash.(W.sites) .% typemax(Int64))
+    ids = _site_ids(W.sites)
     ptrs = Ptr{Cvoid}[pointer(a) for a in host]
     r = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve host check(ccall((:qil_mpo_create, LIB), Cint,
@@ -123,6 +131,11 @@ function apply(W1::DeviceMPO, W2::DeviceMPO; kwargs...)                        #
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:qil_apply_mpo_mpo, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), W1.h, W2.h, r))
     return finalizer(_free!, DeviceMPO(r[], length(W1.sites) >= length(W2.sites) ? W1.sites : W2.sites, W1.paired))
+end
+# W * psi into an existing result of the same bond profile and dtype (steady-state loops: no allocation)
+function apply!(out::DeviceMPS, W::DeviceMPO, psi::DeviceMPS)
+    check(ccall((:qil_apply_into, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), W.h, psi.h, out.h))
+    return out
 end
 *(W::DeviceMPO, psi::DeviceMPS) = apply(W, psi)                                # apply.jl:233-236
 *(W1::DeviceMPO, W2::DeviceMPO) = apply(W1, W2)
@@ -288,6 +301,93 @@ function to_host(psi::DeviceMPS)
     return psi.paired ? _writeback_signal_2n(sig) : sig                     # mps.jl:447-472
 end
 
+# to_host(::DeviceMPO): the tensors come back as W[a, s', s, b] (s' = primed = input leg); fresh bond Indices, shared
+# site Indices -- the reference's constructors re-validate the result (check_singlesitempo / check_pairedsitempo,
+# src/mpo.jl:30-43, 62-73).  A paired chain is returned as PairedSiteMPO (mpo.jl:62-73; the inverse of
+# _as_single_site_mpo, apply.jl:16-32): even chain positions are main sites, odd ones copy sites.
+function to_host(W::DeviceMPO)
+    n = length(W.sites)
+    dims = Vector{Int64}(undef, max(n - 1, 0))
+    check(ccall((:qil_mpo_bond_dims, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), W.h, dims))
+    d = Ref{Cint}(0)
+    check(ccall((:qil_mpo_dtype, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), W.h, d))
+    T = d[] == 1 ? ComplexF64 : Float64
+    bonds = [Index(Int(dims[i]); tags="bond-$i") for i in 1:(n - 1)]
+    data = Vector{ITensor}(undef, n)
+    for i in 1:n
+        dl = i == 1 ? 1 : Int(dims[i - 1])
+        dr = i == n ? 1 : Int(dims[i])
+        A = Array{T}(undef, dl, 2, 2, dr)
+        check(ccall((:qil_mpo_download_site, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}), W.h, i - 1, A))
+        s = W.sites[i]
+        if n == 1
+            data[i] = ITensor(A[1, :, :, 1], s', s)
+        elseif i == 1
+            data[i] = ITensor(A[1, :, :, :], s', s, bonds[i])
+        elseif i == n
+            data[i] = ITensor(A[:, :, :, 1], bonds[i - 1], s', s)
+        else
+            data[i] = ITensor(A, bonds[i - 1], s', s, bonds[i])
+        end
+    end
+    W.paired || return SingleSiteMPO(data, W.sites, bonds)                   # mpo.jl:30-43
+    return PairedSiteMPO(data, W.sites[1:2:end], W.sites[2:2:end], bonds[2:2:end], bonds[1:2:end])   # mpo.jl:62-73
+end
+
+# ---------------------------------------------------------------- rsvd / svd on a matricised ITensor (E3)
+# rsvd(A, Linds...; k, p, q, random_seed, cutoff, maxdim, mindim) (src/linalg/rsvd.jl:38-121) with the matrix work on
+# the device: A is matricised over (Linds | rest) exactly as the reference does with its combiners (:62-68), the
+# factors come back as ITensors U (Linds..., u), S (u, v) diagonal, V (rest..., v) -- the reference's return triple.
+function _matricise(A::ITensor, Linds)
+    Lis = commoninds(A, IndexSet(Linds...))
+    Ris = uniqueinds(A, Lis)
+    (length(Lis) == 0 || length(Ris) == 0) &&
+        error("In `rsvd`, left or right index set is empty. Left inds: $(Lis), right inds: $(Ris).")   # rsvd.jl:56-60
+    T = eltype(A) <: Complex ? ComplexF64 : Float64
+    M = Array{T}(reshape(Array(A, Lis..., Ris...), prod(dim.(Lis)), prod(dim.(Ris))))
+    return M, Lis, Ris, T
+end
+function _factors_to_itensors(U, S, Vh, r, Lis, Ris, bondtag)
+    u = Index(r; tags=bondtag)
+    v = Index(r; tags=bondtag)
+    Ut = ITensor(reshape(U[:, 1:r], dim.(Lis)..., r), Lis..., u)
+    St = diag_itensor(S[1:r], u, v)
+    Vt = ITensor(reshape(permutedims(conj.(Vh[1:r, :])), dim.(Ris)..., r), Ris..., v)   # A = U S V^H, V as in ITensors.svd
+    return Ut, St, Vt
+end
+function rsvd_device(A::ITensor, Linds...; k::Int=20, p::Int=10, q::Int=0, random_seed::Int=1234,
+                     bondtag="Link,rsvd", cutoff::Float64=1e-15, maxdim::Int=k, mindim::Int=1)
+    M, Lis, Ris, T = _matricise(A, Linds)
+    m, n = size(M)
+    l = min(k + p, m, n)                                                       # rsvd.jl:71
+    U = Matrix{T}(undef, m, l); S = Vector{Float64}(undef, l); Vh = Matrix{T}(undef, l, n)
+    r = Ref{Int64}(0)
+    check(ccall((:qil_rsvd, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Int64, Int64, Cint, UInt64, Cdouble, Int64, Int64, Ref{Int64},
+         Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cvoid}),
+        ctx().h, M, m, n, _code(T), k, p, q, random_seed, cutoff, maxdim, mindim, r, U, S, Vh))
+    # the C side packs the factors for the kept rank: U m x r, Vh r x n
+    rr = Int(r[])
+    return _factors_to_itensors(reshape(view(vec(U), 1:(m * rr)), m, rr), S, reshape(view(vec(Vh), 1:(rr * n)), rr, n), rr,
+                                Lis, Ris, bondtag)
+end
+# svd(A, Linds...; cutoff, maxdim, mindim) with the ITensors truncation rule (the call sites mps.jl:929,946;
+# SignalConverters.jl:84,266) on the device
+function svd_device(A::ITensor, Linds...; cutoff::Float64=0.0, maxdim::Int=typemax(Int), mindim::Int=1,
+                    bondtag="Link,svd")
+    M, Lis, Ris, T = _matricise(A, Linds)
+    m, n = size(M)
+    l = min(m, n)
+    U = Matrix{T}(undef, m, l); S = Vector{Float64}(undef, l); Vh = Matrix{T}(undef, l, n)
+    r = Ref{Int64}(0)
+    check(ccall((:qil_svd_trunc, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Cdouble, Int64, Int64, Ref{Int64}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cvoid}),
+        ctx().h, M, m, n, _code(T), cutoff, maxdim, mindim, r, U, S, Vh))
+    rr = Int(r[])
+    return _factors_to_itensors(reshape(view(vec(U), 1:(m * rr)), m, rr), S, reshape(view(vec(Vh), 1:(rr * n)), rr, n), rr,
+                                Lis, Ris, bondtag)
+end
+
 # ---------------------------------------------------------------- beyond the reference's surface (SURVEY 8f)
 # compress!(apply(W, psi); maxdim, tol, sweeps) without materialising the (D chi)^2 product
 function apply_compress(W::DeviceMPO, psi::DeviceMPS; maxdim::Int=typemax(Int), tol::Float64=1e-12,
@@ -350,10 +450,9 @@ function build_dt_mpo_batch(psi::DeviceMPS, wrs::AbstractVector{<:Real}; cutoff:
     n = length(psi.sites) ÷ 2
     w = Vector{Float64}(wrs)
     hs = Vector{Ptr{Cvoid}}(undef, length(w))
-    _site_labels(p) = Int64.(hash.(p.sites) .% typemax(Int64))          # same labels as to_device
     check(ccall((:qil_build_dt_mpo_batch, LIB), Cint,
                 (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Cdouble, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
-                ctx().h, n, length(w), w, cutoff, maxdim, _site_labels(psi), hs))
+                ctx().h, n, length(w), w, cutoff, maxdim, _site_ids(psi.sites), hs))
     return [finalizer(_free!, DeviceMPO(h, copy(psi.sites), true)) for h in hs]
 end
 
