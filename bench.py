@@ -181,7 +181,15 @@ def svd_flops(m, n):
     return 6.0 * m * n * n + 20.0 * n ** 3
 
 
-def truncate_block(qil, ctx, reps=3):
+def _host_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] or [1]))
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def truncate_block(qil, ctx, reps=3, cpu=True):
     """The 'truncate' of apply-and-truncate on the pipeline's own operands (cfg4-shaped): n=24 structured signal
     encoded to chi ~15, genuine zT MPO (D ~89), product bond ~1335, truncated to maxdim 64 at tol 1e-8."""
     n, N = 24, 2 ** 24
@@ -203,6 +211,7 @@ def truncate_block(qil, ctx, reps=3):
     prod = W * psi
     ctx.synchronize()
     t_apply = time.perf_counter() - t0
+    prod_host = (prod.to_host(), prod.amplitude) if cpu else None       # the SAME product for the CPU baseline below
     t0 = time.perf_counter()
     qil.compress(prod, maxdim=maxdim, tol=tol)
     ctx.synchronize()
@@ -215,8 +224,11 @@ def truncate_block(qil, ctx, reps=3):
         return [qil.SignalMPS.alloc(sat(24, 256), dtype=np.float64).fill_random(5 + i) for i in range(k)]
 
     t_one = t_eight = None
+    one_host = None
     for _ in range(2):                                                   # first round warms the pool and the worker streams
         one, eight = chains(1)[0], chains(8)
+        if cpu and one_host is None:
+            one_host = one.to_host()
         ctx.synchronize()
         t0 = time.perf_counter()
         qil.compress(one, maxdim=128, tol=1e-10)
@@ -232,6 +244,33 @@ def truncate_block(qil, ctx, reps=3):
     c_x = qil.apply_coefficient_batch(W, psi, bits)
     scale = np.abs(c_x).max()
     P = [1] + [c * d for c, d in zip(psi.bond_dims, W.bond_dims)] + [1]
+    cpu_res = None
+    if cpu:
+        # the reference-shaped CPU path beside every reported figure -- the numpy / LAPACK restatement of
+        # compress! (oracle.compress = src/mps.jl:913-973: canonicalize!, two-site SVD sweeps, canonicalize!) on the SAME
+        # downloaded tensors, timed on this box's host cores
+        import oracle as O
+        ph = O.SignalMPS(prod_host[0], amplitude=prod_host[1])
+        t0 = time.perf_counter()
+        O.compress(ph, maxdim=maxdim, tol=tol)
+        t_cpu_exact = time.perf_counter() - t0
+        c_cpu = O.coefficient_batch(ph, bits)
+        oh = O.SignalMPS(one_host, amplitude=1.0)
+        t0 = time.perf_counter()
+        O.compress(oh, maxdim=128, tol=1e-10)
+        t_cpu_one = time.perf_counter() - t0
+        cpu_res = {
+            "kind": "port", "cores": _host_threads(), "nproc": os.cpu_count(),
+            "sample": "oracle.compress (numpy + LAPACK gesdd restatement of compress!, src/mps.jl:913-973) on the same downloaded "
+                      "tensors: the whole bond-%d product (48 sites) and the whole chi 256 -> 128 chain (24 sites), one run each"
+                      % max(P),
+            "exact_compress_ms": t_cpu_exact * 1e3, "compress_chi256_to_128_24_sites_ms": t_cpu_one * 1e3,
+            "value": 2 * n / t_cpu_exact, "unit": "site-truncations/s",
+            "gpu_over_cpu_exact_compress": t_cpu_exact / t_exact, "gpu_over_cpu_chi256": t_cpu_one / t_one,
+            "bonds_exact_max": int(max(ph.bond_dims)),
+            "err_cpu_route_vs_exact_product": float(np.abs(c_cpu - c_x).max() / scale),
+            "hip_vs_cpu_truncated_state": float(np.abs(c_e - c_cpu).max() / scale),
+        }
     # flop models (stated, not measured): exact route = one gauge pass of truncated SVDs over the product sites
     # (P_l x 2 P_r, the later passes run at <= maxdim); fused route = the zip-up's theta SVDs (2 r x D chi) with
     # r <= 2 maxdim plus its contraction GEMMs
@@ -249,6 +288,7 @@ def truncate_block(qil, ctx, reps=3):
         "err_exact_route_vs_exact_product": float(np.abs(c_e - c_x).max() / scale),
         "compress_chi256_to_128_24_sites_ms": t_one * 1e3, "compress_batch_of_8_ms": t_eight * 1e3,
         "batch_of_8_over_single": t_eight / t_one,
+        "cpu_baseline": cpu_res,
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS,
                      "achieved": f_exact / t_exact / 1e12, "frac": f_exact / t_exact / 1e12 / F64_MFMA_PEAK_TFLOPS,
                      "achieved_fused": f_fused / t_fused / 1e12,
@@ -439,7 +479,7 @@ def run_apply(args, rk):
     if world == 1 and not args.no_truncate:
         del W, psi
         ctx.trim()
-        res["truncate"] = truncate_block(qil, ctx)
+        res["truncate"] = truncate_block(qil, ctx, cpu=not args.no_cpu_baseline)
         psi = mps_cls.alloc(cb, dtype=np.float64, amplitude=1.0, ctx=ctx).fill_random(20240064 + rank)
         W = (mpo_cls(embed_and_gauge(w_natural, db, np.random.default_rng(20240128)), ctx=ctx) if genuine
              else mpo_cls.alloc(db, dtype=np.complex128, ctx=ctx).fill_random(777))
@@ -491,6 +531,44 @@ def run_sweep(args, rk):
     ab = sum(algorithmic_bytes(psi.bond_dims, W.bond_dims, w_bytes=8, a_bytes=8, o_bytes=8) for W in Ws) / 2.0
     k_ms = kernel_ms / max(n_launch, 1)
     achieved = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # what bounds the step: the per-value builder chain (one launch of dt_build_persistent per sweep), timed here with
+    # host clocks around a synchronised build of this rank's share (the kernel is >= 99 % of it, profiles/r03_kernel_stats_dt_sweep*)
+    share = [sig[i] for i in range(rk.rank, nsig, rk.world)]
+    tb = []
+    for _ in range(3):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        Wb = qil.build_dt_mpo_batch(psi, share)
+        ctx.synchronize()
+        tb.append(time.perf_counter() - t0)
+        del Wb
+    t_build = min(tb)
+    cpu = None
+    if rk.world == 1 and not args.no_cpu_baseline:
+        # the reference-shaped CPU path beside the figure -- build_dt_mpo (numpy restatement of
+        # dt_transformer.jl:312-412) + apply + the same 1024 samples for a bounded subset of the damping values, scaled to 64
+        import oracle as O
+        sub = [0, nsig // 3, 2 * nsig // 3, nsig - 1]
+        ph = O.SignalMPS(psi.to_host(), amplitude=psi.amplitude)
+        t_b = t_a = 0.0
+        worst = 0.0
+        for r in sub:
+            t0 = time.perf_counter()
+            Wc = O.build_dt_mpo(n, float(sig[r]))
+            t_b += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            Wchain = Wc.as_single_site_mpo() if hasattr(Wc, "as_single_site_mpo") else Wc
+            c = O.coefficient_batch(O.apply(Wchain, ph), bits)
+            t_a += time.perf_counter() - t0
+            worst = max(worst, float(np.abs(c - res[r]).max() / peak))
+        t_cpu = (t_b + t_a) / len(sub) * nsig
+        cpu = {"value": nsig * 2 * n / t_cpu, "unit": "site-contractions/s", "cores": _host_threads(), "nproc": os.cpu_count(),
+               "kind": "port",
+               "sample": f"oracle.build_dt_mpo (numpy restatement of dt_transformer.jl:312-412) + oracle.apply + {nsamp} "
+                         f"coefficients for {len(sub)} of the {nsig} damping values (indices {sub}), scaled to {nsig}: "
+                         f"build {t_b / len(sub):.2f} s, apply + sample {t_a / len(sub):.3f} s per value",
+               "seconds_per_sweep_scaled": t_cpu, "build_seconds_per_value": t_b / len(sub),
+               "hip_vs_cpu_max_err_rel_to_signal_peak": worst}
     emit({
         "metric": "MPO×MPS site-contractions/sec + max |coeff err|, n=24 damping sweep (configs[3])",
         "value": nsig * 2 * n / (elapsed / args.steps), "unit": "site-contractions/s",
@@ -500,13 +578,23 @@ def run_sweep(args, rk):
                    "damping_values": nsig, "samples_per_value": nsamp, "mps_bonds_max": max(psi.bond_dims),
                    "mpo_bonds_max": max(max(W.bond_dims) for W in Ws),
                    "parallelism": f"64 damping values round-robin over {rk.world} rank(s), one all_gather",
+                   "ranks_reported_by_collective_backend": rk.world,
+                   "values_per_rank": [len(range(r, nsig, rk.world)) for r in range(rk.world)],
                    "lib_sha16": lib_sha16()},
         "max_coeff_err": err, "coeff_err": {"vs_closed_form_rel_to_signal_peak": err, "queries": nsig * nsamp},
+        # The step is NOT bandwidth- or matrix-bound: it is the latency of one damping value's chain of ~3 300 dependent
+        # in-LDS factorisations inside dt_build_persistent.  `roofline` keeps the contract's shape for the
+        # sweep's apply launches (HBM-bound, tiny); `bound_by` says what the step really waits for.
+        "bound_by": {"kernel": "dt_build_persistent (one launch per sweep, one workgroup per damping value)",
+                     "ms": t_build * 1e3, "frac_of_step": t_build / (elapsed / args.steps),
+                     "kind": "latency chain: zip QR + gauge QR + truncating Jacobi SVD per site and layer, all in LDS",
+                     "workgroups": len(share), "cu_share": len(share) / 256.0},
         "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<double,double> (the sweep's apply launches; the step is "
-                     "dominated by the latency-bound dt_build_persistent chain, see DESIGN.md 3.6)",
+                     "dominated by the latency-bound dt_build_persistent chain, see bound_by and DESIGN.md 3.6)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel_ms": k_ms, "launches_timed": n_launch,
                      "algorithmic_bytes_per_launch": ab},
+        "cpu_baseline": cpu,
     })
 
 
@@ -516,7 +604,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default: 1000 applies (12 s timed) / 40 sweeps (9 s)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="zt_n24_chi64_D128", choices=sorted(WORKLOADS))
-    ap.add_argument("--queries", type=int, default=64, help="coefficient samples for max|coeff err|")
+    ap.add_argument("--queries", type=int, default=4096, help="coefficient samples for max|coeff err| (BASELINE.md 3.6: >= 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-truncate", action="store_true")
     ap.add_argument("--random-mpo", action="store_true", help="seeded random MPO instead of the embedded genuine zT MPO")

@@ -99,18 +99,20 @@ def lazy_coefficient_batch(W, psi, bits):
     M = np.ones((nb, 1, 1), dtype=dt)                          # M[q, a, alpha]
     for i in range(N):
         Wi, Ai = Wd[i], chain.data[i]
-        nM = np.empty((nb, Wi.shape[3], Ai.shape[2]), dtype=dt)
+        D, D2, c, c2 = Wi.shape[0], Wi.shape[3], Ai.shape[0], Ai.shape[2]
+        nM = np.empty((nb, D2, c2), dtype=dt)
+        A2 = np.ascontiguousarray(Ai).reshape(c, 2 * c2).astype(dt, copy=False)          # [alpha, (sp, beta)]
         for b in (0, 1):
             sel = bits[:, i] == b
-            if not sel.any():
+            ns = int(sel.sum())
+            if ns == 0:
                 continue
-            Ms = M[sel]
-            acc = 0
-            for sp in (0, 1):
-                # sum_{a,alpha} W[a,sp,b,a'] M[a,alpha] A[alpha,sp,beta]  (two batched GEMMs)
-                t = np.matmul(np.ascontiguousarray(Wi[:, sp, b, :].T)[None], Ms)
-                acc = acc + np.matmul(t, np.ascontiguousarray(Ai[:, sp, :])[None])
-            nM[sel] = acc
+            # sum_{a,sp,alpha} W[a,sp,b,a'] M[q,a,alpha] A[alpha,sp,beta] as two LARGE GEMMs over all selected queries
+            # (a loop of per-query products is the same arithmetic one query at a time)
+            X = (M[sel].reshape(ns * D, c) @ A2).reshape(ns, D * 2, c2)                   # [q, (a, sp), beta]
+            Wb = np.ascontiguousarray(Wi[:, :, b, :]).reshape(D * 2, D2)                  # [(a, sp), a']
+            Y = Wb.T @ np.ascontiguousarray(X.transpose(1, 0, 2)).reshape(D * 2, ns * c2)   # [a', (q, beta)]
+            nM[sel] = Y.reshape(D2, ns, c2).transpose(1, 0, 2)
         M = nM
     return chain.amplitude * M[:, 0, 0]
 

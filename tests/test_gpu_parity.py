@@ -477,8 +477,9 @@ def test_config4_damping_sweep_full_size(qil):
     peak = np.abs(x).max() / np.sqrt(N)
     for r, s in enumerate(sig):
         ref = x[jj] * np.exp(-s * kk * jj / N) / np.sqrt(N)
-        # encode (rsvd k=15, cutoff 1e-12) + MPO cutoff 1e-14: 1e-6 of the signal peak
-        assert np.abs(got[r] - ref).max() < 1e-6 * peak, (r, s, np.abs(got[r] - ref).max() / peak)
+        # encode (rsvd k=15, cutoff 1e-12) + MPO cutoff 1e-14: measured 6.4e-11 of the signal peak (profiles/r02_bench_sweep.json);
+        # the reference's own DT bound is 1e-7 * max(1, |.|) (test/test_dt_transformer.jl:234)
+        assert np.abs(got[r] - ref).max() < 1e-8 * peak, (r, s, np.abs(got[r] - ref).max() / peak)
 
 
 # ---------------------------------------------------------------- f64-MFMA GEMM (fragment layout check)
@@ -618,11 +619,12 @@ def test_config3_natural_bond_signal_vs_analytical_zt(qil):
     kk, ll = rng.integers(0, 64, size=256), rng.integers(0, 32, size=256)
     got = qil.coefficient_batch(out, _kl_bits(n, kk, ll))
     ref = _zt_closed_form(_structured_terms(), n, 2 * np.pi, kk, ll)
-    assert np.abs(got - ref).max() < 2e-6 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    # the reference's zT bound: 2e-7 ABSOLUTE (test/test_zt_transformer.jl:106)
+    assert np.abs(got - ref).max() < 2e-7, (np.abs(got - ref).max(), np.abs(ref).max())
     grid = qil.coefficient_grid(out, np.arange(8), np.arange(16))
     gk, gl = np.meshgrid(np.arange(8), np.arange(16), indexing="ij")
     gref = _zt_closed_form(_structured_terms(), n, 2 * np.pi, gk.ravel(), gl.ravel()).reshape(8, 16)
-    assert np.abs(grid - gref).max() < 2e-6 * np.abs(gref).max()
+    assert np.abs(grid - gref).max() < 2e-7, (np.abs(grid - gref).max(), np.abs(gref).max())
 
 
 def test_config5_n30_rsvd_encode_and_zt_apply(qil):
@@ -655,6 +657,88 @@ def test_config5_n30_rsvd_encode_and_zt_apply(qil):
     assert out.bond_dims == [c * d for c, d in zip(psi.bond_dims, W.bond_dims)]
     mat = qil.coefficient_batch(out, bits)
     assert np.abs(mat - lazy).max() < 1e-12 * np.abs(mat).max()
+
+
+def _zt_closed_form_integer_modes(modes, n, wr, kk, ll):
+    """chi(k, l) = (1/N) sum_j x_j exp(-(wr k + 2 pi i l) j / N) (test/test_zt_transformer.jl:20-39) for
+    x_j = sum_m a_m exp(-g_m j / N) cos(2 pi f_m j / N + phi_m) with INTEGER frequencies f_m: each half of a cosine is a
+    geometric series with ratio exp(a / N) exp(2 pi i g / N), a = -g_m - wr k real, g = +-f_m - l an integer, so
+    exp(a + 2 pi i g) = exp(a) exactly and the phase of the ratio is reduced in integer arithmetic (a frequency near N / 2
+    times an index near N would otherwise cost 1e-7 in the argument of the cosine)."""
+    N = 1 << n
+    kk, ll = np.asarray(kk, dtype=np.int64), np.asarray(ll, dtype=np.int64)
+    out = np.zeros(len(kk), dtype=np.complex128)
+    for a_m, g_m, f_m, phi_m in modes:
+        for sign in (1, -1):
+            c = 0.5 * a_m * np.exp(1j * sign * phi_m)
+            a = -g_m - wr * kk.astype(np.float64)
+            g = np.mod(sign * int(f_m) - ll, N)                                  # integer, exact
+            th = 2.0 * np.pi * g.astype(np.float64) / N
+            # ratio - 1 = e^{a/N} (cos th + i sin th) - 1, without cancellation for small a / N and th
+            den = (np.expm1(a / N) * np.cos(th) - 2.0 * np.sin(0.5 * th) ** 2) + 1j * np.exp(a / N) * np.sin(th)
+            num = np.expm1(a)
+            out += c * np.where(den == 0, float(N), num / np.where(den == 0, 1.0, den))
+    return out / N
+
+
+def test_config5_n30_chi128_rank128_signal(qil):
+    """configs[4] at its NOMINAL chi_s = 128: a 2^30-sample signal generated in HBM whose matricisations have rank 128 --
+    64 damped cosines with seeded integer frequencies over the whole band, so every cut with both sides >= 128 has rank
+    exactly 128 and a closed form exists -- signal_ztmps(:rsvd, k=128, p=5, q=2, maxdim=128)
+    (src/signals/SignalConverters.jl:107-196, 247-283), the zT MPO at its natural bonds, then
+      (i)   the lazy read-out of chi(k, l) against O.lazy_coefficient_batch on the DOWNLOADED tensors (<= 1e-9) and against
+            the closed form (the reference's zT bound, 2e-7 absolute),
+      (ii)  the materialised apply (bond 128 x ~82: tens of GB, HBM-resident) against the lazy path (<= 1e-12),
+      (iii) sampled reconstruction of the encoded signal (the encoder is exact at rank 128 <= k + p)."""
+    torch = pytest.importorskip("torch")
+    n = 30
+    N = 2 ** n
+    dev = torch.device("cuda", qil.default_context().device)
+    rng = np.random.default_rng(20240530)
+    nm = 64
+    modes = [(float(rng.uniform(0.5, 1.0)), float(rng.uniform(0.0, 4.0)), int(rng.integers(1, N // 2)),
+              float(rng.uniform(0.0, 2 * np.pi))) for _ in range(nm)]
+    jd = torch.arange(N, dtype=torch.int64, device=dev)
+    jf = jd.to(torch.float64) / N
+    xd = torch.zeros(N, dtype=torch.float64, device=dev)
+    for a_m, g_m, f_m, phi_m in modes:
+        ph = torch.remainder(jd * f_m, N).to(torch.float64) * (2.0 * np.pi / N)   # exact integer phase reduction
+        xd += a_m * torch.exp(-g_m * jf) * torch.cos(ph + phi_m)
+        del ph
+    del jd, jf
+    torch.cuda.synchronize()
+    js = rng.integers(0, N, size=256)
+    xs = xd[torch.as_tensor(js, device=dev)].cpu().numpy()
+    xnorm = float(torch.linalg.vector_norm(xd).item())
+    psi = qil.signal_ztmps(xd, method="rsvd", k=128, p=5, q=2, cutoff=1e-14, maxdim=128)
+    del xd
+    torch.cuda.empty_cache()
+    bd = psi.bond_dims
+    assert isinstance(psi, qil.ZTMPS) and len(psi) == n
+    assert max(bd) == 128 and sum(1 for b in bd if b == 128) >= 30, bd        # chi_s = 128 materialises on the bulk bonds
+    # (iii) the encoded signal at 256 sampled indices (main and copy register carry the same index, site 1 = MSB)
+    jb = np.array([interleave(int_to_bits(int(j), n), int_to_bits(int(j), n)) for j in js], dtype=np.uint8)
+    rec = qil.coefficient_batch(psi, jb)
+    rerr = np.abs(rec - xs).max() / np.abs(xs).max()
+    assert rerr < 1e-8, rerr
+    assert abs(psi.amplitude - xnorm) < 1e-9 * xnorm
+    W = qil.build_zt_mpo_batch(psi, [2 * np.pi], cutoff=1e-14)[0]
+    kk, ll = rng.integers(0, 64, size=64), rng.integers(0, 1 << 20, size=64)
+    kk[:32] = rng.integers(0, 4, size=32)                                    # ... half of them on resonance: l = a mode's frequency
+    ll[:32] = [modes[int(i)][2] for i in rng.integers(0, nm, size=32)]
+    bits = _kl_bits(n, kk, ll)
+    lazy = qil.apply_coefficient_batch(W, psi, bits)
+    # (i) same tensors on the CPU: the oracle's lazy restatement
+    ref = O.lazy_coefficient_batch(O.SingleSiteMPO(W.to_host()), O.SignalMPS(psi.to_host(), amplitude=psi.amplitude), bits)
+    assert rel(lazy, ref) < 1e-9, rel(lazy, ref)
+    cf = _zt_closed_form_integer_modes(modes, n, 2 * np.pi, kk, ll)
+    assert np.abs(lazy - cf).max() < 2e-7, np.abs(lazy - cf).max()           # test/test_zt_transformer.jl:106
+    # (ii) the materialised product
+    out = W * psi
+    assert out.bond_dims == [c * d for c, d in zip(psi.bond_dims, W.bond_dims)] and max(out.bond_dims) >= 128 * 64
+    mat = qil.coefficient_batch(out, bits)
+    assert np.abs(mat - lazy).max() < 1e-12 * np.abs(mat).max(), np.abs(mat - lazy).max() / np.abs(mat).max()
+    del out
 
 
 def test_config3_n24_chi64_D128_full_size_vs_cpu_oracle(qil):
