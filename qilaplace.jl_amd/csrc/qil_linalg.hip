@@ -2272,6 +2272,363 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
     return QIL_OK;
 }
 
+// ------------------------------------------------------------------ Gram-matrix block round on the matrix cores
+// One outer round of the same block tournament, but a block pair is orthogonalised through its Gram matrix instead of column by
+// column (the rotation work of the truncate half on v_mfma_f64_16x16x4_f64):
+//   1. the W = 2 BB columns of the pair are staged in LDS (rows padded to a multiple of 16, zero filled);
+//   2. G = P^H P (W x W) on the matrix cores: 16 x 16 tiles, the K range (the rows) split over the 8 waves, partial tiles
+//      summed in a fixed order (deterministic);
+//   3. a sweep of TWO-SIDED rotations on G in LDS -- the BB cross pairs per inner round (AP: all pairs of the 2 BB columns,
+//      2 BB - 1 inner rounds: the first outer round of a sweep, which also covers the pairs inside a block) -- with one
+//      thread per 2 x 2 block (k1, k2) of G: it takes the rotations of pairs k1 and k2 from the current diagonal 2 x 2 blocks
+//      itself (no dot products, no reductions, no exchange of rotation parameters) and writes R1^H B R2 into the other
+//      buffer of G: ONE barrier per inner round; the other four waves accumulate J <- J R;
+//   4. P <- P J on the matrix cores (issued as (J^T tile)(P^T tile) so that every 16 lanes store 128 / 256 contiguous bytes),
+//      straight to global memory.
+// Convergence flags come from the FRESH Gram matrix (relative to the columns' own norms): flag[0] = some pair above tol,
+// flag[1] = some pair above the quadratic-phase level.  prev != nullptr: the flags of the PREVIOUS sweep; when that sweep met
+// nothing above the quadratic level the iteration had converged and this launch (issued speculatively by a host that is one
+// sweep ahead of its read-backs) does nothing.
+template <class T>
+struct gram_round_args {
+    T* A;
+    long long lda;
+    int m, n, nb, round;
+    double tol;
+    int* flag;
+    const int* prev;
+    const double* negligible;
+};
+
+template <class T, int BB>
+constexpr size_t gram_round_lds(int m) {
+    constexpr int W = 2 * BB, LDG = W + 1, NC = sizeof(T) == 16 ? 2 : 1;
+    const int mpad = (m + 15) & ~15;
+    return (size_t)W * (mpad + 2) * sizeof(T)             // the column pair
+           + (size_t)2 * NC * W * LDG * sizeof(double)    // G, two buffers, re / im planes
+           + (size_t)NC * W * W * sizeof(double)          // J
+           + (size_t)8 * NC * 256 * sizeof(double)        // partial Gram tiles of the 8 waves
+           + 64;
+}
+
+template <class T, int BB, bool AP>
+__device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& a, const unsigned bx) {
+    constexpr bool CX = sizeof(T) == 16;
+    constexpr int NC = CX ? 2 : 1;
+    constexpr int W = 2 * BB, LDG = W + 1;
+    constexpr int NTL = W / 16, NT2 = NTL * NTL, KSP = 8 / NT2;      // 16 x 16 tiles of G; waves per tile (K split)
+    static_assert(W == 16 || W == 32, "2 x 8 or 2 x 16 columns");
+    if (a.prev && !a.prev[1]) return;
+    const int m = a.m, n = a.n, nb = a.nb, round = a.round;
+    const int mpad = (m + 15) & ~15, LDR = mpad + 2;
+    extern __shared__ __attribute__((aligned(16))) char gr_smem[];
+    T* Xs = reinterpret_cast<T*>(gr_smem);                           // [W][LDR]
+    double* Gb = reinterpret_cast<double*>(Xs + (size_t)W * LDR);    // [2][NC][W * LDG]
+    double* Jm = Gb + 2 * NC * W * LDG;                              // [NC][W * W], J[c][j] at c * W + j
+    double* Pp = Jm + NC * W * W;                                    // [8][NC][256]
+    int* sflag = reinterpret_cast<int*>(Pp + 8 * NC * 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int P, Q;
+    {
+        const int i = (int)bx;
+        if (i == 0) {
+            P = nb - 1;
+            Q = round;
+        } else {
+            P = (round + i) % (nb - 1);
+            Q = (round + nb - 1 - i) % (nb - 1);
+        }
+        if (nb == 2) {
+            P = 0;
+            Q = 1;
+        }
+        if (P > Q) {
+            const int t = P;
+            P = Q;
+            Q = t;
+        }
+    }
+    if (P * BB >= n) return;                                         // both blocks are padding
+    auto gcol = [&](int k) { return (k < BB ? P * BB + k : Q * BB + (k - BB)); };
+    if (tid == 0) *sflag = 0;
+    // ---- 1. staging (all loads of a column in flight; rows / columns beyond the matrix: clamped address, value times 0)
+    for (int c = wave; c < W; c += 8) {
+        const int gc = gcol(c);
+        const bool cv = gc < n;
+        const T* s0 = a.A + a.lda * (cv ? gc : 0);
+        T* d0 = Xs + (size_t)LDR * c;
+        for (int r0 = 0; r0 < mpad; r0 += 256) {
+            T t0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + lane + 64 * u;
+                t0[u] = scale_t(s0[r < m ? r : 0], (cv && r < m) ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + lane + 64 * u;
+                if (r < mpad) d0[r] = t0[u];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. G = X^H X: wave -> (tile, K slice)
+    {
+        const int tile = wave / KSP, ks0 = wave % KSP;
+        const int ti = tile / NTL, tj = tile % NTL;
+        const int li = lane & 15, lk = lane >> 4;
+        d4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0};
+        const T* xa = Xs + (size_t)LDR * (16 * ti + li) + lk;
+        const T* xb = Xs + (size_t)LDR * (16 * tj + li) + lk;
+        const int nks = mpad / 4;
+        for (int ks = ks0; ks < nks; ks += KSP) {
+            const T av = xa[4 * ks], bv = xb[4 * ks];
+            if constexpr (CX) {
+                // G = (ar - i ai)^T (br + i bi):  re = ar br + ai bi,  im = ar bi - ai br
+                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.re, rr, 0, 0, 0);
+                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.im, rr, 0, 0, 0);
+                ri = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.im, ri, 0, 0, 0);
+                ii = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.re, ii, 0, 0, 0);
+            } else {
+                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, rr, 0, 0, 0);
+            }
+        }
+        double* pw = Pp + (size_t)wave * NC * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pw[(lk + 4 * r) * 16 + li] = rr[r];                      // row i = lk + 4 r, col j = li of the tile
+            if constexpr (CX) pw[256 + (lk + 4 * r) * 16 + li] = ri[r] - ii[r];
+        }
+    }
+    __syncthreads();
+    double* G0 = Gb;
+    for (int t = tid; t < NT2 * 256; t += 512) {
+        const int tile = t >> 8, e = t & 255, i = e >> 4, j = e & 15;
+        const int ti = tile / NTL, tj = tile % NTL;
+        double vr = 0, vi = 0;
+#pragma unroll
+        for (int k = 0; k < KSP; ++k) {
+            vr += Pp[(size_t)(tile * KSP + k) * NC * 256 + e];
+            if constexpr (CX) vi += Pp[(size_t)(tile * KSP + k) * NC * 256 + 256 + e];
+        }
+        G0[(16 * ti + i) * LDG + 16 * tj + j] = vr;
+        if constexpr (CX) G0[W * LDG + (16 * ti + i) * LDG + 16 * tj + j] = vi;
+    }
+    for (int t = tid; t < W * W; t += 512) {
+        Jm[t] = (t / W == t % W) ? 1.0 : 0.0;
+        if constexpr (CX) Jm[W * W + t] = 0.0;
+    }
+    __syncthreads();
+    const double ng = a.negligible ? *a.negligible : 0.0;
+    // ---- convergence flags from the fresh Gram matrix (this visit's pairs)
+    {
+        int fl = 0;
+        for (int t = tid; t < W * W; t += 512) {
+            const int r = t % W, c = t / W;
+            const bool mine = AP ? (r < c) : (r < BB && c >= BB);
+            if (!mine) continue;
+            const double al = G0[r * LDG + r], be = G0[c * LDG + c];
+            if (al < ng || be < ng) continue;
+            double g2 = G0[r * LDG + c] * G0[r * LDG + c];
+            if constexpr (CX) g2 = fma(G0[W * LDG + r * LDG + c], G0[W * LDG + r * LDG + c], g2);
+            const double ab = al * be;
+            if (g2 > a.tol * a.tol * ab && g2 != 0.0) fl |= 1;
+            if (g2 > kQuadraticOff * kQuadraticOff * ab) fl |= 2;
+        }
+        if (fl) atomicOr(sflag, fl);
+    }
+    __syncthreads();
+    const int fl_all = *sflag;
+    if (!(fl_all & 1)) return;                                       // nothing to rotate: the columns stay as they are
+    if (tid == 0) {
+        a.flag[0] = 1;
+        if (fl_all & 2) a.flag[1] = 1;
+    }
+    // ---- 3. two-sided rotations on G (threads 0 .. BB^2 - 1: one 2 x 2 block each), J <- J R (threads 256 ..)
+    constexpr int nin = AP ? W - 1 : BB;
+    auto pair_of = [&](int k, int t, int& p, int& q) {
+        if (AP) {
+            if (k == 0) {
+                p = W - 1;
+                q = t;
+            } else {
+                p = t + k;
+                q = t + W - 1 - k;
+                if (p >= W - 1) p -= W - 1;
+                if (q >= W - 1) q -= W - 1;
+            }
+            if (p > q) {
+                const int t2 = p;
+                p = q;
+                q = t2;
+            }
+        } else {
+            p = k;
+            q = k + t;
+            if (q >= BB) q -= BB;
+            q += BB;
+        }
+    };
+    auto rot_of = [&](const double* G, int p, int q, double& c, double& sr, double& si) {
+        const double al = G[p * LDG + p], be = G[q * LDG + q];
+        const double gr = G[p * LDG + q], gi = CX ? G[W * LDG + p * LDG + q] : 0.0;
+        double sabs, gabs;
+        bool big;
+        if (al < ng || be < ng || !rotation_fast<CX>(al, be, gr, gi, a.tol, c, sr, si, sabs, gabs, big)) {
+            c = 1.0;
+            sr = 0.0;
+            si = 0.0;
+        }
+    };
+    const bool gthr = tid < BB * BB;
+    const int k1 = tid % BB, k2 = (tid / BB) % BB;                   // block (k1, k2) of G
+    const bool jthr = tid >= 256 && tid < 256 + BB * (W / 2);
+    const int jk = (tid - 256) % BB, ji = ((tid - 256) / BB) * 2;    // pair jk, rows ji, ji + 1 of J
+    int cur = 0;
+    for (int t = 0; t < nin; ++t) {
+        const double* G = Gb + (size_t)cur * NC * W * LDG;
+        double* Gn = Gb + (size_t)(cur ^ 1) * NC * W * LDG;
+        if (gthr) {
+            int p1, q1, p2, q2;
+            pair_of(k1, t, p1, q1);
+            pair_of(k2, t, p2, q2);
+            double c1, s1r, s1i, c2, s2r, s2i;
+            rot_of(G, p1, q1, c1, s1r, s1i);
+            if (k1 == k2) {
+                c2 = c1;
+                s2r = s1r;
+                s2i = s1i;
+            } else {
+                rot_of(G, p2, q2, c2, s2r, s2i);
+            }
+            // B = [[G p1p2, G p1q2], [G q1p2, G q1q2]]
+            const double b00r = G[p1 * LDG + p2], b01r = G[p1 * LDG + q2], b10r = G[q1 * LDG + p2], b11r = G[q1 * LDG + q2];
+            if constexpr (CX) {
+                const double* Gi = G + W * LDG;
+                const double b00i = Gi[p1 * LDG + p2], b01i = Gi[p1 * LDG + q2], b10i = Gi[q1 * LDG + p2], b11i = Gi[q1 * LDG + q2];
+                // columns: M = B R2:  M[:,0] = c2 B[:,0] - conj(s2) B[:,1];  M[:,1] = s2 B[:,0] + c2 B[:,1]
+                const double m00r = c2 * b00r - (s2r * b01r + s2i * b01i), m00i = c2 * b00i - (s2r * b01i - s2i * b01r);
+                const double m10r = c2 * b10r - (s2r * b11r + s2i * b11i), m10i = c2 * b10i - (s2r * b11i - s2i * b11r);
+                const double m01r = (s2r * b00r - s2i * b00i) + c2 * b01r, m01i = (s2r * b00i + s2i * b00r) + c2 * b01i;
+                const double m11r = (s2r * b10r - s2i * b10i) + c2 * b11r, m11i = (s2r * b10i + s2i * b10r) + c2 * b11i;
+                // rows: R1^H M:  row0 = c1 M0 - s1 M1;  row1 = conj(s1) M0 + c1 M1
+                double* Gni = Gn + W * LDG;
+                Gn[p1 * LDG + p2] = c1 * m00r - (s1r * m10r - s1i * m10i);
+                Gni[p1 * LDG + p2] = c1 * m00i - (s1r * m10i + s1i * m10r);
+                Gn[p1 * LDG + q2] = c1 * m01r - (s1r * m11r - s1i * m11i);
+                Gni[p1 * LDG + q2] = c1 * m01i - (s1r * m11i + s1i * m11r);
+                Gn[q1 * LDG + p2] = (s1r * m00r + s1i * m00i) + c1 * m10r;
+                Gni[q1 * LDG + p2] = (s1r * m00i - s1i * m00r) + c1 * m10i;
+                Gn[q1 * LDG + q2] = (s1r * m01r + s1i * m01i) + c1 * m11r;
+                Gni[q1 * LDG + q2] = (s1r * m01i - s1i * m01r) + c1 * m11i;
+            } else {
+                const double m00 = fma(c2, b00r, -s2r * b01r), m01 = fma(s2r, b00r, c2 * b01r);
+                const double m10 = fma(c2, b10r, -s2r * b11r), m11 = fma(s2r, b10r, c2 * b11r);
+                Gn[p1 * LDG + p2] = fma(c1, m00, -s1r * m10);
+                Gn[p1 * LDG + q2] = fma(c1, m01, -s1r * m11);
+                Gn[q1 * LDG + p2] = fma(s1r, m00, c1 * m10);
+                Gn[q1 * LDG + q2] = fma(s1r, m01, c1 * m11);
+            }
+        } else if (jthr) {
+            int p, q;
+            pair_of(jk, t, p, q);
+            double c, sr, si;
+            rot_of(G, p, q, c, sr, si);
+            if (sr != 0.0 || si != 0.0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = ji + u;
+                    if constexpr (CX) {
+                        c64 x{Jm[i * W + p], Jm[W * W + i * W + p]}, y{Jm[i * W + q], Jm[W * W + i * W + q]};
+                        rotate_pair_sg(x, y, c, sr, si);
+                        Jm[i * W + p] = x.re;
+                        Jm[W * W + i * W + p] = x.im;
+                        Jm[i * W + q] = y.re;
+                        Jm[W * W + i * W + q] = y.im;
+                    } else {
+                        double x = Jm[i * W + p], y = Jm[i * W + q];
+                        rotate_pair_sg(x, y, c, sr, si);
+                        Jm[i * W + p] = x;
+                        Jm[i * W + q] = y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- 4. X <- X J (as (J^T)(X^T): D[j][r]), wave -> row tiles
+    {
+        const int li = lane & 15, lk = lane >> 4;
+        double jr[NTL][W / 4], jim[NTL][W / 4];
+#pragma unroll
+        for (int tj = 0; tj < NTL; ++tj)
+#pragma unroll
+            for (int ks = 0; ks < W / 4; ++ks) {
+                jr[tj][ks] = Jm[(4 * ks + lk) * W + 16 * tj + li];
+                jim[tj][ks] = CX ? Jm[W * W + (4 * ks + lk) * W + 16 * tj + li] : 0.0;
+            }
+        for (int rt = wave; rt < mpad / 16; rt += 8) {
+            d4 rr[NTL], ii[NTL], ri[NTL];
+#pragma unroll
+            for (int tj = 0; tj < NTL; ++tj) rr[tj] = ii[tj] = ri[tj] = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < W / 4; ++ks) {
+                const T xv = Xs[(size_t)LDR * (4 * ks + lk) + 16 * rt + li];
+#pragma unroll
+                for (int tj = 0; tj < NTL; ++tj) {
+                    if constexpr (CX) {
+                        rr[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(jr[tj][ks], xv.re, rr[tj], 0, 0, 0);
+                        ii[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(jim[tj][ks], xv.im, ii[tj], 0, 0, 0);
+                        ri[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(jim[tj][ks], xv.re, ri[tj], 0, 0, 0);
+                        ri[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(jr[tj][ks], xv.im, ri[tj], 0, 0, 0);
+                    } else {
+                        rr[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(jr[tj][ks], xv, rr[tj], 0, 0, 0);
+                    }
+                }
+            }
+            const int r = 16 * rt + li;
+#pragma unroll
+            for (int tj = 0; tj < NTL; ++tj)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int gc = gcol(16 * tj + lk + 4 * q4);
+                    if (r < m && gc < n) {
+                        if constexpr (CX)
+                            a.A[a.lda * gc + r] = T{rr[tj][q4] - ii[tj][q4], ri[tj][q4]};
+                        else
+                            a.A[a.lda * gc + r] = rr[tj][q4];
+                    }
+                }
+        }
+    }
+}
+
+template <class T, int BB, bool AP>
+__global__ __launch_bounds__(512) void gram_block_round(gram_round_args<T> a) {
+    gram_block_round_body<T, BB, AP>(a, blockIdx.x);
+}
+
+template <class T, int BB>
+int launch_gram_round(qil_context* ctx, T* X, long long ldx, int k, int nblk, int round, double tol, int* flag, const int* prev,
+                      const double* negl) {
+    const size_t lds = gram_round_lds<T, BB>(k);
+    static bool attr = false;
+    if (!attr) {
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_block_round<T, BB, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_block_round<T, BB, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    gram_round_args<T> a{X, ldx, k, k, nblk, round, tol, flag, prev, negl};
+    if (round == 0)
+        hipLaunchKernelGGL((gram_block_round<T, BB, true>), dim3(nblk / 2), dim3(512), lds, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((gram_block_round<T, BB, false>), dim3(nblk / 2), dim3(512), lds, ctx->stream, a);
+    return QIL_OK;
+}
+
 // B (p x q, ldb; destroyed) = Uiso diag(S) V^H:  Uiso (p x k, k = min(p, q)) orthonormal columns sorted by descending
 // singular value, S on the host, SVh (k x q) = diag(S) V^H.  Serves 97 <= k < 640 (and smaller k whose general path would not be LDS-resident) with the columns in LDS;
 // *handled = 0 (nothing touched beyond B's contents being intact) sends the caller to the general svd_impl.
