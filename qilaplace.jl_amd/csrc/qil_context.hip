@@ -112,6 +112,7 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
         hipEventDestroy(pr.second);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->flag_host) hipHostFree(ctx->flag_host);
     if (ctx->sweep_ready) hipEventDestroy(ctx->sweep_ready);
     if (ctx->sweep_done) hipEventDestroy(ctx->sweep_done);
     if (ctx->t0) hipEventDestroy(ctx->t0);
@@ -425,6 +426,18 @@ static int get_event(qil_context* ctx, hipEvent_t* e) {
         return QIL_OK;
     }
     QIL_HIP(hipEventCreate(e));
+    return QIL_OK;
+}
+
+int qil_ctx_event(qil_context* ctx, hipEvent_t* e) { return get_event(ctx, e); }
+void qil_ctx_event_release(qil_context* ctx, hipEvent_t e) {
+    if (e) ctx->event_pool.push_back(e);
+}
+// a small pinned block of the context's own for flag read-backs that the host polls while the stream runs on
+int qil_ctx_flag_host(qil_context* ctx, size_t bytes, void** out) {
+    if (bytes > 4096) return qil_fail(QIL_EINVAL_ARG, "flag block too large");
+    if (!ctx->flag_host) QIL_HIP(hipHostMalloc(&ctx->flag_host, 4096, hipHostMallocDefault));
+    *out = ctx->flag_host;
     return QIL_OK;
 }
 

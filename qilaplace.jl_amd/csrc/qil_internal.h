@@ -90,6 +90,7 @@ struct qil_context {
     // pinned staging for small descriptor / bit uploads
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    void* flag_host = nullptr;    // 4 KB pinned: convergence flags the host reads while the stream runs on (qil_ctx_flag_host)
     void* dev_scratch = nullptr;  // per-call device workspace (stream-ordered reuse)
     size_t dev_scratch_bytes = 0;
     // ring of small host(pinned)/device descriptor slots for grouped launches: a slot is reused
@@ -135,6 +136,9 @@ int qil_ctx_dev_scratch(qil_context* ctx, size_t bytes, void** out);  // grows
 // enqueueing the last kernel that reads the device side
 int qil_ctx_desc_acquire(qil_context* ctx, size_t bytes, void** host, void** dev, int* slot);
 int qil_ctx_desc_commit(qil_context* ctx, int slot);
+int qil_ctx_event(qil_context* ctx, hipEvent_t* e);            // from the context's event pool
+void qil_ctx_event_release(qil_context* ctx, hipEvent_t e);
+int qil_ctx_flag_host(qil_context* ctx, size_t bytes, void** out);
 int qil_ctx_prof_begin(qil_context* ctx);
 int qil_ctx_prof_end(qil_context* ctx);
 

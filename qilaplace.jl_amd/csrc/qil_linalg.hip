@@ -2298,6 +2298,7 @@ struct gram_round_args {
     int* flag;
     const int* prev;
     const double* negligible;
+    long long* prof;            // tools/micro/gram_round_cost.hip only: shader-clock stamps per phase (nullptr in the product)
 };
 
 template <class T, int BB>
@@ -2319,6 +2320,8 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
     constexpr int NTL = W / 16, NT2 = NTL * NTL, KSP = 8 / NT2;      // 16 x 16 tiles of G; waves per tile (K split)
     static_assert(W == 16 || W == 32, "2 x 8 or 2 x 16 columns");
     if (a.prev && !a.prev[1]) return;
+    long long st[6] = {0, 0, 0, 0, 0, 0};
+    if (a.prof) st[0] = __builtin_amdgcn_s_memtime();
     const int m = a.m, n = a.n, nb = a.nb, round = a.round;
     const int mpad = (m + 15) & ~15, LDR = mpad + 2;
     extern __shared__ __attribute__((aligned(16))) char gr_smem[];
@@ -2351,27 +2354,36 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
     if (P * BB >= n) return;                                         // both blocks are padding
     auto gcol = [&](int k) { return (k < BB ? P * BB + k : Q * BB + (k - BB)); };
     if (tid == 0) *sflag = 0;
-    // ---- 1. staging (all loads of a column in flight; rows / columns beyond the matrix: clamped address, value times 0)
-    for (int c = wave; c < W; c += 8) {
-        const int gc = gcol(c);
-        const bool cv = gc < n;
-        const T* s0 = a.A + a.lda * (cv ? gc : 0);
-        T* d0 = Xs + (size_t)LDR * c;
+    // ---- 1. staging (ALL of a wave's loads in flight before the first LDS store -- a column per trip pays one memory
+    // latency per column; rows / columns beyond the matrix: clamped address, value times 0)
+    {
+        constexpr int CPW = W / 8;                                   // columns per wave
         for (int r0 = 0; r0 < mpad; r0 += 256) {
-            T t0[4];
+            T t0[CPW][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + lane + 64 * u;
-                t0[u] = scale_t(s0[r < m ? r : 0], (cv && r < m) ? 1.0 : 0.0);
+            for (int cc = 0; cc < CPW; ++cc) {
+                const int gc = gcol(wave + 8 * cc);
+                const bool cv = gc < n;
+                const T* s0 = a.A + a.lda * (cv ? gc : 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + lane + 64 * u;
+                    t0[cc][u] = scale_t(s0[r < m ? r : 0], (cv && r < m) ? 1.0 : 0.0);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + lane + 64 * u;
-                if (r < mpad) d0[r] = t0[u];
+            for (int cc = 0; cc < CPW; ++cc) {
+                T* d0 = Xs + (size_t)LDR * (wave + 8 * cc);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + lane + 64 * u;
+                    if (r < mpad) d0[r] = t0[cc][u];
+                }
             }
         }
     }
     __syncthreads();
+    if (a.prof) st[1] = __builtin_amdgcn_s_memtime();
     // ---- 2. G = X^H X: wave -> (tile, K slice)
     {
         const int tile = wave / KSP, ks0 = wave % KSP;
@@ -2381,10 +2393,29 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
         const T* xa = Xs + (size_t)LDR * (16 * ti + li) + lk;
         const T* xb = Xs + (size_t)LDR * (16 * tj + li) + lk;
         const int nks = mpad / 4;
-        for (int ks = ks0; ks < nks; ks += KSP) {
+        d4 rr2 = {0, 0, 0, 0}, ii2 = {0, 0, 0, 0}, ri2 = {0, 0, 0, 0};   // second accumulator set: no dependent MFMA chain
+        int ks = ks0;
+        for (; ks + KSP < nks; ks += 2 * KSP) {
             const T av = xa[4 * ks], bv = xb[4 * ks];
+            const T av2 = xa[4 * (ks + KSP)], bv2 = xb[4 * (ks + KSP)];
             if constexpr (CX) {
                 // G = (ar - i ai)^T (br + i bi):  re = ar br + ai bi,  im = ar bi - ai br
+                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.re, rr, 0, 0, 0);
+                rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2.re, bv2.re, rr2, 0, 0, 0);
+                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.im, rr, 0, 0, 0);
+                rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2.im, bv2.im, rr2, 0, 0, 0);
+                ri = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.im, ri, 0, 0, 0);
+                ri2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2.re, bv2.im, ri2, 0, 0, 0);
+                ii = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.re, ii, 0, 0, 0);
+                ii2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2.im, bv2.re, ii2, 0, 0, 0);
+            } else {
+                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, rr, 0, 0, 0);
+                rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2, bv2, rr2, 0, 0, 0);
+            }
+        }
+        for (; ks < nks; ks += KSP) {
+            const T av = xa[4 * ks], bv = xb[4 * ks];
+            if constexpr (CX) {
                 rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.re, rr, 0, 0, 0);
                 rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.im, rr, 0, 0, 0);
                 ri = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.im, ri, 0, 0, 0);
@@ -2392,6 +2423,12 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
             } else {
                 rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, rr, 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rr[r] += rr2[r];
+            ii[r] += ii2[r];
+            ri[r] += ri2[r];
         }
         double* pw = Pp + (size_t)wave * NC * 256;
 #pragma unroll
@@ -2419,6 +2456,7 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
         if constexpr (CX) Jm[W * W + t] = 0.0;
     }
     __syncthreads();
+    if (a.prof) st[2] = __builtin_amdgcn_s_memtime();
     const double ng = a.negligible ? *a.negligible : 0.0;
     // ---- convergence flags from the fresh Gram matrix (this visit's pairs)
     {
@@ -2444,6 +2482,7 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
         a.flag[0] = 1;
         if (fl_all & 2) a.flag[1] = 1;
     }
+    if (a.prof) st[3] = __builtin_amdgcn_s_memtime();
     // ---- 3. two-sided rotations on G (threads 0 .. BB^2 - 1: one 2 x 2 block each), J <- J R (threads 256 ..)
     constexpr int nin = AP ? W - 1 : BB;
     auto pair_of = [&](int k, int t, int& p, int& q) {
@@ -2557,6 +2596,7 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
         __syncthreads();
         cur ^= 1;
     }
+    if (a.prof) st[4] = __builtin_amdgcn_s_memtime();
     // ---- 4. X <- X J (as (J^T)(X^T): D[j][r]), wave -> row tiles
     {
         const int li = lane & 15, lk = lane >> 4;
@@ -2602,6 +2642,12 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
                 }
         }
     }
+    if (a.prof && tid == 0 && bx == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[5] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 5; ++i) a.prof[i] += st[i + 1] - st[i];
+        a.prof[5] += 1;
+    }
 }
 
 template <class T, int BB, bool AP>
@@ -2621,7 +2667,7 @@ int launch_gram_round(qil_context* ctx, T* X, long long ldx, int k, int nblk, in
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    gram_round_args<T> a{X, ldx, k, k, nblk, round, tol, flag, prev, negl};
+    gram_round_args<T> a{X, ldx, k, k, nblk, round, tol, flag, prev, negl, nullptr};
     if (round == 0)
         hipLaunchKernelGGL((gram_block_round<T, BB, true>), dim3(nblk / 2), dim3(512), lds, ctx->stream, a);
     else
@@ -2656,12 +2702,24 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     static const int mode = getenv("QIL_SVD_LEFT_MODE") ? atoi(getenv("QIL_SVD_LEFT_MODE")) : 64;
     const int km = (int)((k + 63) / 64);             // rows per lane, one wave per column
     int G = 64, bb = 8;
+    // Gram-matrix block rounds on the matrix cores (gram_block_round) whenever a block pair and its Gram workspace fit one
+    // CU's LDS: 2 x 16 columns, else 2 x 8; inside a batch whose chains combine their sweeps the vector rounds stay
+    // (measured, compress! on 24 sites: f64 chi 256 -> 128 69.9 ms with the Gram rounds, 70.4 ms with the vector rounds; c64 107
+    // against 103 ms -- a Gram round of 2 x 16 columns takes 20 us where two vector rounds of 2 x 8 take 18, both bound by the
+    // latency of the rotation rounds, tools/micro/gram_round_cost.hip -- so complex operands keep the vector rounds)
+    static const int gram = getenv("QIL_SVD_GRAM") ? atoi(getenv("QIL_SVD_GRAM")) : 1;   // 0 = vector-ALU block rounds, 2 = Gram rounds for c64 too
+    int gbb = 0;
+    if ((gram == 2 || (gram == 1 && sizeof(T) == 8)) && !qil_sweep_combiner_of(ctx)) {
+        if (gram_round_lds<T, 16>((int)k) <= 160 * 1024) gbb = 16;
+        else if (gram_round_lds<T, 8>((int)k) <= 160 * 1024) gbb = 8;
+    }
     if (mode == 32 && (size_t)32 * km * 64 * sizeof(T) + 256 <= 150 * 1024) {
         G = 32;
         bb = 16;
-    } else if ((size_t)16 * km * 64 * sizeof(T) + 128 > 150 * 1024) {
+    } else if (!gbb && (size_t)16 * km * 64 * sizeof(T) + 128 > 150 * 1024) {
         return QIL_OK;
     }
+    if (gbb) bb = gbb;
     const bool dbg = getenv("QIL_SVD_DEBUG") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -2787,7 +2845,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         }
         lap("certificate: declined");
     }
-    QIL_TRY(qil_ctx_alloc(ctx, 256, &flag));
+    QIL_TRY(qil_ctx_alloc(ctx, 512, &flag));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * sizeof(double), &nrm));
     if (negl_rel > 0.0) {
         QIL_TRY(qil_ctx_alloc(ctx, 256, &negl));
@@ -2865,6 +2923,46 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         }
         return QIL_OK;
     };
+    if (gbb) {
+        // Gram-matrix block rounds on the matrix cores.  The host stays ONE SWEEP AHEAD of its read-backs: sweep s + 1 is
+        // enqueued before the flags of sweep s have come back, each of its launches first looks at those flags on the device
+        // and does nothing if sweep s had already converged -- the stream never waits for a host round trip.
+        constexpr int MAXS = 40;
+        void* hostv = nullptr;
+        QIL_TRY(qil_ctx_flag_host(ctx, (size_t)2 * MAXS * sizeof(int), &hostv));
+        volatile int* hv = static_cast<volatile int*>(hostv);
+        int* dflag = static_cast<int*>(flag);                    // [MAXS][2]
+        QIL_HIP(hipMemsetAsync(dflag, 0, (size_t)2 * MAXS * sizeof(int), ctx->stream));
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        QIL_TRY(qil_ctx_event(ctx, &ev[0]));
+        QIL_TRY(qil_ctx_event(ctx, &ev[1]));
+        auto enqueue = [&](int sw) -> int {
+            for (int round = 0; round < nblk - 1; ++round) {
+                const int* prev = sw > 0 ? dflag + 2 * (sw - 1) : nullptr;
+                if (gbb == 16)
+                    QIL_TRY((launch_gram_round<T, 16>(ctx, X, k, (int)k, nblk, round, tol, dflag + 2 * sw, prev, (const double*)negl)));
+                else
+                    QIL_TRY((launch_gram_round<T, 8>(ctx, X, k, (int)k, nblk, round, tol, dflag + 2 * sw, prev, (const double*)negl)));
+            }
+            QIL_HIP(hipMemcpyAsync(const_cast<int*>(hv) + 2 * sw, dflag + 2 * sw, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            QIL_HIP(hipEventRecord(ev[sw & 1], ctx->stream));
+            return QIL_OK;
+        };
+        int st = enqueue(0);
+        for (; st == QIL_OK && sweeps < MAXS; ++sweeps) {
+            if (sweeps + 1 < MAXS) st = enqueue(sweeps + 1);
+            if (st != QIL_OK) break;
+            if (hipEventSynchronize(ev[sweeps & 1]) != hipSuccess) {
+                st = qil_fail(QIL_EHIP, "hipEventSynchronize failed in the Jacobi sweeps");
+                break;
+            }
+            if (dbg) fprintf(stderr, "[svd-left] gram sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[2 * sweeps], hv[2 * sweeps + 1]);
+            if (!hv[2 * sweeps + 1]) break;
+        }
+        qil_ctx_event_release(ctx, ev[0]);
+        qil_ctx_event_release(ctx, ev[1]);
+        QIL_TRY(st);
+    } else
     for (; sweeps < 40; ++sweeps) {
         QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
         if (cb) {
