@@ -235,7 +235,11 @@ static void mark_owned(qil_context* ctx, void* p) {
 }
 
 qil_call_scope::qil_call_scope(qil_context* c)
-    : ctx(c), serial0(c ? c->alloc_serial : 0), fails0(qil_fail_count()) {}
+    : ctx(c), serial0(c ? c->alloc_serial : 0), fails0(qil_fail_count()) {
+    // per-call heuristics state starts afresh: what one call learns about its operands (qr_impl's Cholesky QR refusals) must not
+    // leak into the next one -- an item of a batch then takes exactly the route it takes alone (bit-identical results)
+    if (c) c->cholqr_skip = 0;
+}
 
 qil_call_scope::~qil_call_scope() {
     if (!ctx || qil_fail_count() == fails0) return;

@@ -90,6 +90,7 @@ struct qil_context {
     // pinned staging for small descriptor / bit uploads
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    int cholqr_skip = 0;          // Cholesky QR attempts to skip after a refusal (qr_impl)
     void* flag_host = nullptr;    // 4 KB pinned: convergence flags the host reads while the stream runs on (qil_ctx_flag_host)
     void* dev_scratch = nullptr;  // per-call device workspace (stream-ordered reuse)
     size_t dev_scratch_bytes = 0;

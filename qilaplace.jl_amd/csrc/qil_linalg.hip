@@ -1901,24 +1901,15 @@ __global__ void negate_block(T* __restrict__ A, long long lda, int m, int n) {
         A[(t % m) + lda * (t / m)] = neg_t(A[(t % m) + lda * (t / m)]);
 }
 
-// Xinv (k x k, ld k, zero below the diagonal) = R^-1 for upper-triangular R
+// The off-diagonal blocks of Xinv = R^-1 (k x k, ld k) from its inverted diagonal blocks of width `blk` (already in place):
+// neighbouring blocks are merged level by level, [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1]  (MFMA GEMMs)
 template <class T>
-int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
-    QIL_HIP(hipMemsetAsync(Xinv, 0, (size_t)k * k * sizeof(T), ctx->stream));
-    const int nb = (k + 63) / 64;
-    constexpr size_t diag_lds = (size_t)2 * 64 * 65 * sizeof(T);
-    static bool attr = false;
-    if (!attr) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trtri_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)diag_lds));
-        attr = true;
-    }
-    hipLaunchKernelGGL(trtri_diag<T>, dim3((unsigned)nb), dim3(64), diag_lds, ctx->stream, R, ldr, k, Xinv, (long long)k);
-    QIL_HIP(hipGetLastError());
-    // merge neighbouring inverted diagonal blocks level by level: [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1]
+int trtri_merge(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv, int blk) {
+    const int nb = (k + blk - 1) / blk;
     struct Blk { int start, size; };
     std::vector<Blk> cur;
-    for (int b = 0; b < nb; ++b) cur.push_back(Blk{b * 64, std::min(64, k - b * 64)});
+    for (int b = 0; b < nb; ++b) cur.push_back(Blk{b * blk, std::min(blk, k - b * blk)});
+    if (cur.size() < 2) return QIL_OK;
     void* tmp = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * k * sizeof(T), &tmp));
     T* Tm = static_cast<T*>(tmp);
@@ -1938,6 +1929,231 @@ int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
     }
     QIL_HIP(hipGetLastError());
     qil_ctx_free(ctx, tmp);
+    return QIL_OK;
+}
+
+// Xinv (k x k, ld k, zero below the diagonal) = R^-1 for upper-triangular R
+template <class T>
+int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
+    QIL_HIP(hipMemsetAsync(Xinv, 0, (size_t)k * k * sizeof(T), ctx->stream));
+    const int nb = (k + 63) / 64;
+    constexpr size_t diag_lds = (size_t)2 * 64 * 65 * sizeof(T);
+    static bool attr = false;
+    if (!attr) {
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trtri_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)diag_lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(trtri_diag<T>, dim3((unsigned)nb), dim3(64), diag_lds, ctx->stream, R, ldr, k, Xinv, (long long)k);
+    QIL_HIP(hipGetLastError());
+    return trtri_merge<T>(ctx, R, ldr, k, Xinv, 64);
+}
+
+// ------------------------------------------------------------------ Cholesky QR (CholeskyQR2) for the gauge sweeps
+// A thin QR of a well-conditioned operand needs no column-by-column chain: G = A^H A (one MFMA GEMM), G = R^H R, Q = A R^-1,
+// and once more on Q (CholeskyQR2: orthonormal to rounding while kappa(A)^2 eps << 1).  The gauge sweeps of compress! /
+// canonicalize! factor sites whose conditioning the truncation certificate bounds anyway (it declines beyond kappa ~ 5e5),
+// and a blocked Householder QR of 512 x 256 is ~80 small launches with eight 50-70 us one-workgroup panels in them.
+// chol_inv_block: ONE workgroup of 32 x 32 threads, the diagonal block (nb <= NBK = 32 TS) in REGISTERS: thread (tr, tc) keeps
+// the TS x TS tile (tr, tc) -- of the Schur complement S if tc >= tr (upper triangle), of the elimination matrix E = L~^-1
+// (G = L~ D L~^H, unit lower triangular) if tc <= tr; the diagonal threads keep both.  Step j: the owners of row j publish
+// it (S(j, j:) and E(j, :j]) through a double-buffered LDS row, one barrier, then every thread below row j updates its tile
+// with the multipliers m_i = conj(S(j, i)) / d_j: S(i, k) -= m_i S(j, k), E(i, c) -= m_i E(j, c) -- 2 TS^2 FMAs per thread and
+// step, no read-modify-write traffic (an LDS-resident right-looking factorisation moves n^3 / 3 x 24 B through the LDS:
+// 180 us at n = 128 against ~25 here).  Then R = D^-1/2 S (its rows are final when they are published) and
+// R^-1 = E^H D^-1/2.  A pivot that is not above piv_rel times its original diagonal entry raises *flag (the caller then takes
+// the Householder route; everything written is discarded).
+template <class T, int TS>
+__global__ __launch_bounds__(1024) void chol_inv_block(const T* __restrict__ G, long long ldg, int nb, T* __restrict__ Rout,
+                                                       long long ldr, T* __restrict__ Xout, long long ldx, double piv_rel,
+                                                       int* __restrict__ flag) {
+    constexpr int NBK = 32 * TS;
+    __shared__ __attribute__((aligned(16))) T srow[2][NBK];
+    __shared__ __attribute__((aligned(16))) T erow[2][NBK];
+    __shared__ double dg[NBK], d0[NBK];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, tc = tid & 31, tr = tid >> 5;
+    T w[TS][TS], e2[TS][TS];          // w: S tile (tc >= tr) or E tile (tc < tr); e2: E tile of the diagonal threads
+    auto one = []() {
+        T v{};
+        reinterpret_cast<double*>(&v)[0] = 1.0;
+        return v;
+    };
+#pragma unroll
+    for (int a = 0; a < TS; ++a)
+#pragma unroll
+        for (int b = 0; b < TS; ++b) {
+            const int i = TS * tr + a, k = TS * tc + b;
+            T v{};
+            if (tc >= tr) {                                    // S: the block itself (rows / columns beyond nb: identity)
+                if (i < nb && k < nb)
+                    v = i <= k ? G[i + ldg * k] : conj_t(G[k + ldg * i]);
+                else if (i == k)
+                    v = one();
+            } else if (i == k) {
+                v = one();                                     // (never: tc < tr has no diagonal)
+            }
+            w[a][b] = v;
+            e2[a][b] = (tc == tr && a == b) ? one() : T{};
+        }
+    if (tid == 0) s_bad = 0;
+    if (tc == tr)
+#pragma unroll
+        for (int a = 0; a < TS; ++a) d0[TS * tr + a] = reinterpret_cast<const double*>(&w[a][a])[0];
+    __syncthreads();
+    const int ntile = (nb + TS - 1) / TS;
+    for (int jt = 0; jt < ntile; ++jt) {
+#pragma unroll
+        for (int jj = 0; jj < TS; ++jj) {
+            const int j = TS * jt + jj, par = j & 1;
+            if (tr == jt) {                                    // publish row j
+                if (tc >= tr)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) srow[par][TS * tc + b] = w[jj][b];
+                if (tc < tr)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) erow[par][TS * tc + b] = w[jj][b];
+                if (tc == tr)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) erow[par][TS * tc + b] = e2[jj][b];
+            }
+            __syncthreads();
+            if (tr >= jt) {
+                const double d = reinterpret_cast<const double*>(&srow[par][j])[0];
+                const bool dead = !(d > piv_rel * d0[j]);
+                if (tc == jt && tr == jt) {
+                    dg[j] = dead ? 1.0 : d;
+                    if (dead) s_bad = 1;
+                }
+                const double inv = dead ? 0.0 : rcp_refined(d);
+                T mlt[TS];
+#pragma unroll
+                for (int a = 0; a < TS; ++a) {
+                    const int i = TS * tr + a;
+                    mlt[a] = i > j ? scale_t(conj_t(srow[par][i]), inv) : T{};
+                }
+                if (tc >= tr) {
+                    T v[TS];
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) v[b] = srow[par][TS * tc + b];
+#pragma unroll
+                    for (int a = 0; a < TS; ++a)
+#pragma unroll
+                        for (int b = 0; b < TS; ++b) w[a][b] = sub_t(w[a][b], fma_t(mlt[a], v[b], T{}));
+                }
+                if (tc <= jt && tc <= tr) {
+                    T v[TS];
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) v[b] = erow[par][TS * tc + b];
+                    if (tc < tr) {
+#pragma unroll
+                        for (int a = 0; a < TS; ++a)
+#pragma unroll
+                            for (int b = 0; b < TS; ++b) w[a][b] = sub_t(w[a][b], fma_t(mlt[a], v[b], T{}));
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < TS; ++a)
+#pragma unroll
+                            for (int b = 0; b < TS; ++b) e2[a][b] = sub_t(e2[a][b], fma_t(mlt[a], v[b], T{}));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_bad) atomicOr(flag, 1);
+    // R(i, k) = S(i, k) / sqrt(d_i) (k >= i);  X(c, i) = conj(E(i, c)) / sqrt(d_i) (c <= i)
+#pragma unroll
+    for (int a = 0; a < TS; ++a)
+#pragma unroll
+        for (int b = 0; b < TS; ++b) {
+            const int i = TS * tr + a, k = TS * tc + b;
+            if (i >= nb || k >= nb) continue;
+            const double rs = rsqrt(dg[i]);
+            if (tc >= tr && i <= k) {
+                T v = scale_t(w[a][b], rs);
+                if (i == k) {
+                    v = T{};
+                    reinterpret_cast<double*>(&v)[0] = sqrt(dg[i]);
+                }
+                Rout[i + ldr * k] = v;
+            }
+            if (tc < tr) Xout[k + ldx * i] = scale_t(conj_t(w[a][b]), rs);
+            if (tc == tr && k <= i) Xout[k + ldx * i] = scale_t(conj_t(e2[a][b]), rs);
+        }
+}
+
+// G (n x n, ld n, Hermitian positive definite; DESTROYED) = R^H R;  Rm (upper triangular, ld n) and Xm = R^-1 (ld n), both
+// zero below the diagonal; *flag (device) is raised on a bad pivot.  Diagonal blocks of 32 TS columns in one workgroup each,
+// the rest by MFMA GEMMs.
+template <class T, int TS>
+int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
+    constexpr int NBK = 32 * TS;
+    QIL_HIP(hipMemsetAsync(Rm, 0, (size_t)n * n * sizeof(T), ctx->stream));
+    QIL_HIP(hipMemsetAsync(Xm, 0, (size_t)n * n * sizeof(T), ctx->stream));
+    const int opH = sizeof(T) == 16 ? 2 : 1;
+    for (int j0 = 0; j0 < n; j0 += NBK) {
+        const int nbj = std::min(NBK, n - j0), rest = n - j0 - nbj;
+        hipLaunchKernelGGL((chol_inv_block<T, TS>), dim3(1), dim3(1024), 0, ctx->stream, (const T*)(G + j0 + (long long)n * j0),
+                           (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n,
+                           1e-11, flag);
+        QIL_HIP(hipGetLastError());
+        if (rest > 0) {
+            T* Rjr = Rm + j0 + (long long)n * (j0 + nbj);
+            // R(j, rest) = R_jj^-H G(j, rest);   G(rest, rest) -= R(j, rest)^H R(j, rest)
+            QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, nbj, rest, nbj, Xm + j0 + (long long)n * j0, n, G + j0 + (long long)n * (j0 + nbj), n, Rjr, n));
+            gemm_batch sub;
+            sub.subtract = 1;
+            QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, rest, rest, nbj, Rjr, n, Rjr, n, G + (j0 + nbj) + (long long)n * (j0 + nbj), n, sub));
+        }
+    }
+    return trtri_merge<T>(ctx, Rm, n, n, Xm, NBK);
+}
+// 64-column diagonal blocks (TS = 2) measured best for both dtypes: compress! on 24 sites, chi 512 -> 256: f64 161.6 ms (TS 4:
+// 166.8, TS 1: 179.1, Householder panels: 197.8), c64 212.6 ms (214.0 / 229.2 / 341.6); chi 256 -> 128: 68.2 / 69.5 / 73.2 / 70.7
+template <class T>
+int chol_inv(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
+    return chol_inv_ts<T, 2>(ctx, G, n, Rm, Xm, flag);
+}
+
+// A (m x n, m >= n) -> Q in place, R (n x n, ldr; may be null) with positive diagonal.  *done = false: the operand is not
+// well enough conditioned (or not positive definite to rounding) -- A and R are untouched, the caller factors it by reflectors.
+template <class T>
+int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr, bool* done) {
+    *done = false;
+    const int opH = sizeof(T) == 16 ? 2 : 1;
+    void *g = nullptr, *r1 = nullptr, *x1 = nullptr, *r2 = nullptr, *x2 = nullptr, *q1 = nullptr, *fl = nullptr;
+    auto release = [&]() {
+        for (void* b : {g, r1, x1, r2, x2, q1, fl})
+            if (b) qil_ctx_free(ctx, b);
+    };
+    const size_t nn = (size_t)(n * n) * sizeof(T);
+    QIL_TRY(qil_ctx_alloc(ctx, nn, &g));
+    QIL_TRY(qil_ctx_alloc(ctx, nn, &r1));
+    QIL_TRY(qil_ctx_alloc(ctx, nn, &x1));
+    QIL_TRY(qil_ctx_alloc(ctx, nn, &r2));
+    QIL_TRY(qil_ctx_alloc(ctx, nn, &x2));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * sizeof(T), &q1));
+    QIL_TRY(qil_ctx_alloc(ctx, 256, &fl));
+    QIL_HIP(hipMemsetAsync(fl, 0, sizeof(int), ctx->stream));
+    T *G = static_cast<T*>(g), *R1 = static_cast<T*>(r1), *X1 = static_cast<T*>(x1), *R2 = static_cast<T*>(r2),
+      *X2 = static_cast<T*>(x2), *Q1 = static_cast<T*>(q1);
+    QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, n, n, m, A, lda, A, lda, G, n));
+    QIL_TRY(chol_inv<T>(ctx, G, (int)n, R1, X1, (int*)fl));
+    QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, n, n, A, lda, X1, n, Q1, m));
+    QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, n, n, m, Q1, m, Q1, m, G, n));
+    QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
+    int bad = 0;
+    QIL_HIP(hipMemcpyAsync(&bad, fl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    if (bad) {
+        release();
+        return QIL_OK;
+    }
+    QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, n, n, Q1, m, X2, n, A, lda));
+    if (R) QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, n, n, n, R2, n, R1, n, R, ldr));
+    release();
+    *done = true;
     return QIL_OK;
 }
 
@@ -3460,6 +3676,20 @@ template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
     static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 2048;   // tuning aid
     static const bool hh_panels = !(getenv("QIL_QR_HH") && atoi(getenv("QIL_QR_HH")) == 0);                   // tuning aid
+    // Cholesky QR first where it pays (from a few panels on) and while it keeps succeeding on this context: a numerically
+    // rank-deficient operand (product bonds, deficient sketches) costs the attempt a Gram product, a partial factorisation and
+    // one synchronisation, so after a refusal the next attempts are skipped
+    static const bool cholqr = !(getenv("QIL_QR_CHOL") && atoi(getenv("QIL_QR_CHOL")) == 0);   // 0 = Householder / CGS2 panels only
+    if (cholqr && n >= 64 && n <= 1024 && m >= n && m * n <= (1LL << 22)) {
+        if (ctx->cholqr_skip > 0) {
+            --ctx->cholqr_skip;
+        } else {
+            bool done = false;
+            QIL_TRY(cholqr2<T>(ctx, m, n, A, lda, R, ldr, &done));
+            if (done) return QIL_OK;
+            ctx->cholqr_skip = 8;
+        }
+    }
     // one launch for the whole factorisation: single panels, and anything whose slice fits one CU's LDS
     const bool fits_lds = ((size_t)2 * (n + (n & 1)) + (size_t)(m | 1) * n) * sizeof(T) <= 150 * 1024;
     // panels go through the row-chunk tree from TALL rows on, and already from 640 rows when a rows x 16 panel does
