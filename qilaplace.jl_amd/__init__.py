@@ -21,7 +21,7 @@ from .ops import (apply, apply_compress, apply_compress_batch, mpo_compress, com
                   svd_trunc, gemm, gemm_device_time, qr_positive)
 from .builders import (build_qft_mpo, build_dt_mpo, build_zt_mpo, qft_mpo_tensors,  # noqa: F401
                        dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many, build_dt_mpo_batch,
-                       build_zt_mpo_batch, zt_qft_chain_tensors)
+                       build_zt_mpo_batch, zt_qft_chain_tensors, qft_mpo_device, zt_qft_chain_device)
 from .interchange import save, load  # noqa: F401
 from .sweep import shard_items, sweep, damping_sweep, gather_results  # noqa: F401
 
@@ -31,7 +31,7 @@ __all__ = [
     "apply", "apply_compress", "apply_compress_batch", "coefficient", "coefficient_batch", "apply_coefficient_batch", "apply_coefficient_sweep", "marginal_batch", "coefficient_grid", "laplace_values", "mps_to_vector", "norm",
     "canonicalize", "compress", "signal_mps", "signal_ztmps", "signal_mps_batch", "signal_ztmps_batch", "rsvd", "svd_trunc", "gemm",
     "build_qft_mpo", "build_dt_mpo", "build_zt_mpo", "qft_mpo_tensors", "dt_mpo_tensors", "zt_mpo_tensors",
-    "dt_mpo_tensors_many", "build_dt_mpo_batch", "build_zt_mpo_batch", "zt_qft_chain_tensors", "mpo_compress", "compress_batch", "mpo_compress_batch", "mps_block",
+    "dt_mpo_tensors_many", "build_dt_mpo_batch", "build_zt_mpo_batch", "zt_qft_chain_tensors", "qft_mpo_device", "zt_qft_chain_device", "mpo_compress", "compress_batch", "mpo_compress_batch", "mps_block",
     "save", "load",
     "shard_items", "sweep", "damping_sweep", "gather_results",
     "QilError", "QilDomainError",

@@ -269,14 +269,17 @@ def _n_of(x):
     return len(x) if hasattr(x, "handle") else int(x)
 
 
-def build_qft_mpo(n_or_psi, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
-    """build_qft_mpo(n, sites; cutoff, maxdim) / build_qft_mpo(psi::SignalMPS; ...)."""
+def build_qft_mpo(n_or_psi, sites=None, cutoff=1e-14, maxdim=1000, ctx=None, device=False):
+    """build_qft_mpo(n, sites; cutoff, maxdim) / build_qft_mpo(psi::SignalMPS; ...).  `device`: every factorisation of the
+    chain on the GPU (`qft_mpo_device`); default: the host chain (`qft_mpo_tensors`; D <= 8, milliseconds)."""
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
     n = _n_of(n_or_psi)
     if sites is not None and len(sites) != n:
         raise ValueError(f"build_qft_mpo: Number of sites must be equal to n. Found length(sites)={len(sites)}, n={n}")
     if psi is not None and sites is None:
         sites, ctx = psi.site_ids, ctx or psi.ctx
+    if device:
+        return qft_mpo_device(n, sites, cutoff, maxdim, ctx)
     return SingleSiteMPO(qft_mpo_tensors(n, cutoff, maxdim), sites=sites, ctx=ctx)
 
 
@@ -367,13 +370,56 @@ def zt_qft_chain_tensors(n, cutoff=1e-14, maxdim=1000):
     return _ZT_Q_CACHE[key]
 
 
-def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, workers=None):
+# ------------------------------------------------------------------ QFT chains assembled ON THE DEVICE
+def qft_mpo_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
+    """build_qft_mpo (qft_transformer.jl:121-165) with every factorisation on the GPU: round `it` multiplies the chain by the
+    block control_Hphase_mpo(n - it) on its trailing sites -- the window product of apply(W1, W2) (apply.jl:124-199 ->
+    qil_apply_mpo_mpo), exact, the bonds multiply -- and re-truncates it with zip_to_compress_mpo "up" (exact QR gauge
+    sweep right -> left, truncating SVD sweep left -> right, dt_transformer.jl:233-276 -> qil_mpo_compress): the
+    reference's zip-up (:13-66, QR, nothing dropped) followed by its zip-down (:69-101, SVD at `cutoff`) is the same
+    exact-product-then-truncate step carried out site by site.  Only the 2 x 2 gate blocks are made on the host."""
+    from .containers import default_context
+    from .ops import apply, mpo_compress
+    if n < 1:
+        raise ValueError(f"build_qft_mpo: Number of qubits 'n' must be at least 1. Found n={n}")
+    ctx = ctx or default_context()
+    ids = [int(i) for i in sites] if sites is not None else list(range(1, n + 1))
+    M = SingleSiteMPO(_qft_block(n), sites=ids, ctx=ctx)
+    for it in range(1, n):
+        B = SingleSiteMPO(_qft_block(n - it), sites=ids[it:], ctx=ctx)
+        M = apply(M, B)                                   # M first, then the block on the trailing n - it sites
+        mpo_compress(M, "up", cutoff, maxdim)
+    return M
+
+
+def zt_qft_chain_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
+    """The paired-register QFT half of build_zt_mpo (zt_transformer.jl:78-99) on the GPU: for k = 2..n the chain (2k - 2
+    sites) is multiplied by control_Hphase_ztmps_mpo(k) (2k sites; the two new sites see the identity: the window product
+    pads the shorter operand exactly as the reference's identity extension does) and compressed "down"
+    (zip_to_combine_mpos + zip_to_compress_mpo, dt_transformer.jl:38-95, 185-230)."""
+    from .containers import default_context
+    from .ops import apply, mpo_compress
+    if n < 1:
+        raise ValueError(f"build_zt_mpo: n must be >= 1. Found n={n}")
+    ctx = ctx or default_context()
+    ids = [int(i) for i in sites] if sites is not None else list(range(1, 2 * n + 1))
+    Q = PairedSiteMPO(_zt_block(1), sites=ids[:2], ctx=ctx)
+    for k in range(2, n + 1):
+        B = PairedSiteMPO(_zt_block(k), sites=ids[:2 * k], ctx=ctx)
+        Q = apply(Q, B)
+        mpo_compress(Q, "down", cutoff, maxdim)
+    return Q
+
+
+def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, workers=None, qft="host"):
     """z-transform MPOs for a sweep of damping values with the heavy steps on the GPU: the DT halves are built
     together (qil_build_dt_mpo_batch), the QFT half once on the host (it does not depend on the damping), and
     per value the MPO x MPO product (zt_transformer.jl:103 -> qil_apply_mpo_mpo) and its compression
     (zt_transformer.jl:104 -> qil_mpo_compress) run on the device -- on the host that last step alone is the
     largest part of a build (1.4 s of 2.6 s at n = 24).  With more than one value the per-value compression chains run
-    concurrently (qil_mpo_compress_batch)."""
+    concurrently (qil_mpo_compress_batch).  `qft="device"`: the QFT half is assembled on the GPU too
+    (`zt_qft_chain_device`; nothing but 2 x 2 gate blocks comes from the host), `"host"` (default): numpy, cached per n,
+    overlapping the device DT build."""
     from .ops import apply, mpo_compress_batch
     import threading
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
@@ -389,17 +435,22 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, worke
         except Exception as e:                      # noqa: BLE001  (re-raised on the calling thread)
             box["err"] = e
 
+    if qft not in ("host", "device"):
+        raise ValueError(f"build_zt_mpo_batch: qft must be 'host' or 'device', got {qft!r}")
     th = threading.Thread(target=_host_half)
-    th.start()
+    if qft == "host":
+        th.start()
     try:
         dts = build_dt_mpo_batch(n_or_psi, wrs, cutoff, maxdim, ctx)
     finally:
-        th.join()
+        if qft == "host":
+            th.join()
     if "err" in box:
         raise box["err"]
     home = dts[0].ctx
     ids = dts[0].site_ids
-    Q = PairedSiteMPO(box["Q"], sites=ids, ctx=home)
+    Q = (zt_qft_chain_device(n, ids, cutoff, maxdim, home) if qft == "device"
+         else PairedSiteMPO(box["Q"], sites=ids, ctx=home))
     prods = [apply(W_dt, Q) for W_dt in dts]
     if n == 1:
         return prods

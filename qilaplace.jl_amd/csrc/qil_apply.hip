@@ -285,10 +285,9 @@ int check_apply_operands(const qil_mpo* W, const qil_mps* psi) {
 int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
     qil_context* ctx = W->ctx;
     const int64_t n = W->n();
-    // tuning aid: QIL_APPLY_VARIANT = 4 (default: MPO slab staged in LDS, non-temporal stores, 16 b per
-    // workgroup), 5 (same, 8 b), 0 (MPO entries straight from L1/L2), 1 (plain stores), 2 (32 b), 3 (8 b)
-    static const int variant = getenv("QIL_APPLY_VARIANT") ? atoi(getenv("QIL_APPLY_VARIANT")) : 4;
-    const int nbv = variant == 2 ? 32 : (variant == 3 || variant == 5) ? 8 : kNB;
+    // the one shipped shape: MPO slab staged in LDS, non-temporal stores, 16 b per workgroup (measured against it in r02 and
+    // removed: plain stores -3 %, 32-wide b chunks -3 %, MPO entries straight from L1/L2 -1.5 %, 8-wide chunks -2 %)
+    const int nbv = kNB;
     // real x real results pack two rows per lane (16-B stores): 512-row tiles
     const int tile_rows = (W->dtype == QIL_F64 && psi->dtype == QIL_F64) ? 2 * kRows : kRows;
     std::vector<ApplySite> tab((size_t)n);
@@ -321,21 +320,8 @@ int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
     const ApplySite* dtab = static_cast<const ApplySite*>(dev);
     const dim3 grid((unsigned)blocks), block(kRows);
     const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;
-#define QIL_APPLY_LAUNCH(TW, TA)                                                                              \
-    do {                                                                                                      \
-        if (variant == 1)                                                                                     \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, false, 16, false>), grid, block, 0, ctx->stream, dtab, (int)n); \
-        else if (variant == 2)                                                                                \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 32, false>), grid, block, 0, ctx->stream, dtab, (int)n);  \
-        else if (variant == 3)                                                                                \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 8, false>), grid, block, 0, ctx->stream, dtab, (int)n);   \
-        else if (variant == 4)                                                                                \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16, true>), grid, block, 0, ctx->stream, dtab, (int)n);   \
-        else if (variant == 5)                                                                                \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 8, true>), grid, block, 0, ctx->stream, dtab, (int)n);    \
-        else                                                                                                  \
-            hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16, false>), grid, block, 0, ctx->stream, dtab, (int)n);  \
-    } while (0)
+#define QIL_APPLY_LAUNCH(TW, TA) \
+    hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16, true>), grid, block, 0, ctx->stream, dtab, (int)n)
     if (wc && ac) QIL_APPLY_LAUNCH(c64, c64);
     else if (wc) QIL_APPLY_LAUNCH(c64, double);
     else if (ac) QIL_APPLY_LAUNCH(double, c64);

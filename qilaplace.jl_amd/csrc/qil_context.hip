@@ -113,8 +113,6 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->flag_host) hipHostFree(ctx->flag_host);
-    if (ctx->sweep_ready) hipEventDestroy(ctx->sweep_ready);
-    if (ctx->sweep_done) hipEventDestroy(ctx->sweep_done);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
@@ -309,95 +307,6 @@ int qil_ctx_desc_commit(qil_context* ctx, int slot) {
     return QIL_OK;
 }
 
-// ---------------------------------------------------------------- sweep combiner (see qil_internal.h)
-qil_sweep_combiner* qil_sweep_combiner_of(qil_context* ctx) {
-    // OFF by default: the combined round is cheap (8 operands in 1.2x the time of one, rocprofv3 kernel trace), but the
-    // rendezvous couples the chains -- they wait for each other across the QR / GEMM phases that stay per chain and share
-    // hardware queues -- and 8 chains chi 256 -> 128 take 166 ms (wait 50 us) to 193 ms (wait 2 ms) against 171 ms without
-    // (DESIGN 3.5).  QIL_BATCH_COMBINE=1 enables it (read per call).
-    const char* e = getenv("QIL_BATCH_COMBINE");
-    if (!e || atoi(e) == 0) return nullptr;
-    if (ctx->parent) return ctx->parent->lending ? &ctx->parent->combiner : nullptr;
-    return ctx->lending ? &ctx->combiner : nullptr;
-}
-
-int qil_combined_sweep(qil_context* ctx, qil_sweep_combiner* cb, qil_sweep_request& req,
-                       const std::function<int(const qil_round_item*, int, int)>& launch) {
-    if (!ctx->sweep_ready) {
-        QIL_HIP(hipEventCreateWithFlags(&ctx->sweep_ready, hipEventDisableTiming));
-        QIL_HIP(hipEventCreateWithFlags(&ctx->sweep_done, hipEventDisableTiming));
-    }
-    QIL_HIP(hipEventRecord(ctx->sweep_ready, ctx->stream));       // the operand and its cleared flags are ready after this
-    req.ctx = ctx;
-    req.launched = false;
-    req.taken = false;
-    req.status = QIL_OK;
-    std::unique_lock<std::mutex> lk(cb->mu);
-    cb->pending.push_back(&req);
-    cb->cv.notify_all();
-    for (;;) {
-        if (req.launched) return req.status;
-        if (!cb->leader && !req.taken) break;              // nobody is collecting and nobody has this request: lead
-        cb->cv.wait(lk);
-    }
-    cb->leader = true;
-    // Chains of this class that are sweeping but have not arrived are riding a train launched before this chain joined (or
-    // are a few microseconds behind): they come back when it ends, at most one train (<~1 ms) from now.  Waiting that long
-    // merges the trains for good but stalls this chain; measured, short waits are the better policy.
-    const int wait_us = getenv("QIL_BATCH_COMBINE_WAIT_US") ? atoi(getenv("QIL_BATCH_COMBINE_WAIT_US")) : 50;   // tuning aid (read per call)
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
-    auto arrived = [&]() {
-        int c = 0;
-        for (qil_sweep_request* r : cb->pending) c += r->cls == req.cls;
-        return c;
-    };
-    while (arrived() < cb->sweepers[req.cls] && std::chrono::steady_clock::now() < deadline) cb->cv.wait_until(lk, deadline);
-    {
-        const double w = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - (deadline - std::chrono::microseconds(wait_us))).count();
-        cb->waited_us += w;
-        ++cb->wait_hist[arrived() < cb->sweepers[req.cls] ? 5 : w < 20 ? 0 : w < 100 ? 1 : w < 300 ? 2 : w < 1000 ? 3 : 4];
-    }
-    std::vector<qil_sweep_request*> group, rest;
-    for (qil_sweep_request* r : cb->pending) (r->cls == req.cls ? group : rest).push_back(r);
-    cb->pending.swap(rest);
-    for (qil_sweep_request* r : group) r->taken = true;
-    int status = QIL_OK;
-    auto run = [&]() -> int {
-        const int count = (int)group.size();
-        int max_nblk = 0;
-        for (qil_sweep_request* r : group) max_nblk = std::max(max_nblk, r->item.nblk);
-        if (count == 1) return launch(nullptr, 1, max_nblk);
-        void *hp = nullptr, *dp = nullptr;
-        int slot = -1;
-        QIL_TRY(qil_ctx_desc_acquire(ctx, (size_t)count * sizeof(qil_round_item), &hp, &dp, &slot));
-        qil_round_item* hi = static_cast<qil_round_item*>(hp);
-        for (int i = 0; i < count; ++i) hi[i] = group[(size_t)i]->item;
-        QIL_HIP(hipMemcpyAsync(dp, hp, (size_t)count * sizeof(qil_round_item), hipMemcpyHostToDevice, ctx->stream));
-        for (qil_sweep_request* r : group)
-            if (r->ctx != ctx) QIL_HIP(hipStreamWaitEvent(ctx->stream, r->ctx->sweep_ready, 0));
-        QIL_TRY(launch(static_cast<const qil_round_item*>(dp), count, max_nblk));
-        QIL_TRY(qil_ctx_desc_commit(ctx, slot));
-        QIL_HIP(hipEventRecord(ctx->sweep_done, ctx->stream));
-        for (qil_sweep_request* r : group)
-            if (r->ctx != ctx) QIL_HIP(hipStreamWaitEvent(r->ctx->stream, ctx->sweep_done, 0));
-        return QIL_OK;
-    };
-    // the launches themselves run outside the lock (a train is ~30 launches = ~100 us of host time: chains of other classes,
-    // or late arrivals forming the next group, must not queue behind it); the group's requests are out of `pending` and
-    // their owners blocked on the condition variable until `launched`
-    cb->leader = false;
-    cb->cv.notify_all();
-    lk.unlock();
-    status = run();
-    lk.lock();
-    ++cb->groups[std::min<size_t>(group.size(), 16)];
-    for (qil_sweep_request* r : group) {
-        r->status = status;
-        r->launched = true;
-    }
-    cb->cv.notify_all();
-    return status;
-}
 
 // ---------------------------------------------------------------- timers / profile
 extern "C" int qil_timer_start(qil_context* ctx) {
@@ -625,17 +534,6 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     for (int k : inline_slots) drive(k);
     for (auto& t : threads) t.join();
     home->lending = false;
-    if (batch_debug) {
-        fprintf(stderr, "[batch] combined sweeps by group size:");
-        for (int g = 1; g <= 16; ++g)
-            if (home->combiner.groups[g]) fprintf(stderr, " %d:%lld", g, home->combiner.groups[g]);
-        fprintf(stderr, "; leaders waited %.1f ms in total (waits < 20 us: %lld, < 100: %lld, < 300: %lld, < 1000: %lld, longer: %lld, timed out: %lld)\n",
-                home->combiner.waited_us / 1e3, home->combiner.wait_hist[0], home->combiner.wait_hist[1], home->combiner.wait_hist[2],
-                home->combiner.wait_hist[3], home->combiner.wait_hist[4], home->combiner.wait_hist[5]);
-        for (auto& g : home->combiner.wait_hist) g = 0;
-        for (auto& g : home->combiner.groups) g = 0;
-        home->combiner.waited_us = 0;
-    }
     // every stream of the batch is idle: the chains the workers hold (moved there or created there), what is left of the
     // lent blocks and the workers' caches go (back) to the home context
     for (int k = 1; k < nw; ++k) {

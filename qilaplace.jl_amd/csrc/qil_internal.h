@@ -42,36 +42,6 @@ int qil_fail(int code, const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- context
-// One operand of a batched Jacobi block-round launch (device-side table, see jacobi_block_round_nov in qil_linalg.hip).
-struct qil_round_item {
-    void* X;
-    long long ldx;
-    int k, nblk;
-    int* flag;
-    const double* negl;
-    double tol;
-};
-// A chain's request for one sweep over its operand, and the rendezvous that turns the requests of the chains of a running
-// batch into ONE launch train per kernel class (qil_combined_sweep).
-struct qil_sweep_request {
-    qil_round_item item;
-    int cls = 0;                       // kernel class (dtype, block shape): only requests of one class share launches
-    struct qil_context* ctx = nullptr;
-    bool taken = false;                // a leader has put it into its group (it is no longer in `pending`)
-    bool launched = false;
-    int status = 0;
-};
-struct qil_sweep_combiner {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<qil_sweep_request*> pending;
-    std::map<int, int> sweepers;       // per kernel class: chains currently inside a sweep loop
-    bool leader = false;
-    long long groups[17] = {};         // launches by group size (QIL_BATCH_DEBUG)
-    double waited_us = 0;
-    long long wait_hist[6] = {};       // < 20, < 100, < 300, < 1000, < 2000 us, timed out
-};
-
 struct qil_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -124,8 +94,6 @@ struct qil_context {
     std::multimap<size_t, void*> lend_blocks;        // guarded by pool_mutex
     size_t lend_cached = 0;                          // bytes in lend_blocks (guarded by pool_mutex)
     std::mutex pool_mutex;
-    qil_sweep_combiner combiner;                     // home: rendezvous of the batch's chains (qil_combined_sweep)
-    hipEvent_t sweep_ready = nullptr, sweep_done = nullptr;
 };
 
 int qil_ctx_activate(qil_context* ctx);  // hipSetDevice
@@ -155,17 +123,6 @@ int qil_run_batch(struct qil_chain* const* items, int64_t nb, const std::functio
 // bound to a worker when the batch ends -- moved there by place(j, slot) beforehand or created by fn -- returns to home.
 int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int64_t, qil_context*)>& place,
                      const std::function<int(int64_t, qil_context*)>& fn);
-// Sweeps of independent chains in one launch train.  A chain of a running batch calls this once per sweep instead of
-// launching its block rounds itself: the first chain to arrive waits (bounded: until every chain of its kernel class that
-// is inside a sweep loop has arrived -- the others are riding a train launched earlier and come back when it ends -- at most
-// QIL_BATCH_COMBINE_WAIT_US, default 50 us) and launches the rounds for all requests of its kernel class with one operand
-// per gridDim.y slice -- `launch(dev_items, count, max_nblk)` runs the caller's own round loop on ITS stream, ordered after
-// every participant's stream by events, and every participant's stream is ordered after the train.  16 workgroups per
-// operand become 16 x count.  OFF unless QIL_BATCH_COMBINE=1 (measured: no net gain, see qil_context.hip).
-// qil_sweep_combiner_of returns the combiner for ctx if it is part of a running batch (and combining is on), else nullptr.
-qil_sweep_combiner* qil_sweep_combiner_of(qil_context* ctx);
-int qil_combined_sweep(qil_context* ctx, qil_sweep_combiner* cb, qil_sweep_request& req,
-                       const std::function<int(const qil_round_item*, int, int)>& launch);
 // hand a live pool block of `from` to `to` (bookkeeping only; the caller orders the streams)
 void qil_ctx_transfer(qil_context* from, qil_context* to, void* p);
 // hand a whole chain (its site blocks and its registration) to another context of the same device

@@ -314,19 +314,19 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     const bool can_split = bt.count == 1 || (ldc == m && bt.c_bs == m * n && !bt.cmap);
     // few output tiles + long K (projections Q^H P, sketches of skinny panels): split K over the chip
     int splits = 1;
-    static const long long split_min_k = getenv("QIL_GEMM_SPLIT_MIN_K") ? atoll(getenv("QIL_GEMM_SPLIT_MIN_K")) : 1024;   // tuning aid (512: exact compress! of the bond-1008 product 572 -> 534 ms, compress! 512 -> 256 330 -> 355 ms)
+    static const long long split_min_k = 1024;   // (measured; 512: exact compress! of the bond-1008 product 572 -> 534 ms, compress! 512 -> 256 330 -> 355 ms)
     // ... and from K = 512 when the output is at most 8 tiles (the CGS2 projections Q^H P of 1008-row complex panels:
     // exact compress! of the bond-1008 product 476 -> 445 ms; splitting every K >= 512 product costs the small chains 5 %)
     if (can_split && tiles * bt.count < 128 && (k >= split_min_k || (k >= 512 && tiles * bt.count <= 8)))
         splits = (int)std::min<long long>(std::min<long long>(k / 256, 512 / (tiles * bt.count)), 64);
     // one to four output tiles (complex: a 64 x 64 tile is 0.85 us of MFMA per 16 k on ITS ONE CU -- the projections and
     // environment products of the truncation chains spend 20-40 us there): slices of 64 k from K = 128 on
-    static const long long tiny_k = getenv("QIL_GEMM_TINY_SPLIT_K") ? atoll(getenv("QIL_GEMM_TINY_SPLIT_K")) : 128;   // tuning aid; 0 = off (fused apply-compress 263 -> 244 ms, exact route 439 -> 417 ms)
+    static const long long tiny_k = 128;   // (0 = off: fused apply-compress 263 -> 244 ms, exact route 439 -> 417 ms)
     if (tiny_k > 0 && can_split && tiles * bt.count <= 4 && k >= tiny_k)
         splits = std::max<int>(splits, (int)std::min<long long>(k / 64, 32));
     // one wave of workgroups or less and a long K (the encoder's 16384 x 133 x 16384 sketches: 256 tiles): two to four K
     // slices fill the second workgroup slot of every CU (37.7 -> see DESIGN 3.4)
-    static const bool fill_split = !(getenv("QIL_GEMM_FILL_SPLIT") && atoi(getenv("QIL_GEMM_FILL_SPLIT")) == 0);   // tuning aid
+    static const bool fill_split = true;
     if (fill_split && splits < 2 && can_split && tiles * bt.count >= 128 && tiles * bt.count <= 384 && k >= 4096)
         splits = (int)std::min<long long>(4, (767 / (tiles * bt.count)));
     if (splits < 2) splits = 1;
@@ -344,7 +344,7 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
         ldo = m;
     }
     // narrow outputs: neighbouring workgroups share the same rows of A (served from L2 / Infinity Cache)
-    static const bool xcd_order = !(getenv("QIL_GEMM_XCD") && atoi(getenv("QIL_GEMM_XCD")) == 0);   // tuning aid
+    static const bool xcd_order = true;
     const int col_fastest = (tiles_n <= 8 ? 1 : 0) | (xcd_order ? 0 : 2);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits), dim3(256), lds, ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo,
                        kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,
@@ -374,18 +374,12 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
     constexpr bool CX = sizeof(T) == 16;
 #define QIL_GEMM_GO(BM, BN, WM, WN, PIPE) \
     return gemm_launch<T, BM, BN, WM, WN, PIPE>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch)
-    static const int force = getenv("QIL_GEMM_CFG") ? atoi(getenv("QIL_GEMM_CFG")) : -1;   // tuning aid
     if constexpr (CX) {
-        if (force == 1) QIL_GEMM_GO(64, 64, 32, 32, false);
         QIL_GEMM_GO(64, 64, 32, 32, true);      // pipelined: equal on big squares, 56 vs 45 TFLOP/s on 64 x 16384 x 8192
     } else {
-        if (force == 0) QIL_GEMM_GO(64, 64, 32, 32, true);
-        if (force == 1) QIL_GEMM_GO(64, 64, 32, 32, false);
-        if (force == 3) QIL_GEMM_GO(128, 128, 64, 64, true);
         // 97..144 output columns (RSVD sketches with k + p = 133): one 144-wide tile reads A ONCE and pads
         // 133 -> 144 columns instead of 192
         // one 144-wide tile per row panel; 64 rows (one 16 x 144 strip per wave) fit 2 waves/SIMD, 128 rows do not
-        if (force == 4 && n > 96 && n <= 144) QIL_GEMM_GO(128, 144, 32, 144, true);
         if (m >= 256 && n > 96 && n <= 144) QIL_GEMM_GO(64, 144, 16, 144, true);
         // big outputs: 128 x 128 tiles, 4 x 4 MFMA tiles per wave (two fragment reads per MFMA step pair, 64 MFMAs
         // between barriers) at 2 waves/SIMD -- 59 vs 52 TFLOP/s for the 128 x 64 tile at 4096^3
@@ -1367,7 +1361,7 @@ int gs_fused_launch(qil_context* ctx, unsigned nwg, T* A, long long lda, long lo
                     const double* ref_norm, long long chunk_rows) {
     const long long rows = chunk_rows > 0 ? std::min(chunk_rows, mtot) : mtot;
     const size_t lds = ((size_t)2 * (n + (n & 1)) + (size_t)(rows | 1) * n) * sizeof(T);
-    static const bool use_lds = !(getenv("QIL_QR_LDS") && atoi(getenv("QIL_QR_LDS")) == 0);   // tuning aid
+    static const bool use_lds = true;
     if (use_lds && lds <= 150 * 1024) {
         static bool attr = false;
         if (!attr) {
@@ -1406,10 +1400,10 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
 constexpr int BJ_B = 32;
 constexpr int BJ_W = 2 * BJ_B;
 
-// TWO_SIDED: the visit's sweep is run as two-sided rotations on G itself (G <- R^H G R, angles from the current
-// 2 x 2 blocks) instead of a Cholesky factorisation followed by a one-sided sweep on L^H: no factorisation, no dot
-// products, three short phases per round.
-template <class T, bool TWO_SIDED>
+// The visit's sweep is run as two-sided rotations on G itself (G <- R^H G R, angles from the current 2 x 2 blocks): no
+// factorisation, no dot products, three short phases per round.  (The first version -- Cholesky G = L L^H followed by a
+// one-sided sweep on L^H -- converged in the same number of block sweeps at ~1.7x the cost per visit and was removed.)
+template <class T>
 __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* __restrict__ Jm, double tol,
                                                     int max_sweeps, int* __restrict__ flag,
                                                     const int* __restrict__ big_second,
@@ -1419,7 +1413,7 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
     T* Aw = reinterpret_cast<T*>(bj_smem);
     T* Vw = Aw + N * LD;
     __shared__ double d0[N], lam[N];
-    __shared__ int s_rot, s_any, dest[N];
+    __shared__ int s_any, dest[N];
     const int tid = threadIdx.x;
     const T* G = Gm + (long long)blockIdx.x * N * N;
     T* J = Jm + (long long)blockIdx.x * N * N;
@@ -1452,7 +1446,7 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
         }
         return;
     }
-    if (TWO_SIDED) {
+    {
         __shared__ double rc[N / 2], rs[N / 2], rpr[N / 2], rpi[N / 2];
         __shared__ int rp[N / 2], rq[N / 2];
         for (int t = tid; t < N * N; t += 512) {
@@ -1506,7 +1500,7 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
                     if (sn != 0.0) {
                         constexpr int NR = N / 16;
                         T x[NR], y[NR], u[NR], w[NR];
-#pragma unroll
+    #pragma unroll
                         for (int t = 0; t < NR; ++t) {
                             const int r = lane + 16 * t;
                             x[t] = Aw[r + LD * p];
@@ -1514,7 +1508,7 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
                             u[t] = Vw[r + LD * p];
                             w[t] = Vw[r + LD * q];
                         }
-#pragma unroll
+    #pragma unroll
                         for (int t = 0; t < NR; ++t) {
                             const int r = lane + 16 * t;
                             rotate_pair(x[t], y[t], c, sn, pr, pi);
@@ -1533,13 +1527,13 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
                     if (sn != 0.0) {
                         constexpr int NR = N / 16;
                         T x[NR], y[NR];
-#pragma unroll
+    #pragma unroll
                         for (int t = 0; t < NR; ++t) {
                             const int cc = lane + 16 * t;
                             x[t] = Aw[p + LD * cc];
                             y[t] = Aw[q + LD * cc];
                         }
-#pragma unroll
+    #pragma unroll
                         for (int t = 0; t < NR; ++t) {
                             const int cc = lane + 16 * t;
                             rotate_pair(x[t], y[t], c, sn, pr, -pi);
@@ -1552,58 +1546,6 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
             }
         }
         if (tid < N) lam[tid] = reinterpret_cast<const double*>(&Aw[tid + LD * tid])[0];
-        __syncthreads();
-    } else {
-    // Cholesky of the (semi-definite) Gram matrix, lower triangle, right-looking, ONE barrier per step: the
-        // trailing update uses the UNSCALED column j and 1 / pivot, the columns are scaled by 1 / sqrt(pivot) only
-        // when L^H is written out.  A pivot at rounding level of its original diagonal closes that column
-        // (dependent / zero / padding columns).
-        for (int j = 0; j < N; ++j) {
-            __syncthreads();
-            const double d = reinterpret_cast<const double*>(&Aw[j + LD * j])[0];
-            const bool dead = !(d > 1e-14 * d0[j]);
-            const double inv = dead ? 0.0 : 1.0 / d;
-            if (tid == 0) lam[j] = dead ? 0.0 : d;
-            const int rem = N - 1 - j;
-            for (int t = tid; t < rem * rem; t += 512) {
-                const int i = j + 1 + t % rem, k = j + 1 + t / rem;
-                if (k <= i)
-                    Aw[i + LD * k] = sub_t(Aw[i + LD * k], scale_t(fma_t(Aw[i + LD * j], conj_t(Aw[k + LD * j]), T{}), inv));
-            }
-        }
-        __syncthreads();
-        // M = L^H (upper triangular): M^H M = G, so the right rotations that orthogonalise M's columns diagonalise G
-        for (int t = tid; t < N * N; t += 512) {
-            const int r = t % N, c = t / N;
-            T v{};
-            if (r < c) {
-                v = scale_t(conj_t(Aw[c + LD * r]), lam[r] > 0 ? rsqrt(lam[r]) : 0.0);
-            } else if (r == c) {
-                reinterpret_cast<double*>(&v)[0] = sqrt(lam[r]);
-            }
-            Vw[r + LD * c] = v;
-        }
-        __syncthreads();
-        for (int t = tid; t < N * N; t += 512) {
-            const int r = t % N, c = t / N;
-            Aw[r + LD * c] = Vw[r + LD * c];
-        }
-        __syncthreads();
-        for (int t = tid; t < N * N; t += 512) {
-            const int r = t % N, c = t / N;
-            T v{};
-            if (r == c) reinterpret_cast<double*>(&v)[0] = 1.0;
-            Vw[r + LD * c] = v;
-        }
-        __threadfence_block();
-        __syncthreads();
-        jacobi_sweeps<T, 16, 512>(Aw, LD, N, Vw, LD, N, 1e-15, max_sweeps, &s_rot);
-        __syncthreads();
-        if (tid < N) {
-            double v = 0;
-            for (int r = 0; r < N; ++r) v += abs2_t(Aw[r + LD * tid]);
-            lam[tid] = v;
-        }
         __syncthreads();
     }
     // de Rijk ordering at block level: the rotated columns leave sorted by norm (= eigenvalue of G), the
@@ -1691,15 +1633,12 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
     const size_t lds = (size_t)2 * BJ_W * (BJ_W + 1) * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bj_pair_evd<T, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bj_pair_evd<T, true>),
+        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bj_pair_evd<T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int opH = sizeof(T) == 16 ? 2 : 1;
-    static const int inner_sweeps = getenv("QIL_BJ_INNER") ? atoi(getenv("QIL_BJ_INNER")) : 1;   // tuning aids
-    static const bool two_sided = !(getenv("QIL_BJ_TWO_SIDED") && atoi(getenv("QIL_BJ_TWO_SIDED")) == 0);
+    static const int inner_sweeps = 1;
     gemm_batch bg, bu;
     bg.count = np;
     bg.a_bs = bg.b_bs = (long long)BJ_W * ldx;
@@ -1714,14 +1653,9 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
         for (int r = 0; r < nr && status == QIL_OK; ++r) {
             status = gemm_dispatch<T>(ctx, opH, 0, BJ_W, BJ_W, rows, Xc, ldx, Xc, ldx, static_cast<T*>(gbuf), BJ_W, bg);
             if (status != QIL_OK) break;
-            if (two_sided)
-                hipLaunchKernelGGL((bj_pair_evd<T, true>), dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
-                                   static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
-                                   static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np, negligible);
-            else
-                hipLaunchKernelGGL((bj_pair_evd<T, false>), dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
-                                   static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
-                                   static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np, negligible);
+            hipLaunchKernelGGL((bj_pair_evd<T>), dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
+                               static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
+                               static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np, negligible);
             bu.cmap = static_cast<const int*>(cmapd) + (size_t)r * nb;
             status = gemm_dispatch<T>(ctx, 0, 0, rt, BJ_W, BJ_W, Xc, ldx, static_cast<const T*>(jbuf), BJ_W, Xn, ldx, bu);
             std::swap(Xc, Xn);
@@ -1791,7 +1725,7 @@ __global__ __launch_bounds__(256) void offdiag_max(const T* __restrict__ G, long
 template <class T>
 int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long long ldq, T* R, long long ldr, bool dbg,
                        bool* orthonormal = nullptr) {
-    static const bool reorth = !(getenv("QIL_SVD_REORTH") && atoi(getenv("QIL_SVD_REORTH")) == 0);   // tuning aid
+    static const bool reorth = true;
     if (orthonormal) *orthonormal = true;
     if (!reorth || n < 2) return QIL_OK;
     void *gbuf = nullptr, *mx = nullptr;
@@ -2217,34 +2151,11 @@ int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, do
 // cross rounds group `grp` keeps column p = grp of the lower block in registers over all BB inner rounds; only its partner
 // travels through LDS.  (Measured, tools/micro/jacobi_round_cost.hip, k = 256 f64: the predicated version spent 1.07 us per
 // inner round -- ~40 exec-mask branches -- of a 12.1 us round.)
-// Batched form (items != nullptr, gridDim.y operands of one kernel class -- independent chains of a batch whose sweeps the
-// combiner of qil_context.hip has put into one launch): workgroup (x, y) takes its operand from items[y] and leaves when that
-// operand has fewer block pairs than the grid is wide.  The arithmetic is the single-operand kernel's, bit for bit.
-template <class T, int BB, int KM, int G, bool AP, bool PROF = false, bool BATCHED = false>
-__global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__ A_, long long lda_, int m_, int n_, int nb_,
-                                                                 int round, double tol_, int* __restrict__ rotated_,
-                                                                 const double* __restrict__ negligible_,
-                                                                 long long* __restrict__ prof = nullptr,
-                                                                 const qil_round_item* __restrict__ items = nullptr) {
-    T* __restrict__ A = A_;
-    long long lda = lda_;
-    int m = m_, n = n_, nb = nb_;
-    int* __restrict__ rotated = rotated_;
-    const double* __restrict__ negligible = negligible_;
-    double tol = tol_;
-    if constexpr (BATCHED) {                        // its own instantiation: the single-operand code stays as it was
-        const qil_round_item it = items[blockIdx.y];
-        if ((int)blockIdx.x >= it.nblk / 2 || round >= it.nblk - 1) return;   // narrower operand: fewer pairs, fewer rounds
-        // (as a run-time branch of the one kernel this cost the complex single-operand path 12-16 %: its register arrays
-        // went to scratch)
-        A = static_cast<T*>(it.X);
-        lda = it.ldx;
-        m = n = it.k;
-        nb = it.nblk;
-        rotated = it.flag;
-        negligible = it.negl;
-        tol = it.tol;
-    }
+template <class T, int BB, int KM, int G, bool AP, bool PROF = false>
+__global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__ A, long long lda, int m, int n, int nb,
+                                                                 int round, double tol, int* __restrict__ rotated,
+                                                                 const double* __restrict__ negligible,
+                                                                 long long* __restrict__ prof = nullptr) {
     // PROF (tools/micro/jacobi_round_cost.hip only): shader-clock stamps start / staged / rotated / stored + the 100 MHz clock
     long long st[5];
     if (PROF) {
@@ -2451,7 +2362,7 @@ constexpr size_t block_round_nov_lds() {
 
 template <class T, int BB, int KM, int G>
 int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nblk, int round, double tol, int* flag,
-                           const double* negl, const qil_round_item* items = nullptr, int count = 1) {
+                           const double* negl) {
     constexpr size_t lds = block_round_nov_lds<T, BB, KM, G>();
     static_assert(lds <= 156 * 1024, "column blocks must fit the LDS");
     static bool attr = false;
@@ -2461,23 +2372,6 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
         QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr = true;
-    }
-    if (items) {
-        static bool battr = false;
-        if (!battr) {
-            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, true, false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, false, false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-            battr = true;
-        }
-        if (round == 0)
-            hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true, false, true>), dim3(nblk / 2, count), dim3(BB * G), lds,
-                               ctx->stream, X, ldx, k, k, nblk, round, tol, flag, negl, (long long*)nullptr, items);
-        else
-            hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, false, false, true>), dim3(nblk / 2, count), dim3(BB * G), lds,
-                               ctx->stream, X, ldx, k, k, nblk, round, tol, flag, negl, (long long*)nullptr, items);
-        return QIL_OK;
     }
     if (round == 0)
         hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
@@ -2899,9 +2793,8 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
                  T* SVh, long long ldsvh, double negl_rel, int* handled, double cert_cutoff) {
     *handled = 0;
     const long long k = std::min(p, q);
-    static const bool enabled = !(getenv("QIL_SVD_LEFT") && atoi(getenv("QIL_SVD_LEFT")) == 0);
-    if (!enabled || k < 17 || k >= 640) return QIL_OK;
-    static const long long fused_below = getenv("QIL_SVD_LEFT_MIN") ? atoll(getenv("QIL_SVD_LEFT_MIN")) : 49;   // tuning aid (97 -> 49: compress! chi 64 -> 32 31.6 -> 28 ms, 128 -> 64 52.6 -> 50 ms)
+    if (k < 17 || k >= 640) return QIL_OK;
+    static const long long fused_below = 49;   // (97 -> 49: compress! chi 64 -> 32 31.6 -> 28 ms, 128 -> 64 52.6 -> 50 ms)
     if (k < fused_below) {
         // small operands: the single-workgroup iteration of the general path (operand and V in LDS, no launches) wins
         // whenever it fits; where it does not (complex 2 chi x chi sites with chi > 64, long rows) that path falls back to V
@@ -2910,31 +2803,25 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         const size_t lds_av = (size_t)((rows | 1) * k + (k | 1) * k) * sizeof(T);
         if (lds_av <= 150 * 1024 && rows * k <= (1LL << 19)) return QIL_OK;
     }
-    // Block / group shape (QIL_SVD_LEFT_MODE = 64 | 32, tuning aid).  A sweep over n columns is n - 1 inner rounds of n / 2
-    // pairs whatever the blocking; an inner round is issue-bound on the wave that owns a pair, and every outer round pays a
-    // launch plus the staging of its columns.  Mode 64 (default): one wave per pair, blocks of 8 columns, 512 threads = two
-    // waves per SIMD hiding each other's LDS and dependent-issue latency.  Mode 32: two pairs per wave, blocks of 16
-    // columns (half the outer rounds, the rotation chain paid once per two pairs).
-    static const int mode = getenv("QIL_SVD_LEFT_MODE") ? atoi(getenv("QIL_SVD_LEFT_MODE")) : 64;
+    // Block / group shape.  A sweep over n columns is n - 1 inner rounds of n / 2 pairs whatever the blocking; an inner round
+    // is issue-bound on the wave that owns a pair, and every outer round pays a launch plus the staging of its columns: one
+    // wave per pair, blocks of 8 columns, 512 threads = two waves per SIMD hiding each other's LDS and dependent-issue
+    // latency.  (Two pairs per wave on 16-column blocks -- half the outer rounds, the rotation chain paid once per two pairs --
+    // was measured equal in r02, 126 vs 124 ms, and removed.)
     const int km = (int)((k + 63) / 64);             // rows per lane, one wave per column
-    int G = 64, bb = 8;
+    int bb = 8;
     // Gram-matrix block rounds on the matrix cores (gram_block_round) whenever a block pair and its Gram workspace fit one
-    // CU's LDS: 2 x 16 columns, else 2 x 8; inside a batch whose chains combine their sweeps the vector rounds stay
+    // CU's LDS: 2 x 16 columns, else 2 x 8
     // (measured, compress! on 24 sites: f64 chi 256 -> 128 69.9 ms with the Gram rounds, 70.4 ms with the vector rounds; c64 107
     // against 103 ms -- a Gram round of 2 x 16 columns takes 20 us where two vector rounds of 2 x 8 take 18, both bound by the
     // latency of the rotation rounds, tools/micro/gram_round_cost.hip -- so complex operands keep the vector rounds)
     static const int gram = getenv("QIL_SVD_GRAM") ? atoi(getenv("QIL_SVD_GRAM")) : 1;   // 0 = vector-ALU block rounds, 2 = Gram rounds for c64 too
     int gbb = 0;
-    if ((gram == 2 || (gram == 1 && sizeof(T) == 8)) && !qil_sweep_combiner_of(ctx)) {
+    if (gram == 2 || (gram == 1 && sizeof(T) == 8)) {
         if (gram_round_lds<T, 16>((int)k) <= 160 * 1024) gbb = 16;
         else if (gram_round_lds<T, 8>((int)k) <= 160 * 1024) gbb = 8;
     }
-    if (mode == 32 && (size_t)32 * km * 64 * sizeof(T) + 256 <= 150 * 1024) {
-        G = 32;
-        bb = 16;
-    } else if (!gbb && (size_t)16 * km * 64 * sizeof(T) + 128 > 150 * 1024) {
-        return QIL_OK;
-    }
+    if (!gbb && (size_t)16 * km * 64 * sizeof(T) + 128 > 150 * 1024) return QIL_OK;
     if (gbb) bb = gbb;
     const bool dbg = getenv("QIL_SVD_DEBUG") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -2947,7 +2834,6 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         t_prev = now;
     };
     const bool tall = p >= q;
-    static const bool second_qr = getenv("QIL_SVD_LEFT_QR2") && atoi(getenv("QIL_SVD_LEFT_QR2")) == 1;
     const int cj = sizeof(T) == 16 ? 2 : 1;
     const unsigned gk = (unsigned)std::min<long long>((k * k + 255) / 256, 65536);
     void *rbuf = nullptr, *xbuf = nullptr, *bh = nullptr, *flag = nullptr, *nrm = nullptr, *negl = nullptr, *wbuf = nullptr;
@@ -2986,8 +2872,8 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         // spectra the two orientations need the same sweeps and the second QR (~0.8 ms at 256 columns) is not worth it.  The
         // grading shows in R's diagonal: mean |r_ii|^2 against min |r_ii|^2 (measured on the truncated sites of the same
         // sweep, ratio ~1e5: 13 sweeps on R, 9 after the second QR).
-        bool qr2 = second_qr;
-        static const double grade = getenv("QIL_SVD_LEFT_QR2_GRADE") ? atof(getenv("QIL_SVD_LEFT_QR2_GRADE")) : 1e3;   // tuning aid; 0 = never (1e3: compress! chi 256 -> 128 85.8 -> 73.4 ms, 512 -> 256 211 -> 197 ms, complex 112 -> 104 ms, exact compress!(apply) 389 -> 348 ms; 1e5 / 1e8: 77 / 75 ms)
+        bool qr2 = false;
+        static const double grade = 1e3;   // (0 = never; 1e3: compress! chi 256 -> 128 85.8 -> 73.4 ms, 512 -> 256 211 -> 197 ms, complex 112 -> 104 ms, exact compress!(apply) 389 -> 348 ms; 1e5 / 1e8: 77 / 75 ms)
         if (!qr2 && grade > 0.0) {
             void* st = nullptr;
             constexpr int NB = 16;
@@ -3005,7 +2891,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             // ... but not a numerically rank-deficient one (every product bond before its truncation: min |r_ii| at rounding
             // level): its null directions are set aside by the negligible-column rule, nothing crawls, and the second QR of
             // a deficient factor only costs (zT MPO final compression 137 -> 167 ms with it)
-            static const double grade_max = getenv("QIL_SVD_LEFT_QR2_GRADE_MAX") ? atof(getenv("QIL_SVD_LEFT_QR2_GRADE_MAX")) : 1e24;   // tuning aid
+            static const double grade_max = 1e24;
             qr2 = std::isfinite(fro2) && fro2 > grade * (double)k * dmin && fro2 < grade_max * (double)k * dmin;
             if (dbg) fprintf(stderr, "[svd-left] %lld x %lld: mean / min |r_ii|^2 = %.3g -> %s\n", p, q, fro2 / ((double)k * std::max(dmin, 1e-300)), qr2 ? "second QR" : "rotate R");
         }
@@ -3072,54 +2958,11 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     const double tol = std::max(1e-15, 4.0 * 1.1e-16 * std::sqrt((double)k));
     const int nblk = (int)(((k + bb - 1) / bb + 1) / 2 * 2);
     int sweeps = 0;
-    // inside a batch the sweeps of the chains go through the combiner: one launch train for all operands of this kernel class
-    qil_sweep_combiner* const cb = qil_sweep_combiner_of(ctx);
-    const int cls = (int)sizeof(T) * 1000000 + G * 10000 + bb * 100 + km;
-    struct sweeper_scope {
-        qil_sweep_combiner* cb;
-        int cls;
-        sweeper_scope(qil_sweep_combiner* c, int k) : cb(c), cls(k) {
-            if (cb) {
-                std::lock_guard<std::mutex> g(cb->mu);
-                ++cb->sweepers[cls];
-            }
-        }
-        void leave() {                                  // right after the last sweep: the others must not wait for this chain
-            if (cb) {
-                std::lock_guard<std::mutex> g(cb->mu);
-                --cb->sweepers[cls];
-                cb->cv.notify_all();
-                cb = nullptr;
-            }
-        }
-        ~sweeper_scope() { leave(); }
-    } sweeping(cb, cls);
-    // the rounds of one sweep: over this chain's operand alone, or (items) over `count` operands of the class
-    auto launch_rounds = [&](const qil_round_item* items, int count, int nblk_max) -> int {
-        for (int round = 0; round < nblk_max - 1; ++round) {
-#define QIL_NOV(BBv, KMv, Gv) QIL_TRY((launch_block_round_nov<T, BBv, KMv, Gv>(ctx, X, k, (int)k, items ? nblk_max : nblk, round, tol, (int*)flag, (const double*)negl, items, count)))
-            if (G == 32) {
-                if constexpr (sizeof(T) == 8) {
-                    switch (km) {
-                        case 1: QIL_NOV(16, 2, 32); break;
-                        case 2: QIL_NOV(16, 4, 32); break;
-                        case 3: QIL_NOV(16, 6, 32); break;
-                        case 4: QIL_NOV(16, 8, 32); break;
-                        case 5: QIL_NOV(16, 10, 32); break;
-                        case 6: QIL_NOV(16, 12, 32); break;
-                        case 7: QIL_NOV(16, 14, 32); break;
-                        case 8: QIL_NOV(16, 16, 32); break;
-                        default: QIL_NOV(16, 18, 32); break;
-                    }
-                } else {
-                    switch (km) {
-                        case 1: QIL_NOV(16, 2, 32); break;
-                        case 2: QIL_NOV(16, 4, 32); break;
-                        case 3: QIL_NOV(16, 6, 32); break;
-                        default: QIL_NOV(16, 8, 32); break;
-                    }
-                }
-            } else {
+    // the rounds of one sweep
+    auto launch_rounds = [&]() -> int {
+        for (int round = 0; round < nblk - 1; ++round) {
+#define QIL_NOV(BBv, KMv, Gv) QIL_TRY((launch_block_round_nov<T, BBv, KMv, Gv>(ctx, X, k, (int)k, nblk, round, tol, (int*)flag, (const double*)negl)))
+            {
                 switch (km) {
                     case 1: QIL_NOV(8, 1, 64); break;
                     case 2: QIL_NOV(8, 2, 64); break;
@@ -3181,21 +3024,13 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     } else
     for (; sweeps < 40; ++sweeps) {
         QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
-        if (cb) {
-            qil_sweep_request req;
-            req.item = qil_round_item{X, k, (int)k, nblk, (int*)flag, (const double*)negl, tol};
-            req.cls = cls;
-            QIL_TRY(qil_combined_sweep(ctx, cb, req, launch_rounds));
-        } else {
-            QIL_TRY(launch_rounds(nullptr, 1, nblk));
-        }
+        QIL_TRY(launch_rounds());
         int hv[2] = {0, 0};
         QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         QIL_HIP(hipStreamSynchronize(ctx->stream));
         if (dbg) fprintf(stderr, "[svd-left] sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[0], hv[1]);
         if (!hv[1]) break;
     }
-    sweeping.leave();
     lap("sweeps");
     hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)k), dim3(256), 0, ctx->stream, (const T*)X, k, k, (double*)nrm);
     std::vector<double> sig((size_t)k);
@@ -3282,17 +3117,17 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     // tall-skinny: Wk = Q R, rotate R instead.  Large column counts (block path): always, and rotate R^H --
     // the rows of a triangular factor are far closer to orthogonal than its columns, which saves sweeps
     // (the classical preconditioning of one-sided Jacobi); then R^H = L S V^H gives Wk = (Q V) S L^H.
-    static const long long bj_min = getenv("QIL_BJ_MIN") ? atoll(getenv("QIL_BJ_MIN")) : 640;   // tuning aids (crossover with the in-LDS block rounds: 600-700 columns)
-    static const bool bj_rt = !(getenv("QIL_BJ_RT") && atoi(getenv("QIL_BJ_RT")) == 0);
+    static const long long bj_min = 640;   // (crossover with the in-LDS block rounds: 600-700 columns)
+    static const bool bj_rt = true;
     // mid-size operands too: neutral on random matrices, but graded / low-rank spectra -- what truncation sees after an
     // apply -- need 2-4x fewer sweeps (512 x 256 graded: 36 -> 9 ms including the QR)
-    static const long long rt_min = getenv("QIL_RT_MIN") ? atoll(getenv("QIL_RT_MIN")) : 97;
+    static const long long rt_min = 97;
     const bool blocked = cols >= bj_min;
     bool rt = (blocked && bj_rt) || cols >= rt_min;
     T* Q = nullptr;
     long long ldq = 0, qrows = 0;
     void *rbuf = nullptr, *rtbuf = nullptr, *abuf = nullptr;
-    static const long long qr_ratio = getenv("QIL_SVD_QR_RATIO") ? atoll(getenv("QIL_SVD_QR_RATIO")) : 8;
+    static const long long qr_ratio = 8;
     if ((rows >= qr_ratio * cols && rows >= 512) || rt) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rbuf));
         QIL_TRY(qr_impl<T>(ctx, rows, cols, Wk, ldw, static_cast<T*>(rbuf), cols));
@@ -3342,8 +3177,8 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     const double tol = std::max(1e-15, 4.0 * 1.1e-16 * std::sqrt((double)rows));
     const size_t lds_a = (size_t)((rows | 1) * cols) * sizeof(T);
     const size_t lds_av = lds_a + (size_t)((cols | 1) * cols) * sizeof(T);
-    static const bool a_in_lds = !(getenv("QIL_SVD_A_LDS") && atoi(getenv("QIL_SVD_A_LDS")) == 0);   // tuning aids
-    static const bool fused_global = getenv("QIL_SVD_FUSED_GLOBAL") && atoi(getenv("QIL_SVD_FUSED_GLOBAL")) == 1;
+    static const bool a_in_lds = true;
+    static const bool fused_global = false;
     // one workgroup for the whole iteration only while (at least) A lives in LDS; a single workgroup working out of
     // L2 is slower than the tournament launches, which spread the pairs over the chip
     if (ncol <= 96 && rows * cols <= (1LL << 19) &&
@@ -3396,11 +3231,11 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         const int nn = (int)nj, npad = nn + (nn & 1);
         // in-LDS block rounds when 2 BB columns of A and V fit one CU's LDS (not after the GEMM-shaped block sweeps:
         // their fallback keeps the scalar rounds)
-        static const bool block_rounds = !(getenv("QIL_SVD_BLOCK_ROUNDS") && atoi(getenv("QIL_SVD_BLOCK_ROUNDS")) == 0);
+        static const bool block_rounds = true;
         int bb = 0;
         if (block_rounds && !blocked && rows <= (1 << 20)) {
             const size_t per_col = (size_t)((rows | 1) + (cols | 1)) * sizeof(T);
-            static const int bb_max = getenv("QIL_SVD_BB") ? atoi(getenv("QIL_SVD_BB")) : 8;   // tuning aid
+            static const int bb_max = 8;
             if (bb_max >= 8 && 16 * per_col <= 150 * 1024) bb = 8;
             else if (8 * per_col <= 150 * 1024) bb = 4;
         }
@@ -3440,7 +3275,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
             QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             QIL_HIP(hipStreamSynchronize(ctx->stream));
             if (getenv("QIL_SVD_DEBUG")) fprintf(stderr, "[svd] scalar sweep %d (cols %lld): rotated=%d above-quadratic=%d\n", sweep, nj, hv[0], hv[1]);
-            static const bool early = !(getenv("QIL_JACOBI_EARLY") && atoi(getenv("QIL_JACOBI_EARLY")) == 0);   // tuning aid
+            static const bool early = true;
             if (!(early ? hv[1] : hv[0])) break;   // nothing rotated, or only pairs already below the quadratic-phase level
         }
         hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)nj), dim3(256), 0, ctx->stream, Wk, ldw, rows,
@@ -3647,7 +3482,7 @@ __global__ __launch_bounds__(256) void tsqr_apply_q2(T* __restrict__ P, long lon
 template <class T>
 int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, long long ldr,
                const double* ref_norm) {
-    static const long long min_chunk = getenv("QIL_TSQR_MIN_CHUNK") ? atoll(getenv("QIL_TSQR_MIN_CHUNK")) : 512;
+    static const long long min_chunk = 512;
     const long long chunk = std::max<long long>(min_chunk, (m / 512 + 255) / 256 * 256);
     const long long nch = (m + chunk - 1) / chunk;
     void *rs = nullptr, *r2 = nullptr;
@@ -3674,8 +3509,8 @@ int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, 
 //     spread over the chip by the GEMMs and the launch count drops from ~5 n to ~7 n / 16.
 template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
-    static const long long TALL = getenv("QIL_TSQR_MIN_ROWS") ? atoll(getenv("QIL_TSQR_MIN_ROWS")) : 2048;   // tuning aid
-    static const bool hh_panels = !(getenv("QIL_QR_HH") && atoi(getenv("QIL_QR_HH")) == 0);                   // tuning aid
+    static const long long TALL = 2048;
+    static const bool hh_panels = true;
     // Cholesky QR first where it pays (from a few panels on) and while it keeps succeeding on this context: a numerically
     // rank-deficient operand (product bonds, deficient sketches) costs the attempt a Gram product, a partial factorisation and
     // one synchronisation, so after a refusal the next attempts are skipped
@@ -3696,13 +3531,13 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     // not fit LDS (complex panels above ~580 rows): its 512-row chunks do, and a single workgroup factoring such a
     // panel out of L2 takes ~220-290 us instead of three short launches
     const bool panel16_fits = ((size_t)32 + (size_t)(m | 1) * 16) * sizeof(T) <= 150 * 1024;
-    static const long long tree_min = getenv("QIL_TSQR_NOFIT_ROWS") ? atoll(getenv("QIL_TSQR_NOFIT_ROWS")) : 640;        // tuning aid (1024 -> 600: exact compress! of the bond-1008 product 476 -> 455 ms, neutral elsewhere)
+    static const long long tree_min = 640;        // (1024 -> 600: exact compress! of the bond-1008 product 476 -> 455 ms, neutral elsewhere)
     const bool tree = m >= TALL || (!panel16_fits && m >= tree_min);
     // up to `fused_max` columns the CGS2 kernel does the whole factorisation in one launch; beyond, whenever a Householder
     // panel fits, one panel launch (n <= 32) or the blocked route below is faster even where the operand fits one CU's LDS
     // (128 x 64: 274 -> ~140 us -- the CGS2 kernel pays ~4 us per column, the Householder panel ~1.5; compress! chi 64 -> 32
     // 28 -> 24.5 ms, 128 -> 64 50 -> 42 ms; narrower panels measured equal within noise either way)
-    static const long long fused_max = getenv("QIL_QR_FUSED_MAX_N") ? atoll(getenv("QIL_QR_FUSED_MAX_N")) : 16;   // tuning aid
+    static const long long fused_max = 16;
     const bool hh_ok = hh_panels && !tree && n > fused_max && hh_panel_fits<T>(m, (int)std::min<long long>(n, 32));
     if (hh_ok && n <= 32) return hh_panel_launch<T>(ctx, A, lda, m, (int)n, R, ldr, (const double*)nullptr);
     if (n <= 16 || (fits_lds && !hh_ok)) {
@@ -3717,7 +3552,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
         return gs_fused_launch<T>(ctx, 1u, A, lda, m, (int)n, R, ldr, (const double*)nullptr, 0LL);
     }
     // panel width: 32 columns while a rows x 32 panel still fits one CU's LDS (half the launches), else 16
-    static const int pb_max = getenv("QIL_QR_PANEL") ? atoi(getenv("QIL_QR_PANEL")) : 32;   // tuning aid
+    static const int pb_max = 32;
     const bool wide = pb_max >= 32 && !tree && ((size_t)64 + (size_t)(m | 1) * 32) * sizeof(T) <= 150 * 1024;
     const int PB = wide ? 32 : 16;
     if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
@@ -3922,7 +3757,7 @@ int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t 
 
 int qil_dev_svd(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* U,
                 int64_t ldu, double* S_host, void* Vh, int64_t ldvh, double negligible_rel) {
-    static const bool skip = !(getenv("QIL_SVD_NEGLIGIBLE") && atoi(getenv("QIL_SVD_NEGLIGIBLE")) == 0);   // tuning aid
+    static const bool skip = true;
     if (!skip) negligible_rel = 0.0;
     if (dtype == QIL_C64)
         return svd_impl<c64>(ctx, m, n, (c64*)A, lda, (c64*)U, ldu, S_host, (c64*)Vh, ldvh, negligible_rel);

@@ -396,7 +396,7 @@ static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* db
     // Measured on a 256 x 256 grid scan (65,536 queries): bond 504 chains 0.40 s vs GEMM 0.09 s; bond 23
     // chains 4.9 ms vs GEMM 3.2 ms -- many queries favour the GEMM path at any bond dimension.  Few queries, 40
     // complex sites: bond 64 chains 0.37 ms vs GEMM 0.55 ms, bond 128 1.07 vs 0.81 ms, bond 512 9.2 vs 2.1 ms.
-    static const long long min_chi = getenv("QIL_COEFF_GEMM_MINCHI") ? atoll(getenv("QIL_COEFF_GEMM_MINCHI")) : 128;
+    static const long long min_chi = 128;
     if (nb >= 4 && (maxchi >= min_chi || (nb >= 1024 && maxchi >= 16))) {
         // Large bonds: all queries advance together, one f64-MFMA GEMM per site.  The site tensor is
         // read ONCE for the whole batch: T (nb x 2 chi_r) = V (nb x chi_l) * A_i (chi_l x 2 chi_r),
@@ -501,7 +501,7 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
         qil_mps_destroy(prod);
         return st;
     };
-    static const bool concurrent = !(getenv("QIL_SWEEP_CONCURRENT") && atoi(getenv("QIL_SWEEP_CONCURRENT")) == 0);   // tuning aid
+    static const bool concurrent = true;   // tuning aid
     if (concurrent && distinct && nw >= 4) {
         // every value's product + read-out is a chain of ~100 small launches: the values run concurrently on the context's
         // streams.  The operators move to their slot for the duration of the call (bookkeeping only), every slot reads its
@@ -563,7 +563,7 @@ extern "C" int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi,
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout));
     // Many queries on a wide product bond: the per-query chains (one workgroup each, vector ALU) give way to
     // batched MFMA GEMMs.  Tuning aid: QIL_LAZY_GEMM_MIN = smallest chi * D that takes the GEMM form.
-    static const long long lazy_min = getenv("QIL_LAZY_GEMM_MIN") ? atoll(getenv("QIL_LAZY_GEMM_MIN")) : 1024;   // measured crossover: 1.0 vs 2.0 ms at 1024, 0.85 vs 0.77 at 512
+    static const long long lazy_min = 1024;   // measured crossover: 1.0 vs 2.0 ms at 1024, 0.85 vs 0.77 at 512
     if (nb >= 16 && msz >= lazy_min) {
         int st = lazy_gemm_path(ctx, W, psi, nb, dbits, (c64*)dout);
         if (st == QIL_OK && hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)

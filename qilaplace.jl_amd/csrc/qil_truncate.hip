@@ -463,7 +463,7 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
         return QIL_OK;
     }
     void *Om = nullptr, *Y = nullptr, *Zq = nullptr, *Bt = nullptr;
-    const bool dbg = getenv("QIL_RSVD_DEBUG") != nullptr && m * n >= (getenv("QIL_RSVD_DEBUG_MIN") ? atoll(getenv("QIL_RSVD_DEBUG_MIN")) : (1LL << 24));
+    const bool dbg = getenv("QIL_RSVD_DEBUG") != nullptr && m * n >= ((1LL << 24));
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!dbg) return;
@@ -904,8 +904,8 @@ static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* 
     // contains the kept space -- 200 random flat-spectrum products and the oracle tests give the same final accuracy as with
     // 2 maxdim (r01 / early r02), in 0.16 instead of 0.24 s on the bench's product; 1.5 maxdim alone (oversampling 4 at
     // maxdim = 8) fails 2 of 200
-    const double zip_factor = getenv("QIL_ZIP_FACTOR") ? atof(getenv("QIL_ZIP_FACTOR")) : 1.5;
-    const int64_t zip_over = getenv("QIL_ZIP_OVERSAMPLE") ? atoll(getenv("QIL_ZIP_OVERSAMPLE")) : 16;
+    const double zip_factor = 1.5;
+    const int64_t zip_over = 16;
     if (zip_maxdim <= 0)
         zip_maxdim = maxdim > kNoCap / 2 ? kNoCap : std::max<int64_t>(maxdim + zip_over, (int64_t)std::ceil(zip_factor * (double)maxdim));
     const double cutoff = tol * tol / ((double)(N - 1) * sweeps);
@@ -1008,7 +1008,7 @@ static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* 
         t_prev = now;
     };
     // sketch matrix for capped bonds (one for the whole call: any sub-block of a Gaussian matrix is Gaussian)
-    static const bool sketch = !(getenv("QIL_ZIP_SKETCH") && atoi(getenv("QIL_ZIP_SKETCH")) == 0);   // tuning aid
+    static const bool sketch = true;   // tuning aid
     void* Om = nullptr;
     int64_t om_ld = 1;
     if (sketch && zip_maxdim < kNoCap / 2) {

@@ -1409,6 +1409,59 @@ def test_build_zt_mpo_batch_device_assisted(qil, pins):
         assert rel(qil.coefficient_batch(Wp * psi, bits), qil.coefficient_batch(Ws_ * psi, bits)) == 0.0
 
 
+def test_device_qft_builders(qil, pins):
+    """SURVEY 8f-1, the QFT half: build_qft_mpo (qft_transformer.jl:121-165) and the paired-register QFT chain of
+    build_zt_mpo (zt_transformer.jl:78-99) with every factorisation on the GPU (window MPO x MPO product +
+    zip_to_compress_mpo): dense operators against the oracle's builders for n <= 6 (1e-10), the reference's max-bond series
+    (mpo_bond_dim.jld2: QFT 2, 2, 4, 4, 7, 8, 8 for n = 2..8; zT 8, 8, 37, 39, 78 for n = 2..6), site labels, and the
+    transform itself against numpy's FFT."""
+    from helpers import dense_mpo
+    for n in (1, 2, 3, 4, 5, 6):
+        W = qil.build_qft_mpo(n, device=True)
+        assert len(W) == n and not W.paired
+        ref = dense_mpo(O.build_qft_mpo(n).data)
+        assert np.abs(dense_mpo(W.to_host()) - ref).max() < 1e-10, n
+    want = pins["mpo_maxbond_n2_30"]["qft"]
+    for n in (2, 3, 4, 5, 6, 7, 8, 12):
+        W = qil.build_qft_mpo(n, cutoff=1e-15, maxdim=None, device=True)
+        assert max(W.bond_dims) == want[n - 2], (n, W.bond_dims)
+    n = 10
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal(2 ** n)
+    psi = qil.signal_mps(x, cutoff=1e-14)
+    ids = [7 + 2 * i for i in range(n)]
+    psi = qil.SignalMPS(psi.to_host(), amplitude=psi.amplitude, sites=ids)
+    W = qil.build_qft_mpo(psi, device=True)
+    assert W.site_ids == ids
+    fx = np.fft.fft(x) / np.sqrt(2 ** n)
+    err_d = np.abs(qil.mps_to_vector(W * psi, reverse=True) - fx).max()
+    err_h = np.abs(qil.mps_to_vector(qil.build_qft_mpo(psi) * psi, reverse=True) - fx).max()
+    # MPO cutoff 1e-14: ~1e-7 per truncated bond either way (measured 9.5e-7 on the device chain)
+    assert err_d < 5e-6 and err_d < 5 * max(err_h, 1e-7), (err_d, err_h)
+    # the paired chain: same operator as the host chain (and the oracle's) ...
+    for n in (1, 2, 3, 4):
+        Qd = qil.zt_qft_chain_device(n)
+        Qh = qil.PairedSiteMPO(qil.zt_qft_chain_tensors(n))
+        assert len(Qd.to_host()) == 2 * n and Qd.paired and Qd.bond_dims == Qh.bond_dims
+        assert np.abs(dense_mpo(Qd.to_host()) - dense_mpo(Qh.to_host())).max() < 1e-10, n
+    # ... and the whole zT build with nothing but gate blocks from the host
+    series = pins["mpo_maxbond_n2_30"]["zt"]
+    for n in (2, 3, 4, 5, 6):
+        W = qil.build_zt_mpo_batch(n, [2 * np.pi], cutoff=1e-15, maxdim=None, qft="device")[0]
+        assert max(W.bond_dims) == series[n - 2], (n, W.bond_dims)
+    n = 5
+    a = random_mps_data(saturated_profile(2 * n, 6), np.random.default_rng(4))
+    psi = qil.ZTMPS(a)
+    bits = np.random.default_rng(5).integers(0, 2, size=(128, 2 * n))
+    for wr in (0.3, 2 * np.pi):
+        Wd = qil.build_zt_mpo_batch(psi, [wr], qft="device")[0]
+        Wh = qil.build_zt_mpo(psi, wr, device=False)
+        assert Wd.site_ids == psi.site_ids
+        assert rel(qil.coefficient_batch(Wd * psi, bits), qil.coefficient_batch(Wh * psi, bits)) < 1e-9
+    with pytest.raises(ValueError, match="qft must be"):
+        qil.build_zt_mpo_batch(3, [1.0], qft="gpu")
+
+
 def test_failed_calls_leave_no_device_memory_behind(qil):
     """Error-path reclamation: whichever allocation inside a call fails, the pool's in-use byte count returns to
     what the live handles account for, in-place operands stay usable, and the same call succeeds afterwards."""
@@ -2198,24 +2251,3 @@ def test_signal_mps_svd_wide_bonds_reconstruct(qil):
     psi = qil.signal_mps(z, method="svd")
     assert np.abs(qil.mps_to_vector(psi) - z).max() < 1e-11 * np.abs(z).max()
 
-
-def test_combined_sweeps_of_a_batch_are_bit_identical(qil, monkeypatch):
-    """QIL_BATCH_COMBINE=1: the chains of a running batch hand their Jacobi sweeps to a rendezvous that launches the block
-    rounds of all operands of one kernel class as ONE train (one operand per gridDim.y slice, narrower operands leave the
-    rounds they do not have).  The arithmetic is the single-operand kernel's: every tensor equals the item-by-item result
-    bit for bit -- mixed widths inside one class (130 / 150 / 190 columns), several classes, both dtypes."""
-    rng = np.random.default_rng(4242)
-    specs = [(9, 130, np.float64), (9, 150, np.float64), (10, 190, np.float64), (9, 130, np.float64), (9, 100, np.complex128),
-             (9, 120, np.complex128), (10, 64, np.float64), (10, 256, np.float64), (10, 256, np.float64), (9, 130, np.complex128)]
-    data = [random_mps_data(saturated_profile(L, chi), rng, dtype=dt) for L, chi, dt in specs]
-    ref = [qil.compress(qil.SignalMPS([t.copy() for t in a]), maxdim=48, tol=1e-9) for a in data]
-    for wait in ("50", "1000"):
-        monkeypatch.setenv("QIL_BATCH_COMBINE", "1")
-        monkeypatch.setenv("QIL_BATCH_COMBINE_WAIT_US", wait)
-        items = [qil.SignalMPS([t.copy() for t in a]) for a in data]
-        qil.compress_batch(items, maxdim=48, tol=1e-9)
-        for r, b in zip(ref, items):
-            assert b.bond_dims == r.bond_dims and b.amplitude == r.amplitude
-            for tr, tb in zip(r.to_host(), b.to_host()):
-                assert np.array_equal(tr, tb)
-    assert qil.default_context().unowned_bytes() == 0
