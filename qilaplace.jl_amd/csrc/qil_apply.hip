@@ -315,13 +315,13 @@ int launch_apply(const qil_mpo* W, const qil_mps* psi, qil_mps* out) {
     int slot = 0;
     QIL_TRY(qil_ctx_desc_acquire(ctx, bytes, &pin, &dev, &slot));
     memcpy(pin, tab.data(), bytes);
-    QIL_HIP(hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, qil_stream(ctx)));
     QIL_TRY(qil_ctx_prof_begin(ctx));
     const ApplySite* dtab = static_cast<const ApplySite*>(dev);
     const dim3 grid((unsigned)blocks), block(kRows);
     const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;
 #define QIL_APPLY_LAUNCH(TW, TA) \
-    hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16, true>), grid, block, 0, ctx->stream, dtab, (int)n)
+    hipLaunchKernelGGL((site_apply_grouped<TW, TA, true, 16, true>), grid, block, 0, qil_stream(ctx), dtab, (int)n)
     if (wc && ac) QIL_APPLY_LAUNCH(c64, c64);
     else if (wc) QIL_APPLY_LAUNCH(c64, double);
     else if (ac) QIL_APPLY_LAUNCH(double, c64);
@@ -430,27 +430,27 @@ extern "C" int qil_apply_mpo_mpo(const qil_mpo* W1, const qil_mpo* W2, qil_mpo**
             void* o = res->site[(size_t)i];
             const void *p1 = W1->site[(size_t)i1], *p2 = W2->site[(size_t)i2];
             if (c1 && c2)
-                hipLaunchKernelGGL((mpo_compose_site<c64, c64>), dim3(blocks), dim3(threads), 0, ctx->stream,
+                hipLaunchKernelGGL((mpo_compose_site<c64, c64>), dim3(blocks), dim3(threads), 0, qil_stream(ctx),
                                    (const c64*)p1, (const c64*)p2, (c64*)o, D1l, D1r, D2l, D2r);
             else if (c1)
-                hipLaunchKernelGGL((mpo_compose_site<c64, double>), dim3(blocks), dim3(threads), 0, ctx->stream,
+                hipLaunchKernelGGL((mpo_compose_site<c64, double>), dim3(blocks), dim3(threads), 0, qil_stream(ctx),
                                    (const c64*)p1, (const double*)p2, (c64*)o, D1l, D1r, D2l, D2r);
             else if (c2)
-                hipLaunchKernelGGL((mpo_compose_site<double, c64>), dim3(blocks), dim3(threads), 0, ctx->stream,
+                hipLaunchKernelGGL((mpo_compose_site<double, c64>), dim3(blocks), dim3(threads), 0, qil_stream(ctx),
                                    (const double*)p1, (const c64*)p2, (c64*)o, D1l, D1r, D2l, D2r);
             else
                 hipLaunchKernelGGL((mpo_compose_site<double, double>), dim3(blocks), dim3(threads), 0,
-                                   ctx->stream, (const double*)p1, (const double*)p2, (double*)o, D1l, D1r, D2l,
+                                   qil_stream(ctx), (const double*)p1, (const double*)p2, (double*)o, D1l, D1r, D2l,
                                    D2r);
         } else {
             // non-overlapping sites are copied from the base MPO (apply.jl:150-153); promote if needed
             if (base->dtype == odt) {
                 QIL_HIP(hipMemcpyAsync(res->site[(size_t)i], base->site[(size_t)i], base->site_bytes(i),
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+                                       hipMemcpyDeviceToDevice, qil_stream(ctx)));
             } else {
                 const long long ne = base->site_elems(i);
                 hipLaunchKernelGGL(widen_real_to_complex, dim3((unsigned)std::min<long long>((ne + 255) / 256, 1024)),
-                                   dim3(256), 0, ctx->stream, (const double*)base->site[(size_t)i],
+                                   dim3(256), 0, qil_stream(ctx), (const double*)base->site[(size_t)i],
                                    (c64*)res->site[(size_t)i], ne);
             }
         }

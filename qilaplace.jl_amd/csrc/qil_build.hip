@@ -335,7 +335,7 @@ struct Builder {
     }
     int pinned_slot(size_t bytes, char** out) {
         if (bytes > pin_slot_bytes) {
-            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            QIL_HIP(qil_stream_sync(ctx));
             if (pin) QIL_HIP(hipHostFree(pin));
             pin = nullptr;
             pin_slot_bytes = std::max<size_t>(2 * bytes, 1 << 16);
@@ -348,8 +348,8 @@ struct Builder {
 
     int upload(const std::vector<double>& h, void** dev) {
         QIL_TRY(qil_ctx_alloc(ctx, h.size() * sizeof(double), dev));
-        QIL_HIP(hipMemcpyAsync(*dev, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_HIP(hipMemcpyAsync(*dev, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));
         return QIL_OK;
     }
 
@@ -385,9 +385,9 @@ struct Builder {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * n * n * sizeof(double), &R));
         const size_t lds = ((size_t)(n + (n & 1)) + (size_t)(m | 1) * n) * sizeof(double);
         if (lds <= 60 * 1024)
-            hipLaunchKernelGGL(bgs_fused<true>, dim3(B), dim3(256), lds, ctx->stream, Mat, (double*)R, m, n);
+            hipLaunchKernelGGL(bgs_fused<true>, dim3(B), dim3(256), lds, qil_stream(ctx), Mat, (double*)R, m, n);
         else
-            hipLaunchKernelGGL(bgs_fused<false>, dim3(B), dim3(256), (size_t)n * sizeof(double), ctx->stream, Mat,
+            hipLaunchKernelGGL(bgs_fused<false>, dim3(B), dim3(256), (size_t)n * sizeof(double), qil_stream(ctx), Mat,
                                (double*)R, m, n);
         QIL_HIP(hipGetLastError());
         *R_out = R;
@@ -410,7 +410,7 @@ struct Builder {
             const int rows = R * 4, cols = B1 * B2;
             void* core = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * rows * cols * sizeof(double), &core));
-            hipLaunchKernelGGL(bz_core, dim3(nblk((long long)rows * cols), B), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(bz_core, dim3(nblk((long long)rows * cols), B), dim3(256), 0, qil_stream(ctx),
                                (const double*)T, (const double*)M[(size_t)k].p, (const double*)Blk[(size_t)k].p,
                                (double*)core, R, Da, Dc, B1, B2);
             qil_ctx_free(ctx, T);
@@ -424,7 +424,7 @@ struct Builder {
             } else {                        // fat/square: Q = I, T = core
                 void* Q = nullptr;
                 QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * rows * rows * sizeof(double), &Q));
-                hipLaunchKernelGGL(bidentity, dim3(nblk((long long)rows * rows), B), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(bidentity, dim3(nblk((long long)rows * rows), B), dim3(256), 0, qil_stream(ctx),
                                    (double*)Q, rows);
                 M[(size_t)k].p = Q;
                 T = core;
@@ -441,7 +441,7 @@ struct Builder {
             BSite& nx = M[(size_t)L2];
             void* out = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * R * 4 * nx.dr * sizeof(double), &out));
-            hipLaunchKernelGGL(bgemm, dim3(nblk((long long)R * 4 * nx.dr), B), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(bgemm, dim3(nblk((long long)R * 4 * nx.dr), B), dim3(256), 0, qil_stream(ctx),
                                (const double*)T, (const double*)nx.p, (double*)out, R, 4 * nx.dr, Da);
             bfree(ctx, nx);
             nx.p = out;
@@ -450,7 +450,7 @@ struct Builder {
             BSite& lt = M[(size_t)L2 - 1];
             void* out = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * lt.dl * 4 * Da * sizeof(double), &out));
-            hipLaunchKernelGGL(bgemm, dim3(nblk((long long)lt.dl * 4 * Da), B), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(bgemm, dim3(nblk((long long)lt.dl * 4 * Da), B), dim3(256), 0, qil_stream(ctx),
                                (const double*)lt.p, (const double*)T, (double*)out, lt.dl * 4, Da, R);
             bfree(ctx, lt);
             lt.p = out;
@@ -471,10 +471,10 @@ struct Builder {
                 // fat site: Q = I_m (an isometry), R = the site itself; the bond shrinks to m
                 void *out = nullptr, *Q = nullptr;
                 QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * m * 4 * nx.dr * sizeof(double), &out));
-                hipLaunchKernelGGL(bgemm, dim3(nblk((long long)m * 4 * nx.dr), B), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(bgemm, dim3(nblk((long long)m * 4 * nx.dr), B), dim3(256), 0, qil_stream(ctx),
                                    (const double*)M[(size_t)i].p, (const double*)nx.p, (double*)out, m, 4 * nx.dr, n);
                 QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * m * m * sizeof(double), &Q));
-                hipLaunchKernelGGL(bidentity, dim3(nblk((long long)m * m), B), dim3(256), 0, ctx->stream, (double*)Q, m);
+                hipLaunchKernelGGL(bidentity, dim3(nblk((long long)m * m), B), dim3(256), 0, qil_stream(ctx), (double*)Q, m);
                 bfree(ctx, M[(size_t)i]);
                 M[(size_t)i].p = Q;
                 M[(size_t)i].dr = m;
@@ -488,7 +488,7 @@ struct Builder {
             QIL_TRY(qr_tall_or_identity((double*)M[(size_t)i].p, m, n, nullptr, &Rm, &nb));
             void* out = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * n * 4 * nx.dr * sizeof(double), &out));
-            hipLaunchKernelGGL(bgemm, dim3(nblk((long long)n * 4 * nx.dr), B), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(bgemm, dim3(nblk((long long)n * 4 * nx.dr), B), dim3(256), 0, qil_stream(ctx),
                                (const double*)Rm, (const double*)nx.p, (double*)out, n, 4 * nx.dr, n);
             qil_ctx_free(ctx, Rm);
             bfree(ctx, nx);
@@ -508,16 +508,16 @@ struct Builder {
             void* Wk = nullptr;                             // rows x cols work matrix whose columns get rotated
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * rows * cols * sizeof(double), &Wk));
             if (!tall)
-                hipLaunchKernelGGL(btranspose, dim3(nblk((long long)d * w), B), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(btranspose, dim3(nblk((long long)d * w), B), dim3(256), 0, qil_stream(ctx),
                                    (const double*)rt.p, (double*)Wk, d, w);                       // Wk = M[i]^T (w x d)
             else
                 QIL_HIP(hipMemcpyAsync(Wk, rt.p, (size_t)B * d * w * sizeof(double), hipMemcpyDeviceToDevice,
-                                       ctx->stream));
+                                       qil_stream(ctx)));
             void* nrm = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * cols * sizeof(double), &nrm));
             const size_t lds = (size_t)((rows | 1) * cols) * sizeof(double);
             if (cols <= 32 && rows <= 128 && lds <= 60 * 1024) {
-                hipLaunchKernelGGL((bjacobi<true, 256>), dim3(B), dim3(256), lds, ctx->stream, (double*)Wk,
+                hipLaunchKernelGGL((bjacobi<true, 256>), dim3(B), dim3(256), lds, qil_stream(ctx), (double*)Wk,
                                    (double*)nrm, rows, cols, 1e-15);
             } else if (lds <= 150 * 1024) {
                 static bool attr = false;
@@ -526,10 +526,10 @@ struct Builder {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
                     attr = true;
                 }
-                hipLaunchKernelGGL((bjacobi<true, 1024>), dim3(B), dim3(1024), lds, ctx->stream, (double*)Wk,
+                hipLaunchKernelGGL((bjacobi<true, 1024>), dim3(B), dim3(1024), lds, qil_stream(ctx), (double*)Wk,
                                    (double*)nrm, rows, cols, 1e-15);
             } else {
-                hipLaunchKernelGGL((bjacobi<false, 1024>), dim3(B), dim3(1024), 0, ctx->stream, (double*)Wk,
+                hipLaunchKernelGGL((bjacobi<false, 1024>), dim3(B), dim3(1024), 0, qil_stream(ctx), (double*)Wk,
                                    (double*)nrm, rows, cols, 1e-15);
             }
             QIL_HIP(hipGetLastError());
@@ -542,8 +542,8 @@ struct Builder {
             double* inv = sig + nsig;
             int* perm = reinterpret_cast<int*>(inv + nsig);
             int* rank = perm + nsig;
-            QIL_HIP(hipMemcpyAsync(sig, nrm, nsig * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            QIL_HIP(hipMemcpyAsync(sig, nrm, nsig * sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
+            QIL_HIP(qil_stream_sync(ctx));
             std::vector<double> S((size_t)cols);
             int rmax = 1;
             for (int b = 0; b < B; ++b) {
@@ -560,7 +560,7 @@ struct Builder {
             }
             void* dpack = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, up_bytes, &dpack));
-            QIL_HIP(hipMemcpyAsync(dpack, inv, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+            QIL_HIP(hipMemcpyAsync(dpack, inv, up_bytes, hipMemcpyHostToDevice, qil_stream(ctx)));
             const double* dinv = static_cast<const double*>(dpack);
             const int* dperm = reinterpret_cast<const int*>(dinv + nsig);
             const int* drank = dperm + nsig;
@@ -569,23 +569,23 @@ struct Builder {
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * d * rmax * sizeof(double), &US));
             if (!tall) {
                 // M[i]^T = (Wk D^-1) D V^T : Vh = (Wk[:, perm] D^-1)^T (rmax x w) ; U S = M[i] Vh^T (d x rmax)
-                hipLaunchKernelGGL(bgather, dim3(nblk((long long)w * rmax), B), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(bgather, dim3(nblk((long long)w * rmax), B), dim3(256), 0, qil_stream(ctx),
                                    (const double*)Wk, w, cols, (const int*)dperm, (const double*)dinv,
                                    (const int*)drank, (double*)Vh, rmax, 1);
-                hipLaunchKernelGGL(bgemm_nt, dim3(nblk((long long)d * rmax), B), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(bgemm_nt, dim3(nblk((long long)d * rmax), B), dim3(256), 0, qil_stream(ctx),
                                    (const double*)rt.p, (const double*)Vh, (double*)US, d, rmax, w);
             } else {
                 // M[i] = (Wk D^-1) D V^T with Wk = M[i] rotated (d x w): U S = Wk[:, perm] ; Vh = D^-2 (U S)^T M[i]
-                hipLaunchKernelGGL(bgather, dim3(nblk((long long)d * rmax), B), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(bgather, dim3(nblk((long long)d * rmax), B), dim3(256), 0, qil_stream(ctx),
                                    (const double*)Wk, d, cols, (const int*)dperm, (const double*)nullptr,
                                    (const int*)drank, (double*)US, rmax, 0);
-                hipLaunchKernelGGL(bgemm_tn_scaled, dim3(nblk((long long)rmax * w), B), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(bgemm_tn_scaled, dim3(nblk((long long)rmax * w), B), dim3(256), 0, qil_stream(ctx),
                                    (const double*)US, (const double*)rt.p, (const double*)dinv, (double*)Vh, rmax, w, d,
                                    cols);
             }
             // M[i-1] <- M[i-1] (U S)
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * lf.dl * 4 * rmax * sizeof(double), &nl));
-            hipLaunchKernelGGL(bgemm, dim3(nblk((long long)lf.dl * 4 * rmax), B), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(bgemm, dim3(nblk((long long)lf.dl * 4 * rmax), B), dim3(256), 0, qil_stream(ctx),
                                (const double*)lf.p, (const double*)US, (double*)nl, lf.dl * 4, rmax, d);
             QIL_HIP(hipGetLastError());
             qil_ctx_free(ctx, Wk);
@@ -607,7 +607,7 @@ struct Builder {
         for (size_t i = 0; i < M.size(); ++i) {
             BSite& src = M[M.size() - 1 - i];
             QIL_TRY(balloc(ctx, B, src.dr, src.dl, &out[i]));
-            hipLaunchKernelGGL(bmirror, dim3(nblk(src.elems()), B), dim3(256), 0, ctx->stream, (const double*)src.p,
+            hipLaunchKernelGGL(bmirror, dim3(nblk(src.elems()), B), dim3(256), 0, qil_stream(ctx), (const double*)src.p,
                                (double*)out[i].p, src.dl, src.dr);
         }
         QIL_HIP(hipGetLastError());
@@ -790,12 +790,12 @@ extern "C" int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, c
         for (int i = 0; i < L; ++i) {
             const size_t bytes = (size_t)M[(size_t)i].elems() * sizeof(double);
             hipError_t e = hipMemcpyAsync(W->site[(size_t)i], static_cast<char*>(M[(size_t)i].p) + (size_t)b * bytes, bytes,
-                                          hipMemcpyDeviceToDevice, ctx->stream);
+                                          hipMemcpyDeviceToDevice, qil_stream(ctx));
             if (e != hipSuccess) return fail(qil_fail(QIL_EHIP, "copy failed: %s", hipGetErrorString(e)));
         }
         out[b] = W;
     }
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(qil_stream_sync(ctx));
     for (auto& s : M) bfree(ctx, s);
     return QIL_OK;
 }

@@ -1038,7 +1038,7 @@ static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* 
     if (prof) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)B * PB_NCYC * sizeof(unsigned long long), &dcyc));
     }
-    QIL_HIP(hipMemcpyAsync(dg, gates.data(), gates.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dg, gates.data(), gates.size() * sizeof(double), hipMemcpyHostToDevice, qil_stream(ctx)));
     PbArgs a;
     a.n = (int)n;
     a.L = L;
@@ -1053,13 +1053,13 @@ static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* 
     a.arena_doubles = arena_doubles;
     a.cycles = static_cast<unsigned long long*>(dcyc);
     if (prof) QIL_TRY(qil_timer_start(ctx));
-    hipLaunchKernelGGL(dt_build_persistent, dim3(B), dim3(PB_NT), (size_t)arena_doubles * 8, ctx->stream, a);
+    hipLaunchKernelGGL(dt_build_persistent, dim3(B), dim3(PB_NT), (size_t)arena_doubles * 8, qil_stream(ctx), a);
     QIL_HIP(hipGetLastError());
     double kernel_ms = 0.0;
     if (prof) QIL_TRY(qil_timer_stop(ctx, &kernel_ms));
     std::vector<int> meta(meta_ints);
-    QIL_HIP(hipMemcpyAsync(meta.data(), dmeta, meta_ints * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));           // also orders the pageable `gates` upload before its release
+    QIL_HIP(hipMemcpyAsync(meta.data(), dmeta, meta_ints * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));           // also orders the pageable `gates` upload before its release
     if (prof) {
         std::vector<unsigned long long> cyc((size_t)B * PB_NCYC);
         QIL_HIP(hipMemcpy(cyc.data(), dcyc, cyc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1105,13 +1105,13 @@ static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* 
     void* dptr = nullptr;
     if (st == QIL_OK) st = qil_ctx_alloc(ctx, ptrs.size() * sizeof(double*), &dptr);
     if (st == QIL_OK) {
-        hipError_t e = hipMemcpyAsync(dptr, ptrs.data(), ptrs.size() * sizeof(double*), hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(dptr, ptrs.data(), ptrs.size() * sizeof(double*), hipMemcpyHostToDevice, qil_stream(ctx));
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(pb_copy_out, dim3(L, B), dim3(256), 0, ctx->stream, (const double*)ws, site_cap, L,
+            hipLaunchKernelGGL(pb_copy_out, dim3(L, B), dim3(256), 0, qil_stream(ctx), (const double*)ws, site_cap, L,
                                (const int*)dmeta, (double* const*)dptr);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = qil_stream_sync(ctx);
         if (e != hipSuccess) st = qil_fail(QIL_EHIP, "build_dt_mpo: copy-out failed: %s", hipGetErrorString(e));
     }
     if (dptr) qil_ctx_free(ctx, dptr);

@@ -2,8 +2,10 @@
 #include <cstdarg>
 
 #include "qil_internal.h"
+#include "qil_launch.h"
 
 #include <algorithm>
+#include <memory>
 #include <chrono>
 #include <system_error>
 #include <thread>
@@ -74,13 +76,13 @@ extern "C" int qil_context_create(int device, void* stream, qil_context** out) {
 
 extern "C" int qil_context_synchronize(qil_context* ctx) {
     QIL_TRY(qil_ctx_activate(ctx));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(qil_stream_sync(ctx));
     return QIL_OK;
 }
 
 extern "C" int qil_context_trim(qil_context* ctx) {
     QIL_TRY(qil_ctx_activate(ctx));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(qil_stream_sync(ctx));
     for (auto& kv : ctx->free_blocks) hipFree(kv.second);
     ctx->free_blocks.clear();
     ctx->bytes_cached = 0;
@@ -93,7 +95,7 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
     for (qil_context* w : ctx->workers) qil_context_destroy(w);
     ctx->workers.clear();
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    qil_stream_sync(ctx);
     for (qil_chain* c : ctx->chains) {                    // handles the caller has not destroyed yet: orphan them
         c->ctx = nullptr;
         for (void*& p : c->site) p = nullptr;
@@ -113,6 +115,7 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->flag_host) hipHostFree(ctx->flag_host);
+    if (ctx->sync_event) hipEventDestroy(ctx->sync_event);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
@@ -179,7 +182,7 @@ int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out) {
         if (e == hipErrorOutOfMemory && !ctx->free_blocks.empty()) {
             // give cached blocks back and retry once
             (void)hipGetLastError();
-            hipStreamSynchronize(ctx->stream);
+            qil_stream_sync(ctx);
             for (auto& kv : ctx->free_blocks) hipFree(kv.second);
             ctx->free_blocks.clear();
             ctx->bytes_cached = 0;
@@ -216,7 +219,7 @@ int qil_ctx_free(qil_context* ctx, void* p) {
     // the driver; the large recurring ones (apply outputs) stay, they are what the cache is for.
     constexpr size_t kMaxCachedBlocks = 8192, kSmall = 1u << 20;
     if (ctx->free_blocks.size() > kMaxCachedBlocks) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)qil_stream_sync(ctx);
         auto end = ctx->free_blocks.upper_bound(kSmall);
         for (auto f = ctx->free_blocks.begin(); f != end; ++f) {
             (void)hipFree(f->second);
@@ -258,7 +261,7 @@ qil_call_scope::~qil_call_scope() {
 
 int qil_ctx_pinned(qil_context* ctx, size_t bytes, void** out) {
     if (bytes > ctx->pinned_bytes) {
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_HIP(qil_stream_sync(ctx));
         if (ctx->pinned) hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
         size_t nb = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
@@ -271,7 +274,7 @@ int qil_ctx_pinned(qil_context* ctx, size_t bytes, void** out) {
 
 int qil_ctx_dev_scratch(qil_context* ctx, size_t bytes, void** out) {
     if (bytes > ctx->dev_scratch_bytes) {
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_HIP(qil_stream_sync(ctx));
         if (ctx->dev_scratch) hipFree(ctx->dev_scratch);
         ctx->dev_scratch = nullptr;
         size_t nb = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
@@ -302,7 +305,7 @@ int qil_ctx_desc_acquire(qil_context* ctx, size_t bytes, void** host, void** dev
 }
 
 int qil_ctx_desc_commit(qil_context* ctx, int slot) {
-    QIL_HIP(hipEventRecord(ctx->desc_event[slot], ctx->stream));
+    QIL_HIP(hipEventRecord(ctx->desc_event[slot], qil_stream(ctx)));
     ctx->desc_used[slot] = true;
     return QIL_OK;
 }
@@ -311,14 +314,14 @@ int qil_ctx_desc_commit(qil_context* ctx, int slot) {
 // ---------------------------------------------------------------- timers / profile
 extern "C" int qil_timer_start(qil_context* ctx) {
     QIL_TRY(qil_ctx_activate(ctx));
-    QIL_HIP(hipEventRecord(ctx->t0, ctx->stream));
+    QIL_HIP(hipEventRecord(ctx->t0, qil_stream(ctx)));
     return QIL_OK;
 }
 
 extern "C" int qil_timer_stop(qil_context* ctx, double* ms) {
     QIL_TRY(qil_ctx_activate(ctx));
     QIL_REQUIRE(ms, QIL_EINVAL_ARG, "qil_timer_stop: null out");
-    QIL_HIP(hipEventRecord(ctx->t1, ctx->stream));
+    QIL_HIP(hipEventRecord(ctx->t1, qil_stream(ctx)));
     QIL_HIP(hipEventSynchronize(ctx->t1));
     float f = 0.f;
     QIL_HIP(hipEventElapsedTime(&f, ctx->t0, ctx->t1));
@@ -360,19 +363,19 @@ int qil_ctx_prof_begin(qil_context* ctx) {
     QIL_TRY(get_event(ctx, &a));
     QIL_TRY(get_event(ctx, &b));
     ctx->prof_events.emplace_back(a, b);
-    QIL_HIP(hipEventRecord(a, ctx->stream));
+    QIL_HIP(hipEventRecord(a, qil_stream(ctx)));
     return QIL_OK;
 }
 
 int qil_ctx_prof_end(qil_context* ctx) {
     if (!ctx->profile) return QIL_OK;
-    QIL_HIP(hipEventRecord(ctx->prof_events.back().second, ctx->stream));
+    QIL_HIP(hipEventRecord(ctx->prof_events.back().second, qil_stream(ctx)));
     return QIL_OK;
 }
 
 extern "C" int qil_profile_read(qil_context* ctx, int64_t* n_launches, double* total_ms, int reset) {
     QIL_TRY(qil_ctx_activate(ctx));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(qil_stream_sync(ctx));
     double tot = 0;
     for (auto& pr : ctx->prof_events) {
         float f = 0.f;
@@ -451,6 +454,190 @@ static void chain_move(qil_chain* c, qil_context* to) {
     to->chains.insert(c);
 }
 
+// ---------------------------------------------------------------- lock-step batches (see qil_launch.h)
+constexpr unsigned QIL_RING = 256;       // launch requests a chain may be ahead of the launcher
+struct qil_chainq {
+    qil_launch_req ring[QIL_RING];
+    alignas(64) std::atomic<unsigned> head{0};     // next request to issue (launcher)
+    alignas(64) std::atomic<unsigned> tail{0};     // next free entry (the chain's thread)
+    std::atomic<uint64_t> key{0};                  // where the chain is working (mirrors ctx->progress_key)
+    std::atomic<unsigned> seq{0};                  // launches it has queued since the key last changed
+    std::atomic<int> live{1};
+    std::atomic<int> status{0};                    // first failed launch of this chain
+};
+struct qil_lockstep {
+    int nslots = 0;
+    qil_chainq* q = nullptr;
+    hipStream_t stream = nullptr;                  // the one stream all slots share
+    long long requests = 0, launches = 0, timeouts = 0;
+    double launch_us = 0, total_us = 0;            // QIL_BATCH_DEBUG: time inside the launch calls / of the launcher loop
+    long long group_hist[QIL_MAXB + 1] = {};
+};
+
+void qil_progress_step(qil_context* ctx, bool new_pass, long long step) {
+    if (!ctx) return;
+    uint64_t pass = ctx->progress_key >> 40;
+    if (new_pass) ++pass;
+    ctx->progress_key = (pass << 40) | ((uint64_t)(step & 0xfffff) << 16);
+    if (ctx->lockstep) {
+        ctx->lockstep->q[ctx->ls_slot].seq.store(0, std::memory_order_relaxed);
+        ctx->lockstep->q[ctx->ls_slot].key.store(ctx->progress_key, std::memory_order_release);
+    }
+}
+void qil_progress_phase(qil_context* ctx, int phase) {
+    if (!ctx) return;
+    const uint64_t nk = (ctx->progress_key & ~0xffffull) | (uint64_t)(phase & 0xffff);
+    if (nk == ctx->progress_key) return;
+    ctx->progress_key = nk;
+    if (ctx->lockstep) {
+        ctx->lockstep->q[ctx->ls_slot].seq.store(0, std::memory_order_relaxed);
+        ctx->lockstep->q[ctx->ls_slot].key.store(nk, std::memory_order_release);
+    }
+}
+
+static inline void spin_pause(int& spins) {
+    if (++spins < (1 << 14))
+        __builtin_ia32_pause();
+    else
+        std::this_thread::yield();
+}
+
+qil_launch_req* qil_lockstep_begin(qil_lockstep* ls, qil_context* ctx) {
+    qil_chainq& q = ls->q[ctx->ls_slot];
+    const unsigned t = q.tail.load(std::memory_order_relaxed);
+    int spins = 0;
+    while (t - q.head.load(std::memory_order_acquire) >= QIL_RING) spin_pause(spins);   // ring full
+    qil_launch_req* r = &q.ring[t % QIL_RING];
+    r->progress = ctx->progress_key;
+    r->seq = q.seq.load(std::memory_order_relaxed);
+    return r;
+}
+int qil_lockstep_commit(qil_lockstep* ls, qil_context* ctx) {
+    qil_chainq& q = ls->q[ctx->ls_slot];
+    q.seq.store(q.seq.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+    q.tail.store(q.tail.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+    const int st = q.status.load(std::memory_order_relaxed);
+    return st == QIL_OK ? QIL_OK : qil_fail(st, "a combined launch of this chain failed");
+}
+void qil_lockstep_drain(qil_context* ctx) {
+    qil_lockstep* ls = ctx->lockstep;
+    if (!ls) return;
+    qil_chainq& q = ls->q[ctx->ls_slot];
+    const unsigned t = q.tail.load(std::memory_order_relaxed);
+    int spins = 0;
+    while (q.head.load(std::memory_order_acquire) != t) spin_pause(spins);
+}
+
+hipError_t qil_stream_sync(qil_context* ctx) {
+    if (!ctx->lockstep) return hipStreamSynchronize(ctx->stream);
+    qil_lockstep_drain(ctx);
+    if (!ctx->sync_event) {
+        const hipError_t e = hipEventCreateWithFlags(&ctx->sync_event, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    const hipError_t e = hipEventRecord(ctx->sync_event, ctx->stream);
+    return e != hipSuccess ? e : hipEventSynchronize(ctx->sync_event);
+}
+
+// the launcher: until every chain has left and every ring is empty.  A launch goes out when every chain that is no further
+// along than the heads to be issued has queued its own next step (so that they share the launch) -- or after `patience` of
+// waiting for such a chain (it may be deep in host work or waiting for the device).
+static void lockstep_run(qil_lockstep* ls, bool timing) {
+    int spins = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    // (measured, 8 chains chi 256: 50 us -> 7441 launches / 161 ms, 200 us -> 7039 / 160 ms, 1 ms -> 6979 / 155 ms, 5 ms -> 6976 / 146 ms)
+    const auto patience = std::chrono::microseconds(2000);
+    bool waiting = false;
+    std::chrono::steady_clock::time_point wait_since;
+    for (;;) {
+        // order = (progress key, position inside the key's segment): chains running the same program queue the same kernel
+        // at the same position, so serving the smallest position first re-aligns chains that are one step apart
+        uint64_t headkey = ~0ull, idlekey = ~0ull;
+        unsigned headseq = ~0u, idleseq = ~0u;
+        bool any = false;
+        unsigned heads[QIL_MAXB], tails[QIL_MAXB];
+        for (int s = 0; s < ls->nslots; ++s) {
+            qil_chainq& q = ls->q[s];
+            const int live = q.live.load(std::memory_order_acquire);
+            tails[s] = q.tail.load(std::memory_order_acquire);
+            heads[s] = q.head.load(std::memory_order_relaxed);
+            if (heads[s] != tails[s]) {
+                any = true;
+                const qil_launch_req& r = q.ring[heads[s] % QIL_RING];
+                if (r.progress < headkey || (r.progress == headkey && r.seq < headseq)) {
+                    headkey = r.progress;
+                    headseq = r.seq;
+                }
+            } else if (live) {
+                any = true;
+                const uint64_t k = q.key.load(std::memory_order_acquire);
+                const unsigned sq = q.seq.load(std::memory_order_relaxed);
+                if (k < idlekey || (k == idlekey && sq < idleseq)) {
+                    idlekey = k;
+                    idleseq = sq;
+                }
+            }
+        }
+        if (!any) break;
+        if (headkey == ~0ull) {                                 // nothing queued anywhere
+            spin_pause(spins);
+            continue;
+        }
+        if (idlekey < headkey || (idlekey == headkey && idleseq <= headseq)) {   // a chain that is not ahead has not queued this step yet
+            const auto now = std::chrono::steady_clock::now();
+            if (!waiting) {
+                waiting = true;
+                wait_since = now;
+            }
+            if (now - wait_since < patience) {
+                __builtin_ia32_pause();
+                continue;
+            }
+            ++ls->timeouts;
+        }
+        waiting = false;
+        spins = 0;
+        qil_launch_req* sel[QIL_MAXB];
+        int slot_of[QIL_MAXB], nsel = 0;
+        for (int s = 0; s < ls->nslots; ++s)
+            if (heads[s] != tails[s] && ls->q[s].ring[heads[s] % QIL_RING].progress == headkey &&
+                ls->q[s].ring[heads[s] % QIL_RING].seq == headseq) {
+                sel[nsel] = &ls->q[s].ring[heads[s] % QIL_RING];
+                slot_of[nsel++] = s;
+            }
+        bool taken[QIL_MAXB] = {};
+        for (int i = 0; i < nsel; ++i) {
+            if (taken[i]) continue;
+            qil_launch_req* grp[QIL_MAXB];
+            int gs[QIL_MAXB], n = 0;
+            for (int j = i; j < nsel; ++j) {
+                qil_launch_req* r = sel[j];
+                if (taken[j] || r->kern != sel[i]->kern || r->lds != sel[i]->lds || r->block.x != sel[i]->block.x ||
+                    r->block.y != sel[i]->block.y || r->block.z != sel[i]->block.z)
+                    continue;
+                taken[j] = true;
+                gs[n] = slot_of[j];
+                grp[n++] = r;
+            }
+            const auto tl0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+            const int st = sel[i]->launch_group(grp, n, ls->stream);
+            if (timing) ls->launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count();
+            ++ls->launches;
+            ls->requests += n;
+            ++ls->group_hist[n];
+            for (int k = 0; k < n; ++k) {
+                qil_chainq& q = ls->q[gs[k]];
+                if (st != QIL_OK) {
+                    int ok = QIL_OK;
+                    q.status.compare_exchange_strong(ok, st);
+                }
+                q.head.store(q.head.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+            }
+        }
+    }
+    ls->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+}
+
 int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int64_t, qil_context*)>& place,
                      const std::function<int(int64_t, qil_context*)>& fn) {
     if (nb <= 0) return QIL_OK;
@@ -461,7 +648,17 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     static const int max_workers = getenv("QIL_BATCH_WORKERS") ? atoi(getenv("QIL_BATCH_WORKERS")) : 8;   // tuning aid (8 streams on the 4 queues: 2.09x single for 8 chains, 4 streams: 2.22x)
     // a context that is already one slot of a running batch (the home context during its own batch, or a worker) runs
     // nested batches inline: the slots are taken, and the batch mutex is held by the outer call
-    const int nw = (home->lending || home->parent) ? 1 : (int)std::min<int64_t>(nb, std::max(1, max_workers));
+    // Lock-step groups (qil_launch.h): up to QIL_MAXB chains share ONE stream and a launcher that issues the same step of all of
+    // them as one table launch; up to 4 such groups run side by side on streams of their own (one per hardware queue).  One
+    // group is a serial stream -- measured, compress! chi 256 -> 128: 8 chains 146-160 ms as one group against 136 ms on 8
+    // streams, 4 chains 109 against 75 ms -- so small batches keep the stream-per-chain form and lock-step takes over where
+    // the 4 hardware queues are the limit: from 12 chains on (QIL_BATCH_LOCKSTEP = 0: never, 1: always, default: auto).
+    const int ls_mode = getenv("QIL_BATCH_LOCKSTEP") ? atoi(getenv("QIL_BATCH_LOCKSTEP")) : -1;
+    const bool lockstep = ls_mode == 1 || (ls_mode != 0 && nb >= 5);
+    constexpr int kMaxGroups = 4;
+    const int nw = (home->lending || home->parent) ? 1
+                   : (int)std::min<int64_t>(nb, lockstep ? QIL_MAXB * kMaxGroups : std::max(1, max_workers));
+    const int ng = lockstep ? std::min(kMaxGroups, nw) : 0;      // all four queues, the chains dealt over them; slot k belongs to group k % ng
     if (nw <= 1) {
         int first = QIL_OK;
         std::string msg;
@@ -494,6 +691,33 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     if (place)
         for (int64_t j = 0; j < nb; ++j)
             if (j % nw) place(j, slot_ctx((int)(j % nw)));
+    std::vector<qil_lockstep> lsg((size_t)std::max(ng, 1));
+    std::unique_ptr<qil_chainq[]> rings;
+    std::vector<hipStream_t> own_stream((size_t)nw, nullptr);
+    if (lockstep) {
+        rings.reset(new qil_chainq[(size_t)nw]);
+        for (int k = 0; k < nw; ++k) own_stream[(size_t)k] = slot_ctx(k)->stream;
+        int off = 0;
+        for (int g = 0; g < ng; ++g) {
+            qil_lockstep& ls = lsg[(size_t)g];
+            ls.q = rings.get() + off;
+            ls.nslots = (nw - g + ng - 1) / ng;                  // slots g, g + ng, g + 2 ng, ...
+            off += ls.nslots;
+            ls.stream = own_stream[(size_t)g];                   // group 0: the home stream; group g: its first slot's own stream
+            if (g && hipStreamWaitEvent(ls.stream, ready, 0) != hipSuccess) {
+                (void)hipEventDestroy(ready);
+                return qil_fail(QIL_EHIP, "hipStreamWaitEvent failed");
+            }
+        }
+        for (int k = 0; k < nw; ++k) {
+            qil_context* w = slot_ctx(k);
+            qil_lockstep& ls = lsg[(size_t)(k % ng)];
+            w->stream = ls.stream;
+            w->ls_slot = k / ng;
+            w->progress_key = 0;
+            w->lockstep = &ls;
+        }
+    }
     home->lend_blocks.swap(home->free_blocks);               // lend the cache (free_blocks is now empty)
     home->lend_cached = home->bytes_cached;
     home->bytes_cached = 0;
@@ -504,8 +728,9 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     const auto t_batch = std::chrono::steady_clock::now();
     auto drive = [&](int k) {
         qil_context* w = slot_ctx(k);
+        const bool in_step = lockstep && w->lockstep;            // (a slot whose thread could not be started runs alone afterwards)
         int s0 = QIL_OK;
-        if (k && (hipSetDevice(w->device) != hipSuccess || hipStreamWaitEvent(w->stream, ready, 0) != hipSuccess)) s0 = QIL_EHIP;
+        if ((k || lockstep) && (hipSetDevice(w->device) != hipSuccess || (!lockstep && hipStreamWaitEvent(w->stream, ready, 0) != hipSuccess))) s0 = QIL_EHIP;
         for (int64_t j = k; j < nb; j += nw) {
             const auto tj0 = std::chrono::steady_clock::now();
             const int s = s0 != QIL_OK ? s0 : fn(j, w);
@@ -518,21 +743,60 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
                 message[(size_t)j] = s0 != QIL_OK ? "worker stream setup failed" : qil_last_error();
             }
         }
-        (void)hipStreamSynchronize(w->stream);
+        if (in_step) {
+            qil_lockstep_drain(w);
+            w->lockstep->q[w->ls_slot].live.store(0, std::memory_order_release);    // the launcher no longer waits for this slot
+        } else {
+            (void)hipStreamSynchronize(w->stream);
+        }
     };
     std::vector<std::thread> threads;
     threads.reserve((size_t)nw - 1);
     std::vector<int> inline_slots;                            // slots whose thread could not be started run here afterwards
-    for (int k = 1; k < nw; ++k) {
+    // lock-step: every slot, the home one included, runs on a thread of its own and this thread is the launcher
+    for (int k = lockstep ? 0 : 1; k < nw; ++k) {
         try {
             threads.emplace_back(drive, k);
         } catch (const std::system_error&) {
             inline_slots.push_back(k);
+            if (lockstep) {
+                qil_context* w = slot_ctx(k);
+                w->lockstep->q[w->ls_slot].live.store(0, std::memory_order_release);
+                w->lockstep = nullptr;
+                w->stream = own_stream[(size_t)k];
+            }
         }
     }
-    drive(0);
+    if (lockstep) {                                               // one launcher per group; this thread serves group 0
+        std::vector<std::thread> launchers;
+        for (int g = 1; g < ng; ++g) launchers.emplace_back([&, g]() {
+            (void)hipSetDevice(home->device);
+            lockstep_run(&lsg[(size_t)g], batch_debug);
+        });
+        lockstep_run(&lsg[0], batch_debug);
+        for (auto& t : launchers) t.join();
+    } else {
+        drive(0);
+    }
     for (int k : inline_slots) drive(k);
     for (auto& t : threads) t.join();
+    if (lockstep) {
+        for (int g = 0; g < ng; ++g) (void)hipStreamSynchronize(lsg[(size_t)g].stream);
+        for (int k = 0; k < nw; ++k) {
+            qil_context* w = slot_ctx(k);
+            w->stream = own_stream[(size_t)k];
+            w->lockstep = nullptr;
+        }
+        if (batch_debug)
+            for (int g = 0; g < ng; ++g) {
+                const qil_lockstep& ls = lsg[(size_t)g];
+                fprintf(stderr, "[batch] lock-step group %d (%d chains): %lld requests in %lld launches (%lld after waiting for a chain); "
+                        "launches by group size:", g, ls.nslots, ls.requests, ls.launches, ls.timeouts);
+                for (int c = 1; c <= QIL_MAXB; ++c)
+                    if (ls.group_hist[c]) fprintf(stderr, " %d:%lld", c, ls.group_hist[c]);
+                fprintf(stderr, "; launcher %.1f ms, %.1f ms of it inside launch calls\n", ls.total_us / 1e3, ls.launch_us / 1e3);
+            }
+    }
     home->lending = false;
     // every stream of the batch is idle: the chains the workers hold (moved there or created there), what is left of the
     // lent blocks and the workers' caches go (back) to the home context
@@ -620,7 +884,7 @@ static int chain_create(qil_context* ctx, int64_t n, int dtype, int paired, int 
                 return qil_fail(QIL_EINVAL_ARG, "site %lld: null host pointer", (long long)(i + 1));
             }
             hipError_t e = hipMemcpyAsync(h->site[(size_t)i], site_ptrs[i], h->site_bytes(i),
-                                          hipMemcpyHostToDevice, ctx->stream);
+                                          hipMemcpyHostToDevice, qil_stream(ctx));
             if (e != hipSuccess) {
                 qil_chain_release(h);
                 delete h;
@@ -629,7 +893,7 @@ static int chain_create(qil_context* ctx, int64_t n, int dtype, int paired, int 
             }
         }
         // host buffers may be pageable and are not retained: finish the copies before returning
-        hipError_t e = hipStreamSynchronize(ctx->stream);
+        hipError_t e = qil_stream_sync(ctx);
         if (e != hipSuccess) {
             qil_chain_release(h);
             delete h;
@@ -691,7 +955,7 @@ int qil_mps_clone_to(qil_context* ctx, const qil_mps* psi, qil_mps** out) {
     (*out)->amplitude = psi->amplitude;
     for (int64_t i = 0; i < psi->n(); ++i)
         QIL_HIP(hipMemcpyAsync((*out)->site[(size_t)i], psi->site[(size_t)i], psi->site_bytes(i),
-                               hipMemcpyDeviceToDevice, ctx->stream));
+                               hipMemcpyDeviceToDevice, qil_stream(ctx)));
     return QIL_OK;
 }
 
@@ -737,8 +1001,8 @@ extern "C" int qil_mps_clone(const qil_mps* psi, qil_mps** out) {
         QIL_REQUIRE(i >= 0 && i < c->n(), QIL_EINVAL_ARG, "site index %lld out of range", (long long)i); \
         QIL_TRY(qil_ctx_activate(c->ctx));                                                              \
         QIL_HIP(hipMemcpyAsync(dst, c->site[(size_t)i], c->site_bytes(i), hipMemcpyDeviceToHost,        \
-                               c->ctx->stream));                                                        \
-        QIL_HIP(hipStreamSynchronize(c->ctx->stream));                                                  \
+                               qil_stream(c->ctx)));                                                        \
+        QIL_HIP(qil_stream_sync(c->ctx));                                                  \
         return QIL_OK;                                                                                  \
     }                                                                                                   \
     extern "C" int PFX##_site_device_ptr(const TYPE* c, int64_t i, void** p) {                          \
@@ -755,8 +1019,8 @@ extern "C" int qil_mps_upload_site(qil_mps* c, int64_t i, const void* src) {
     QIL_REQUIRE(c && src, QIL_EINVAL_ARG, "qil_mps_upload_site: null argument");
     QIL_REQUIRE(i >= 0 && i < c->n(), QIL_EINVAL_ARG, "site index %lld out of range", (long long)i);
     QIL_TRY(qil_ctx_activate(c->ctx));
-    QIL_HIP(hipMemcpyAsync(c->site[(size_t)i], src, c->site_bytes(i), hipMemcpyHostToDevice, c->ctx->stream));
-    QIL_HIP(hipStreamSynchronize(c->ctx->stream));
+    QIL_HIP(hipMemcpyAsync(c->site[(size_t)i], src, c->site_bytes(i), hipMemcpyHostToDevice, qil_stream(c->ctx)));
+    QIL_HIP(qil_stream_sync(c->ctx));
     return QIL_OK;
 }
 

@@ -60,6 +60,10 @@ struct qil_context {
     // pinned staging for small descriptor / bit uploads
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    struct qil_lockstep* lockstep = nullptr;   // set while this context is a slot of a running lock-step batch (qil_launch.h)
+    int ls_slot = 0;              // ... and which one
+    hipEvent_t sync_event = nullptr;   // qil_stream_sync inside a lock-step batch
+    uint64_t progress_key = 0;    // where the chain driven through this context is (qil_progress)
     int cholqr_skip = 0;          // Cholesky QR attempts to skip after a refusal (qr_impl)
     void* flag_host = nullptr;    // 4 KB pinned: convergence flags the host reads while the stream runs on (qil_ctx_flag_host)
     void* dev_scratch = nullptr;  // per-call device workspace (stream-ordered reuse)
@@ -96,6 +100,16 @@ struct qil_context {
     std::mutex pool_mutex;
 };
 
+// The stream for anything that is NOT a qil_klaunch: inside a lock-step batch the chain first waits until the launcher has
+// issued everything it has queued (stream order), otherwise this is ctx->stream.
+void qil_lockstep_drain(qil_context* ctx);
+inline hipStream_t qil_stream(qil_context* ctx) {
+    if (ctx->lockstep) qil_lockstep_drain(ctx);
+    return ctx->stream;
+}
+// hipStreamSynchronize for chain code: inside a lock-step batch the slots share one stream that the launcher keeps feeding, so
+// the chain waits for an event recorded behind ITS last operation instead of for the whole stream to run dry
+hipError_t qil_stream_sync(qil_context* ctx);
 int qil_ctx_activate(qil_context* ctx);  // hipSetDevice
 int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out);
 int qil_ctx_free(qil_context* ctx, void* p);
@@ -226,6 +240,12 @@ int qil_dev_set_identity(qil_context* ctx, int dtype, void* V, int64_t ldv, int6
 // rank-deficient operands; one small GEMM and one stream synchronisation when nothing needs doing).
 int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda,
                         void* R, int64_t ldr, bool orthonormal = false);
+// device-to-device copies / zero fills as kernels (they ride the combined launches of a lock-step batch, qil_launch.h);
+// pitches and widths in bytes
+int qil_dev_copy2d(qil_context* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);
+int qil_dev_copy(qil_context* ctx, void* dst, const void* src, size_t bytes);
+int qil_dev_zero2d(qil_context* ctx, void* dst, size_t pitch, size_t width, size_t height);
+int qil_dev_zero(qil_context* ctx, void* dst, size_t bytes);
 // ITensors truncation rule (host): number of singular values kept.
 int64_t qil_truncation_rank(const double* S, int64_t n, double cutoff, bool use_cutoff, int64_t maxdim,
                             int64_t mindim);

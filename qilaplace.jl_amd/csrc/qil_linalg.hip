@@ -14,6 +14,7 @@
 #include <numeric>
 
 #include "qil_internal.h"
+#include "qil_launch.h"
 #include "qil_device_utils.h"
 
 namespace {
@@ -59,7 +60,7 @@ __device__ __forceinline__ c64 maybe_conj(c64 v, int cj) { return cj ? c64{v.re,
 // ARC / BKC: op(A)'s row index / op(B)'s k index is the contiguous one in memory (compile time, so that the staging
 // pattern -- which element of the tile a thread loads and where it lands in LDS -- folds into constants).
 template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 2 : 1)) void gemm_mfma(long long m, long long n, long long k_total,
+__device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3 gridDim, long long m, long long n, long long k_total,
                                                  const T* __restrict__ A, long long a_rs, long long a_ks, int conjA,
                                                  const T* __restrict__ B, long long b_ks, long long b_cs, int conjB,
                                                  T* __restrict__ C, long long ldc, long long kchunk,
@@ -265,9 +266,17 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 2 : 1)) void gemm_mfma
                 }
             }
 }
+template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC>
+struct gemm_mfma_k {
+    static constexpr int NT = 256, MINW = (BM * BN <= 128 * 128 ? 2 : 1);
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        gemm_mfma_body<T, BM, BN, WM, WN, PIPE, ARC, BKC>(b, g, a...);
+    }
+};
 
 template <class T>
-__global__ void splitk_reduce(const T* __restrict__ W, long long cstride, int splits, long long m, long long n,
+__device__ __forceinline__ void splitk_reduce_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ W, long long cstride, int splits, long long m, long long n,
                               T* __restrict__ C, long long ldc, int subtract) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < m * n;
          t += (long long)gridDim.x * blockDim.x) {
@@ -277,6 +286,14 @@ __global__ void splitk_reduce(const T* __restrict__ W, long long cstride, int sp
         *cp = subtract ? sub_t(*cp, acc) : acc;
     }
 }
+template <class T>
+struct splitk_reduce_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        splitk_reduce_body<T>(b, g, a...);
+    }
+};
 
 // strided batch (gridDim.y); split-K of a batch needs packed outputs (ldc == m, c_bs == m * n, no cmap)
 struct gemm_batch {
@@ -296,19 +313,6 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     constexpr int NP = sizeof(T) == 16 ? 2 : 1;
     constexpr size_t lds = (size_t)(PIPE ? 2 : 1) * NP * GK * ((BM + GPAD) + (BN + GPAD)) * sizeof(double);
     const bool arc = a_rs == 1, bkc = b_ks == 1;
-    using kern_t = void (*)(long long, long long, long long, const T*, long long, long long, int, const T*, long long,
-                            long long, int, T*, long long, long long, long long, int, int, int, long long, long long,
-                            long long, const int*, int, const uint8_t*, long long, long long, int);
-    const kern_t kern = arc ? (bkc ? (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, true, true>
-                                   : (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, true, false>)
-                            : (bkc ? (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, false, true>
-                                   : (kern_t)&gemm_mfma<T, BM, BN, WM, WN, PIPE, false, false>);
-    static bool attr_set[4] = {false, false, false, false};
-    if (lds > 64 * 1024 && !attr_set[arc * 2 + bkc]) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        attr_set[arc * 2 + bkc] = true;
-    }
     const long long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
     const long long tiles = tiles_m * tiles_n;
     const bool can_split = bt.count == 1 || (ldc == m && bt.c_bs == m * n && !bt.cmap);
@@ -346,14 +350,19 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     // narrow outputs: neighbouring workgroups share the same rows of A (served from L2 / Infinity Cache)
     static const bool xcd_order = true;
     const int col_fastest = (tiles_n <= 8 ? 1 : 0) | (xcd_order ? 0 : 2);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits), dim3(256), lds, ctx->stream, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, b_cs, conjB, Cout, ldo,
-                       kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,
-                       bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride, splits > 1 ? 0 : bt.subtract);
-    QIL_HIP(hipGetLastError());
+#define QIL_GEMM_K(ARCv, BKCv)                                                                                               \
+    QIL_TRY((qil_klaunch<gemm_mfma_k<T, BM, BN, WM, WN, PIPE, ARCv, BKCv>>(                                                      \
+        ctx, dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits), dim3(256), lds, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, \
+        b_cs, conjB, Cout, ldo, kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,        \
+        bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride, splits > 1 ? 0 : bt.subtract)))
+    if (arc && bkc) QIL_GEMM_K(true, true);
+    else if (arc) QIL_GEMM_K(true, false);
+    else if (bkc) QIL_GEMM_K(false, true);
+    else QIL_GEMM_K(false, false);
+#undef QIL_GEMM_K
     if (splits > 1) {
         // a packed batch reduces as one m x (n * count) matrix
-        hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)std::min<long long>((cstride + 255) / 256, 2048)), dim3(256),
-                           0, ctx->stream, (const T*)Cout, cstride, splits, m, n * bt.count, C, ldc, bt.subtract);
+        QIL_TRY((qil_klaunch<splitk_reduce_k<T>>(ctx, dim3((unsigned)std::min<long long>((cstride + 255) / 256, 2048)), dim3(256), 0, (const T*)Cout, cstride, splits, m, n * bt.count, C, ldc, bt.subtract)));
         QIL_HIP(hipGetLastError());
         qil_ctx_free(ctx, wsp);
     }
@@ -396,7 +405,7 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
 
 // ------------------------------------------------------------------ one-sided Jacobi SVD
 template <class T>
-__global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long lda, long long m,
+__device__ __forceinline__ void jacobi_round_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ A, long long lda, long long m,
                                                     T* __restrict__ V, long long ldv, int vrows, int n,
                                                     int npad, int round, double tol,
                                                     int* __restrict__ rotated,
@@ -453,6 +462,14 @@ __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ A, long long
         vq[r] = y;
     }
 }
+template <class T>
+struct jacobi_round_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        jacobi_round_body<T>(b, g, a...);
+    }
+};
 
 
 // One column pair of an in-LDS block round, handled by one wave.  KM > 0: at most KM elements per lane (m, vrows <= 64 KM);
@@ -543,7 +560,7 @@ __device__ __forceinline__ int block_pair_rotate(T* __restrict__ ap, T* __restri
 // pair among the 2 BB columns, which also covers the pairs inside each block once per sweep -- and writes the columns
 // back.  A sweep is nb - 1 launches instead of n - 1.
 template <class T, int BB>
-__global__ __launch_bounds__(64 * BB) void jacobi_block_round(T* __restrict__ A, long long lda, int m,
+__device__ __forceinline__ void jacobi_block_round_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ A, long long lda, int m,
                                                               T* __restrict__ V, long long ldv, int vrows, int n, int nb,
                                                               int round, int all_pairs, double tol,
                                                               int* __restrict__ rotated,
@@ -656,12 +673,20 @@ __global__ __launch_bounds__(64 * BB) void jacobi_block_round(T* __restrict__ A,
     unstage(A, lda, m, As, la);
     unstage(V, ldv, vrows, Vs, lv);
 }
+template <class T, int BB>
+struct jacobi_block_round_k {
+    static constexpr int NT = 64 * BB, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        jacobi_block_round_body<T, BB>(b, g, a...);
+    }
+};
 
 // MODE 1: A and V staged in LDS for the whole iteration; MODE 2: only A in LDS, V in global memory (complex operands of
 // 2 chi x chi sites with chi ~ 64: A fits the CU's LDS, A and V together do not) -- the dot products and the rotation
 // of A, which every round's critical path waits for, still run out of LDS; MODE 0: both in global memory.
 template <class T, int MODE>
-__global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long long lda, int m,
+__device__ __forceinline__ void jacobi_fused_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ A, long long lda, int m,
                                                      T* __restrict__ V, long long ldv, int n, double tol,
                                                      int max_sweeps, double* __restrict__ norms, double negl_rel) {
     extern __shared__ __attribute__((aligned(16))) char jf_smem[];
@@ -720,9 +745,17 @@ __global__ __launch_bounds__(1024) void jacobi_fused(T* __restrict__ A, long lon
             for (int t = tid; t < n * n; t += 1024) V[(t % n) + ldv * (t / n)] = Vw[(t % n) + lv * (t / n)];
     }
 }
+template <class T, int MODE>
+struct jacobi_fused_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        jacobi_fused_body<T, MODE>(b, g, a...);
+    }
+};
 
 template <class T>
-__global__ __launch_bounds__(256) void col_norms(const T* __restrict__ A, long long lda, long long m,
+__device__ __forceinline__ void col_norms_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ A, long long lda, long long m,
                                                  double* __restrict__ out) {
     __shared__ double red[4];
     const T* a = A + lda * blockIdx.x;
@@ -731,9 +764,17 @@ __global__ __launch_bounds__(256) void col_norms(const T* __restrict__ A, long l
     block_sum<1>(v, red);
     if (threadIdx.x == 0) out[blockIdx.x] = sqrt(v[0]);
 }
+template <class T>
+struct col_norms_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        col_norms_body<T>(b, g, a...);
+    }
+};
 
 template <class T>
-__global__ void set_identity(T* __restrict__ V, long long ldv, int n) {
+__device__ __forceinline__ void set_identity_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ V, long long ldv, int n) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < (long long)n * n;
          t += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(t % n), c = (int)(t / n);
@@ -742,10 +783,18 @@ __global__ void set_identity(T* __restrict__ V, long long ldv, int n) {
         V[r + ldv * c] = v;
     }
 }
+template <class T>
+struct set_identity_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        set_identity_body<T>(b, g, a...);
+    }
+};
 
 // dst[:, j] = src[:, perm[j]] * scale[j]   (conjT = 0)   or   dst[j, i] = conj(src[i, perm[j]]) * scale[j]
 template <class T>
-__global__ void gather_cols(const T* __restrict__ src, long long lds_, long long rows,
+__device__ __forceinline__ void gather_cols_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ src, long long lds_, long long rows,
                             const int* __restrict__ perm, const double* __restrict__ scale, T* __restrict__ dst,
                             long long ldd, int r0, int conjT) {
     const long long total = rows * r0;
@@ -761,9 +810,17 @@ __global__ void gather_cols(const T* __restrict__ src, long long lds_, long long
             dst[i + ldd * j] = v;
     }
 }
+template <class T>
+struct gather_cols_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        gather_cols_body<T>(b, g, a...);
+    }
+};
 
 template <class T, bool CONJ = true>
-__global__ void conj_transpose(const T* __restrict__ A, long long lda, long long m, long long n,
+__device__ __forceinline__ void conj_transpose_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ A, long long lda, long long m, long long n,
                                T* __restrict__ At, long long ldt) {
     const long long total = m * n;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
@@ -773,6 +830,14 @@ __global__ void conj_transpose(const T* __restrict__ A, long long lda, long long
         At[j + ldt * i] = CONJ ? conj_t(v) : v;
     }
 }
+template <class T, bool CONJ = true>
+struct conj_transpose_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        conj_transpose_body<T, CONJ>(b, g, a...);
+    }
+};
 
 // Whole CGS2 QR in ONE launch of ONE 1024-thread workgroup (small/medium panels).  Per column, two
 // project/subtract passes then normalisation.  The projections c[i] = q_i^H y for ALL previous columns
@@ -791,7 +856,7 @@ __global__ void conj_transpose(const T* __restrict__ A, long long lda, long long
 // written back at the end -- every phase of every column is a dependent round trip to wherever the slice lives, and
 // a 512 x 55 sketch out of L2 took 22 us per column (1.2 ms per QR, 3/4 of an n = 24 RSVD encode).
 template <class T, bool LDS>
-__global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long ldg, long long mtot, int n,
+__device__ __forceinline__ void gs_fused_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ Ag, long long ldg, long long mtot, int n,
                                                  T* __restrict__ R, long long ldr,
                                                  const double* __restrict__ ref_norm, long long chunk_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -977,6 +1042,14 @@ __global__ __launch_bounds__(1024) void gs_fused(T* __restrict__ Ag, long long l
             for (int r = lane; r < m; r += 64) dst[r] = src[r];
         }
 }
+template <class T, bool LDS>
+struct gs_fused_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        gs_fused_body<T, LDS>(b, g, a...);
+    }
+};
 
 // ------------------------------------------------------------------ Householder panel (in LDS)
 // Thin QR of one panel P (m x b, b <= 32) resident in LDS, the intra-panel step of the blocked QR below (r02; it
@@ -1018,7 +1091,7 @@ template <class T, int KM>
 constexpr int hh_panel_waves() { return KM * (int)(sizeof(T) / 8) > 18 ? 8 : 16; }   // long columns: 256 registers per lane
 
 template <class T, int KM, bool PROF = false>
-__global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __restrict__ P, long long lda, int m, int b,
+__device__ __forceinline__ void hh_panel_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ P, long long lda, int m, int b,
                                                                          T* __restrict__ R, long long ldr,
                                                                          const double* __restrict__ ref_norm,
                                                                          long long* __restrict__ prof = nullptr) {
@@ -1322,6 +1395,14 @@ __global__ __launch_bounds__((64 * hh_panel_waves<T, KM>())) void hh_panel(T* __
         }
     }
 }
+template <class T, int KM, bool PROF = false>
+struct hh_panel_k {
+    static constexpr int NT = (64 * hh_panel_waves<T, KM>()), MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        hh_panel_body<T, KM, PROF>(b, g, a...);
+    }
+};
 
 // true when the panel fits (LDS and rows-per-lane budget); launches it
 template <class T>
@@ -1334,14 +1415,8 @@ int hh_panel_launch(qil_context* ctx, T* P, long long lda, long long m, int b, T
     const int km = (int)((m + 63) / 64);
 #define QIL_HHP(KMv)                                                                                                   \
     do {                                                                                                               \
-        static bool attr = false;                                                                                      \
-        if (!attr) {                                                                                                   \
-            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hh_panel<T, KMv>),                              \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                      \
-            attr = true;                                                                                               \
-        }                                                                                                              \
-        hipLaunchKernelGGL((hh_panel<T, KMv>), dim3(1), dim3(64 * hh_panel_waves<T, KMv>()), lds, ctx->stream, P, lda, (int)m, b, R, \
-                           ldr, ref_norm, (long long*)nullptr);                                                                             \
+        QIL_TRY((qil_klaunch<hh_panel_k<T, KMv>>(ctx, dim3(1), dim3(64 * hh_panel_waves<T, KMv>()), lds, P, lda, (int)m, b, R, \
+                           ldr, ref_norm, (long long*)nullptr)));                                                                             \
     } while (0)
     if (km <= 2) QIL_HHP(2);
     else if (km <= 4) QIL_HHP(4);
@@ -1363,17 +1438,9 @@ int gs_fused_launch(qil_context* ctx, unsigned nwg, T* A, long long lda, long lo
     const size_t lds = ((size_t)2 * (n + (n & 1)) + (size_t)(rows | 1) * n) * sizeof(T);
     static const bool use_lds = true;
     if (use_lds && lds <= 150 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_fused<T, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-            attr = true;
-        }
-        hipLaunchKernelGGL((gs_fused<T, true>), dim3(nwg), dim3(1024), lds, ctx->stream, A, lda, mtot, n, R, ldr, ref_norm,
-                           chunk_rows);
+        QIL_TRY((qil_klaunch<gs_fused_k<T, true>>(ctx, dim3(nwg), dim3(1024), lds, A, lda, mtot, n, R, ldr, ref_norm, chunk_rows)));
     } else {
-        hipLaunchKernelGGL((gs_fused<T, false>), dim3(nwg), dim3(1024), (size_t)n * sizeof(T), ctx->stream, A, lda, mtot, n,
-                           R, ldr, ref_norm, chunk_rows);
+        QIL_TRY((qil_klaunch<gs_fused_k<T, false>>(ctx, dim3(nwg), dim3(1024), (size_t)n * sizeof(T), A, lda, mtot, n, R, ldr, ref_norm, chunk_rows)));
     }
     QIL_HIP(hipGetLastError());
     return QIL_OK;
@@ -1404,7 +1471,7 @@ constexpr int BJ_W = 2 * BJ_B;
 // factorisation, no dot products, three short phases per round.  (The first version -- Cholesky G = L L^H followed by a
 // one-sided sweep on L^H -- converged in the same number of block sweeps at ~1.7x the cost per visit and was removed.)
 template <class T>
-__global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* __restrict__ Jm, double tol,
+__device__ __forceinline__ void bj_pair_evd_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ Gm, T* __restrict__ Jm, double tol,
                                                     int max_sweeps, int* __restrict__ flag,
                                                     const int* __restrict__ big_second,
                                                     const double* __restrict__ negligible) {
@@ -1575,6 +1642,14 @@ __global__ __launch_bounds__(512) void bj_pair_evd(const T* __restrict__ Gm, T* 
         J[r + N * dest[c]] = acc;
     }
 }
+template <class T>
+struct bj_pair_evd_k {
+    static constexpr int NT = 512, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        bj_pair_evd_body<T>(b, g, a...);
+    }
+};
 
 // Runs block sweeps on [Wk; I] (copied into a padded, double-buffered work area) until no pair's Gram matrix
 // has a relative off-diagonal above `tol` (or `max_sweeps`).  Returns the buffer holding the result:
@@ -1622,21 +1697,14 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
         for (int i = 0; i < np; ++i)
             big2[(size_t)r * np + i] = lab[(size_t)r * nb + 2 * i] > lab[(size_t)r * nb + 2 * i + 1] ? 1 : 0;
     QIL_TRY(qil_ctx_alloc(ctx, cmap.size() * sizeof(int), &cmapd));
-    QIL_HIP(hipMemcpyAsync(cmapd, cmap.data(), cmap.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(cmapd, cmap.data(), cmap.size() * sizeof(int), hipMemcpyHostToDevice, qil_stream(ctx)));
     T* Xc = static_cast<T*>(xa);
     T* Xn = static_cast<T*>(xb);
-    QIL_HIP(hipMemsetAsync(Xc, 0, (size_t)(ldx * cpad) * sizeof(T), ctx->stream));
-    QIL_HIP(hipMemcpy2DAsync(Xc, (size_t)ldx * sizeof(T), Wk, (size_t)ldw * sizeof(T), (size_t)rows * sizeof(T),
-                             (size_t)cols, hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(set_identity<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
-                       dim3(256), 0, ctx->stream, Xc + rows, ldx, (int)cols);
+    QIL_TRY(qil_dev_zero(ctx, Xc, (size_t)(ldx * cpad) * sizeof(T)));
+    QIL_TRY(qil_dev_copy2d(ctx, Xc, (size_t)ldx * sizeof(T), Wk, (size_t)ldw * sizeof(T), (size_t)rows * sizeof(T),
+                             (size_t)cols));
+    QIL_TRY((qil_klaunch<set_identity_k<T>>(ctx, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)), dim3(256), 0, Xc + rows, ldx, (int)cols)));
     const size_t lds = (size_t)2 * BJ_W * (BJ_W + 1) * sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bj_pair_evd<T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     const int opH = sizeof(T) == 16 ? 2 : 1;
     static const int inner_sweeps = 1;
     gemm_batch bg, bu;
@@ -1649,20 +1717,18 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
     bu.cmap_blk = BJ_B;
     int status = QIL_OK;
     for (int sweep = 0; sweep < max_sweeps && status == QIL_OK; ++sweep) {
-        QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
+        QIL_TRY(qil_dev_zero(ctx, flag, 2 * sizeof(int)));
         for (int r = 0; r < nr && status == QIL_OK; ++r) {
             status = gemm_dispatch<T>(ctx, opH, 0, BJ_W, BJ_W, rows, Xc, ldx, Xc, ldx, static_cast<T*>(gbuf), BJ_W, bg);
             if (status != QIL_OK) break;
-            hipLaunchKernelGGL((bj_pair_evd<T>), dim3((unsigned)np), dim3(512), lds, ctx->stream, (const T*)gbuf,
-                               static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag,
-                               static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np, negligible);
+            QIL_TRY((qil_klaunch<bj_pair_evd_k<T>>(ctx, dim3((unsigned)np), dim3(512), lds, (const T*)gbuf, static_cast<T*>(jbuf), tol, inner_sweeps, (int*)flag, static_cast<const int*>(cmapd) + (size_t)nr * nb + (size_t)r * np, negligible)));
             bu.cmap = static_cast<const int*>(cmapd) + (size_t)r * nb;
             status = gemm_dispatch<T>(ctx, 0, 0, rt, BJ_W, BJ_W, Xc, ldx, static_cast<const T*>(jbuf), BJ_W, Xn, ldx, bu);
             std::swap(Xc, Xn);
         }
         int hh[2] = {0, 0};
-        QIL_HIP(hipMemcpyAsync(hh, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_HIP(hipMemcpyAsync(hh, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));
         float worst;
         memcpy(&worst, &hh[1], sizeof(float));
         if (getenv("QIL_SVD_DEBUG"))
@@ -1673,7 +1739,7 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
             break;
         }
     }
-    QIL_HIP(hipStreamSynchronize(ctx->stream));   // cmap (host vector) upload has completed
+    QIL_HIP(qil_stream_sync(ctx));   // cmap (host vector) upload has completed
     qil_ctx_free(ctx, Xc == xa ? xb : xa);
     qil_ctx_free(ctx, gbuf);
     qil_ctx_free(ctx, jbuf);
@@ -1686,7 +1752,7 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
 }
 
 // out[0] = rel * sum_j norms[j]^2  (the threshold below which a column counts as rounding residue)
-__global__ __launch_bounds__(256) void negligible_threshold(const double* __restrict__ norms, int n, double rel,
+__device__ __forceinline__ void negligible_threshold_body(const uint3 blockIdx, const uint3 gridDim, const double* __restrict__ norms, int n, double rel,
                                                             double* __restrict__ out) {
     __shared__ double red[4];
     double v = 0;
@@ -1696,10 +1762,17 @@ __global__ __launch_bounds__(256) void negligible_threshold(const double* __rest
     __syncthreads();
     if (threadIdx.x == 0) out[0] = rel * ((red[0] + red[1]) + (red[2] + red[3]));
 }
+struct negligible_threshold_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        negligible_threshold_body(b, g, a...);
+    }
+};
 
 // out[0] = max over i != j of |G[i, j]| (as the bit pattern of a non-negative double: atomicMax on the integer view)
 template <class T>
-__global__ __launch_bounds__(256) void offdiag_max(const T* __restrict__ G, long long ldg, long long n,
+__device__ __forceinline__ void offdiag_max_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ G, long long ldg, long long n,
                                                    unsigned long long* __restrict__ out) {
     double v = 0;
     for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n * n; t += (long long)gridDim.x * 256) {
@@ -1715,6 +1788,14 @@ __global__ __launch_bounds__(256) void offdiag_max(const T* __restrict__ G, long
     }
     if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
 }
+template <class T>
+struct offdiag_max_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        offdiag_max_body<T>(b, g, a...);
+    }
+};
 
 // CGS2 keeps Q orthonormal only while the operand is numerically of full rank ("twice is enough" needs
 // kappa * eps < 1).  Operands that are not -- product bonds before their truncation, sketches wider than the rank,
@@ -1732,13 +1813,12 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * sizeof(T), &gbuf));
     QIL_TRY(qil_ctx_alloc(ctx, 256, &mx));
     for (int pass = 0; pass < 3; ++pass) {
-        QIL_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned long long), ctx->stream));
+        QIL_TRY(qil_dev_zero(ctx, mx, sizeof(unsigned long long)));
         QIL_TRY(gemm_dispatch<T>(ctx, sizeof(T) == 16 ? 2 : 1, 0, n, n, m, Q, ldq, Q, ldq, static_cast<T*>(gbuf), n));
-        hipLaunchKernelGGL(offdiag_max<T>, dim3((unsigned)std::min<long long>((n * n + 255) / 256, 1024)), dim3(256), 0,
-                           ctx->stream, (const T*)gbuf, n, n, (unsigned long long*)mx);
+        QIL_TRY((qil_klaunch<offdiag_max_k<T>>(ctx, dim3((unsigned)std::min<long long>((n * n + 255) / 256, 1024)), dim3(256), 0, (const T*)gbuf, n, n, (unsigned long long*)mx)));
         double worst = 0;
-        QIL_HIP(hipMemcpyAsync(&worst, mx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_HIP(hipMemcpyAsync(&worst, mx, sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));
         if (dbg) fprintf(stderr, "[qr] max |Q^H Q - I| off-diagonal %.3g\n", worst);
         if (orthonormal) *orthonormal = !(worst > 1e-9);
         if (!(worst > 1e-11) || pass == 2) break;
@@ -1748,8 +1828,8 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * sizeof(T), &rnew));
             QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, n, n, n, static_cast<const T*>(gbuf), n, (const T*)R, ldr,
                                      static_cast<T*>(rnew), n));
-            QIL_HIP(hipMemcpy2DAsync(R, (size_t)ldr * sizeof(T), rnew, (size_t)n * sizeof(T), (size_t)n * sizeof(T),
-                                     (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+            QIL_TRY(qil_dev_copy2d(ctx, R, (size_t)ldr * sizeof(T), rnew, (size_t)n * sizeof(T), (size_t)n * sizeof(T),
+                                     (size_t)n));
             qil_ctx_free(ctx, rnew);
         }
     }
@@ -1768,7 +1848,7 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
 // gauge-invariant quantity sees) and the Jacobi iteration is skipped.  Rank-deficient operands -- every product bond of
 // the signal pipelines -- fail the first test (sigma_min <= min |r_ii|) before anything is inverted.
 template <class T>
-__global__ __launch_bounds__(256) void tri_stats(const T* __restrict__ R, long long ldr, int k, int upper_only,
+__device__ __forceinline__ void tri_stats_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ R, long long ldr, int k, int upper_only,
                                                  double* __restrict__ out /* per block: [fro2, min |r_ii|^2] */) {
     __shared__ double red[8];
     double f = 0, d = 1e300;
@@ -1792,6 +1872,14 @@ __global__ __launch_bounds__(256) void tri_stats(const T* __restrict__ R, long l
         out[2 * blockIdx.x + 1] = fmin(fmin(red[4], red[5]), fmin(red[6], red[7]));
     }
 }
+template <class T>
+struct tri_stats_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        tri_stats_body<T>(b, g, a...);
+    }
+};
 
 __device__ __forceinline__ double inv_t(double u) { return 1.0 / u; }
 __device__ __forceinline__ c64 inv_t(c64 u) {
@@ -1806,7 +1894,7 @@ __device__ __forceinline__ c64 neg_t(c64 a) { return c64{-a.re, -a.im}; }
 // X (column block b of the k x k result) = inverse of the 64 x 64 (or smaller, last) upper-triangular diagonal block b of R:
 // thread j solves U x_j = e_j by back substitution, the block in LDS
 template <class T>
-__global__ __launch_bounds__(64) void trtri_diag(const T* __restrict__ R, long long ldr, int k, T* __restrict__ X, long long ldx) {
+__device__ __forceinline__ void trtri_diag_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ R, long long ldr, int k, T* __restrict__ X, long long ldx) {
     extern __shared__ __attribute__((aligned(16))) char trtri_smem[];
     T* U = reinterpret_cast<T*>(trtri_smem);
     T* Xs = U + 64 * 65;
@@ -1828,12 +1916,28 @@ __global__ __launch_bounds__(64) void trtri_diag(const T* __restrict__ R, long l
     for (int c = 0; c < nb; ++c)
         if (j < nb && j <= c) X[(b0 + j) + ldx * (long long)(b0 + c)] = Xs[j + 65 * c];
 }
+template <class T>
+struct trtri_diag_k {
+    static constexpr int NT = 64, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        trtri_diag_body<T>(b, g, a...);
+    }
+};
 
 template <class T>
-__global__ void negate_block(T* __restrict__ A, long long lda, int m, int n) {
+__device__ __forceinline__ void negate_block_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ A, long long lda, int m, int n) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < (long long)m * n; t += (long long)gridDim.x * blockDim.x)
         A[(t % m) + lda * (t / m)] = neg_t(A[(t % m) + lda * (t / m)]);
 }
+template <class T>
+struct negate_block_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        negate_block_body<T>(b, g, a...);
+    }
+};
 
 // The off-diagonal blocks of Xinv = R^-1 (k x k, ld k) from its inverted diagonal blocks of width `blk` (already in place):
 // neighbouring blocks are merged level by level, [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1]  (MFMA GEMMs)
@@ -1854,8 +1958,7 @@ int trtri_merge(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv, int
             // T = B C^-1 (sa x sc), X12 = -(A^-1 T)
             QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sa, sc, sc, R + a0 + ldr * (long long)c0, ldr, Xinv + c0 + (long long)k * c0, k, Tm, sa));
             QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sa, sc, sa, Xinv + a0 + (long long)k * a0, k, Tm, sa, Xinv + a0 + (long long)k * c0, k));
-            hipLaunchKernelGGL(negate_block<T>, dim3((unsigned)std::min<long long>(((long long)sa * sc + 255) / 256, 1024)), dim3(256), 0,
-                               ctx->stream, Xinv + a0 + (long long)k * c0, (long long)k, sa, sc);
+            QIL_TRY((qil_klaunch<negate_block_k<T>>(ctx, dim3((unsigned)std::min<long long>(((long long)sa * sc + 255) / 256, 1024)), dim3(256), 0, Xinv + a0 + (long long)k * c0, (long long)k, sa, sc)));
             next.push_back(Blk{a0, sa + sc});
         }
         if (cur.size() & 1) next.push_back(cur.back());
@@ -1869,16 +1972,10 @@ int trtri_merge(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv, int
 // Xinv (k x k, ld k, zero below the diagonal) = R^-1 for upper-triangular R
 template <class T>
 int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
-    QIL_HIP(hipMemsetAsync(Xinv, 0, (size_t)k * k * sizeof(T), ctx->stream));
+    QIL_TRY(qil_dev_zero(ctx, Xinv, (size_t)k * k * sizeof(T)));
     const int nb = (k + 63) / 64;
     constexpr size_t diag_lds = (size_t)2 * 64 * 65 * sizeof(T);
-    static bool attr = false;
-    if (!attr) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trtri_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)diag_lds));
-        attr = true;
-    }
-    hipLaunchKernelGGL(trtri_diag<T>, dim3((unsigned)nb), dim3(64), diag_lds, ctx->stream, R, ldr, k, Xinv, (long long)k);
+    QIL_TRY((qil_klaunch<trtri_diag_k<T>>(ctx, dim3((unsigned)nb), dim3(64), diag_lds, R, ldr, k, Xinv, (long long)k)));
     QIL_HIP(hipGetLastError());
     return trtri_merge<T>(ctx, R, ldr, k, Xinv, 64);
 }
@@ -1898,7 +1995,7 @@ int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
 // R^-1 = E^H D^-1/2.  A pivot that is not above piv_rel times its original diagonal entry raises *flag (the caller then takes
 // the Householder route; everything written is discarded).
 template <class T, int TS>
-__global__ __launch_bounds__(1024) void chol_inv_block(const T* __restrict__ G, long long ldg, int nb, T* __restrict__ Rout,
+__device__ __forceinline__ void chol_inv_block_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ G, long long ldg, int nb, T* __restrict__ Rout,
                                                        long long ldr, T* __restrict__ Xout, long long ldx, double piv_rel,
                                                        int* __restrict__ flag) {
     constexpr int NBK = 32 * TS;
@@ -2016,6 +2113,14 @@ __global__ __launch_bounds__(1024) void chol_inv_block(const T* __restrict__ G, 
             if (tc == tr && k <= i) Xout[k + ldx * i] = scale_t(conj_t(e2[a][b]), rs);
         }
 }
+template <class T, int TS>
+struct chol_inv_block_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        chol_inv_block_body<T, TS>(b, g, a...);
+    }
+};
 
 // G (n x n, ld n, Hermitian positive definite; DESTROYED) = R^H R;  Rm (upper triangular, ld n) and Xm = R^-1 (ld n), both
 // zero below the diagonal; *flag (device) is raised on a bad pivot.  Diagonal blocks of 32 TS columns in one workgroup each,
@@ -2023,14 +2128,12 @@ __global__ __launch_bounds__(1024) void chol_inv_block(const T* __restrict__ G, 
 template <class T, int TS>
 int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
     constexpr int NBK = 32 * TS;
-    QIL_HIP(hipMemsetAsync(Rm, 0, (size_t)n * n * sizeof(T), ctx->stream));
-    QIL_HIP(hipMemsetAsync(Xm, 0, (size_t)n * n * sizeof(T), ctx->stream));
+    QIL_TRY(qil_dev_zero(ctx, Rm, (size_t)n * n * sizeof(T)));
+    QIL_TRY(qil_dev_zero(ctx, Xm, (size_t)n * n * sizeof(T)));
     const int opH = sizeof(T) == 16 ? 2 : 1;
     for (int j0 = 0; j0 < n; j0 += NBK) {
         const int nbj = std::min(NBK, n - j0), rest = n - j0 - nbj;
-        hipLaunchKernelGGL((chol_inv_block<T, TS>), dim3(1), dim3(1024), 0, ctx->stream, (const T*)(G + j0 + (long long)n * j0),
-                           (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n,
-                           1e-11, flag);
+        QIL_TRY((qil_klaunch<chol_inv_block_k<T, TS>>(ctx, dim3(1), dim3(1024), 0, (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
         QIL_HIP(hipGetLastError());
         if (rest > 0) {
             T* Rjr = Rm + j0 + (long long)n * (j0 + nbj);
@@ -2069,7 +2172,7 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     QIL_TRY(qil_ctx_alloc(ctx, nn, &x2));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * sizeof(T), &q1));
     QIL_TRY(qil_ctx_alloc(ctx, 256, &fl));
-    QIL_HIP(hipMemsetAsync(fl, 0, sizeof(int), ctx->stream));
+    QIL_TRY(qil_dev_zero(ctx, fl, sizeof(int)));
     T *G = static_cast<T*>(g), *R1 = static_cast<T*>(r1), *X1 = static_cast<T*>(x1), *R2 = static_cast<T*>(r2),
       *X2 = static_cast<T*>(x2), *Q1 = static_cast<T*>(q1);
     QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, n, n, m, A, lda, A, lda, G, n));
@@ -2078,8 +2181,8 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, n, n, m, Q1, m, Q1, m, G, n));
     QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
     int bad = 0;
-    QIL_HIP(hipMemcpyAsync(&bad, fl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(&bad, fl, sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     if (bad) {
         release();
         return QIL_OK;
@@ -2103,9 +2206,9 @@ int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, do
     double hb[2 * NB];
     double h[2];
     auto stats = [&](const T* M, long long ldm) -> int {
-        hipLaunchKernelGGL(tri_stats<T>, dim3(NB), dim3(256), 0, ctx->stream, M, ldm, k, 1, (double*)st);
-        QIL_HIP(hipMemcpyAsync(hb, st, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_TRY((qil_klaunch<tri_stats_k<T>>(ctx, dim3(NB), dim3(256), 0, M, ldm, k, 1, (double*)st)));
+        QIL_HIP(hipMemcpyAsync(hb, st, sizeof(hb), hipMemcpyDeviceToHost, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));
         h[0] = 0;
         h[1] = 1e300;
         for (int b = 0; b < NB; ++b) {          // fixed order
@@ -2152,7 +2255,7 @@ int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, do
 // travels through LDS.  (Measured, tools/micro/jacobi_round_cost.hip, k = 256 f64: the predicated version spent 1.07 us per
 // inner round -- ~40 exec-mask branches -- of a 12.1 us round.)
 template <class T, int BB, int KM, int G, bool AP, bool PROF = false>
-__global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__ A, long long lda, int m, int n, int nb,
+__device__ __forceinline__ void jacobi_block_round_nov_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ A, long long lda, int m, int n, int nb,
                                                                  int round, double tol, int* __restrict__ rotated,
                                                                  const double* __restrict__ negligible,
                                                                  long long* __restrict__ prof = nullptr) {
@@ -2354,6 +2457,14 @@ __global__ __launch_bounds__(BB * G) void jacobi_block_round_nov(T* __restrict__
         prof[4] += 1;
     }
 }
+template <class T, int BB, int KM, int G, bool AP, bool PROF = false>
+struct jacobi_block_round_nov_k {
+    static constexpr int NT = BB * G, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        jacobi_block_round_nov_body<T, BB, KM, G, AP, PROF>(b, g, a...);
+    }
+};
 
 template <class T, int BB, int KM, int G>
 constexpr size_t block_round_nov_lds() {
@@ -2365,20 +2476,10 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
                            const double* negl) {
     constexpr size_t lds = block_round_nov_lds<T, BB, KM, G>();
     static_assert(lds <= 156 * 1024, "column blocks must fit the LDS");
-    static bool attr = false;
-    if (!attr) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round_nov<T, BB, KM, G, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr = true;
-    }
     if (round == 0)
-        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, true>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
-                           k, nblk, round, tol, flag, negl);
+        QIL_TRY((qil_klaunch<jacobi_block_round_nov_k<T, BB, KM, G, true>>(ctx, dim3(nblk / 2), dim3(BB * G), lds, X, ldx, k, k, nblk, round, tol, flag, negl)));
     else
-        hipLaunchKernelGGL((jacobi_block_round_nov<T, BB, KM, G, false>), dim3(nblk / 2), dim3(BB * G), lds, ctx->stream, X, ldx, k,
-                           k, nblk, round, tol, flag, negl);
+        QIL_TRY((qil_klaunch<jacobi_block_round_nov_k<T, BB, KM, G, false>>(ctx, dim3(nblk / 2), dim3(BB * G), lds, X, ldx, k, k, nblk, round, tol, flag, negl)));
     return QIL_OK;
 }
 
@@ -2761,28 +2862,18 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
 }
 
 template <class T, int BB, bool AP>
-__global__ __launch_bounds__(512) void gram_block_round(gram_round_args<T> a) {
-    gram_block_round_body<T, BB, AP>(a, blockIdx.x);
-}
+struct gram_block_round_k {
+    static constexpr int NT = 512, MINW = 1;
+    static __device__ __forceinline__ void run(const uint3 b, const uint3, gram_round_args<T> a) { gram_block_round_body<T, BB, AP>(a, b.x); }
+};
 
 template <class T, int BB>
 int launch_gram_round(qil_context* ctx, T* X, long long ldx, int k, int nblk, int round, double tol, int* flag, const int* prev,
                       const double* negl) {
     const size_t lds = gram_round_lds<T, BB>(k);
-    static bool attr = false;
-    if (!attr) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_block_round<T, BB, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_block_round<T, BB, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
     gram_round_args<T> a{X, ldx, k, k, nblk, round, tol, flag, prev, negl, nullptr};
-    if (round == 0)
-        hipLaunchKernelGGL((gram_block_round<T, BB, true>), dim3(nblk / 2), dim3(512), lds, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((gram_block_round<T, BB, false>), dim3(nblk / 2), dim3(512), lds, ctx->stream, a);
-    return QIL_OK;
+    if (round == 0) return qil_klaunch<gram_block_round_k<T, BB, true>>(ctx, dim3(nblk / 2), dim3(512), lds, a);
+    return qil_klaunch<gram_block_round_k<T, BB, false>>(ctx, dim3(nblk / 2), dim3(512), lds, a);
 }
 
 // B (p x q, ldb; destroyed) = Uiso diag(S) V^H:  Uiso (p x k, k = min(p, q)) orthonormal columns sorted by descending
@@ -2827,13 +2918,14 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!dbg) return;
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)qil_stream_sync(ctx);
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[svd-left] %lld x %lld: %s %.2f ms\n", p, q, what,
                 std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
     const bool tall = p >= q;
+    qil_progress_phase(ctx, 1);                              // lock-step batches: QR < grading / second QR < certificate < sweeps < factors
     const int cj = sizeof(T) == 16 ? 2 : 1;
     const unsigned gk = (unsigned)std::min<long long>((k * k + 255) / 256, 65536);
     void *rbuf = nullptr, *xbuf = nullptr, *bh = nullptr, *flag = nullptr, *nrm = nullptr, *negl = nullptr, *wbuf = nullptr;
@@ -2855,8 +2947,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             void* tmp = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)(p * q) * sizeof(T), &tmp));
             QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, p, q, q, B, ldb, R, k, static_cast<T*>(tmp), p));
-            QIL_HIP(hipMemcpy2DAsync(B, (size_t)ldb * sizeof(T), tmp, (size_t)p * sizeof(T), (size_t)p * sizeof(T), (size_t)q,
-                                     hipMemcpyDeviceToDevice, ctx->stream));
+            QIL_TRY(qil_dev_copy2d(ctx, B, (size_t)ldb * sizeof(T), tmp, (size_t)p * sizeof(T), (size_t)p * sizeof(T), (size_t)q));
             qil_ctx_free(ctx, tmp);
             release();
             return QIL_OK;
@@ -2873,15 +2964,16 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         // grading shows in R's diagonal: mean |r_ii|^2 against min |r_ii|^2 (measured on the truncated sites of the same
         // sweep, ratio ~1e5: 13 sweeps on R, 9 after the second QR).
         bool qr2 = false;
+        qil_progress_phase(ctx, 2);
         static const double grade = 1e3;   // (0 = never; 1e3: compress! chi 256 -> 128 85.8 -> 73.4 ms, 512 -> 256 211 -> 197 ms, complex 112 -> 104 ms, exact compress!(apply) 389 -> 348 ms; 1e5 / 1e8: 77 / 75 ms)
         if (!qr2 && grade > 0.0) {
             void* st = nullptr;
             constexpr int NB = 16;
             QIL_TRY(qil_ctx_alloc(ctx, 2 * NB * sizeof(double), &st));
             double hb[2 * NB];
-            hipLaunchKernelGGL(tri_stats<T>, dim3(NB), dim3(256), 0, ctx->stream, (const T*)R, k, (int)k, 1, (double*)st);
-            QIL_HIP(hipMemcpyAsync(hb, st, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
-            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            QIL_TRY((qil_klaunch<tri_stats_k<T>>(ctx, dim3(NB), dim3(256), 0, (const T*)R, k, (int)k, 1, (double*)st)));
+            QIL_HIP(hipMemcpyAsync(hb, st, sizeof(hb), hipMemcpyDeviceToHost, qil_stream(ctx)));
+            QIL_HIP(qil_stream_sync(ctx));
             qil_ctx_free(ctx, st);
             double fro2 = 0, dmin = 1e300;
             for (int bI = 0; bI < NB; ++bI) {
@@ -2899,19 +2991,18 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             // R^H = Q1 R1; the columns of X = R1^H are rotated (R = X Q1^H has the same left singular vectors)
             void* r1 = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * k) * sizeof(T), &r1));
-            hipLaunchKernelGGL(conj_transpose<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)R, k, k, k, X, k);
+            QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3(gk), dim3(256), 0, (const T*)R, k, k, k, X, k)));
             QIL_TRY(qr_impl<T>(ctx, k, k, X, k, static_cast<T*>(r1), k));
             QIL_TRY(qr_reorthogonalise<T>(ctx, k, k, X, k, static_cast<T*>(r1), k, dbg, nullptr));
-            hipLaunchKernelGGL(conj_transpose<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)r1, k, k, k, X, k);
+            QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3(gk), dim3(256), 0, (const T*)r1, k, k, k, X, k)));
             qil_ctx_free(ctx, r1);
         } else {
-            QIL_HIP(hipMemcpyAsync(X, R, (size_t)(k * k) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+            QIL_TRY(qil_dev_copy(ctx, X, R, (size_t)(k * k) * sizeof(T)));
         }
     } else {
         // B^H = Q R  =>  B = R^H Q^H: the left singular vectors of B are those of X = R^H
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(q * p) * sizeof(T), &bh));
-        hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((p * q + 255) / 256, 65536)), dim3(256), 0,
-                           ctx->stream, (const T*)B, ldb, p, q, static_cast<T*>(bh), q);
+        QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3((unsigned)std::min<long long>((p * q + 255) / 256, 65536)), dim3(256), 0, (const T*)B, ldb, p, q, static_cast<T*>(bh), q)));
         QIL_TRY(qr_impl<T>(ctx, q, p, static_cast<T*>(bh), q, R, k));
         bool ok = true;
         QIL_TRY(qr_reorthogonalise<T>(ctx, q, p, static_cast<T*>(bh), q, R, k, dbg, &ok));
@@ -2919,9 +3010,10 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             release();
             return QIL_OK;
         }
-        hipLaunchKernelGGL(conj_transpose<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)R, k, k, k, X, k);
+        QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3(gk), dim3(256), 0, (const T*)R, k, k, k, X, k)));
     }
     lap("QR");
+    qil_progress_phase(ctx, 3);
     if (cert_cutoff > 0.0) {
         // the caller truncates by cutoff only and does not read the singular values: if nothing can be dropped, the thin
         // QR is the gauge step (*handled = 2, S_host untouched)
@@ -2929,15 +3021,12 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         QIL_TRY(certify_no_truncation<T>(ctx, R, k, (int)k, cert_cutoff, &certified));
         if (certified) {
             if (tall) {                                  // B = Q R: Uiso = Q (in B), S V^H = R
-                QIL_HIP(hipMemcpy2DAsync(Uiso, (size_t)ldu * sizeof(T), Qm, (size_t)ldq * sizeof(T), (size_t)p * sizeof(T), (size_t)k,
-                                         hipMemcpyDeviceToDevice, ctx->stream));
-                QIL_HIP(hipMemcpy2DAsync(SVh, (size_t)ldsvh * sizeof(T), R, (size_t)k * sizeof(T), (size_t)k * sizeof(T), (size_t)q,
-                                         hipMemcpyDeviceToDevice, ctx->stream));
+                QIL_TRY(qil_dev_copy2d(ctx, Uiso, (size_t)ldu * sizeof(T), Qm, (size_t)ldq * sizeof(T), (size_t)p * sizeof(T), (size_t)k));
+                QIL_TRY(qil_dev_copy2d(ctx, SVh, (size_t)ldsvh * sizeof(T), R, (size_t)k * sizeof(T), (size_t)k * sizeof(T), (size_t)q));
             } else {                                     // p < q: the whole row space is kept: Uiso = I, S V^H = B
-                QIL_HIP(hipMemset2DAsync(Uiso, (size_t)ldu * sizeof(T), 0, (size_t)k * sizeof(T), (size_t)k, ctx->stream));
-                hipLaunchKernelGGL(set_identity<T>, dim3(gk), dim3(256), 0, ctx->stream, Uiso, ldu, (int)k);
-                QIL_HIP(hipMemcpy2DAsync(SVh, (size_t)ldsvh * sizeof(T), B, (size_t)ldb * sizeof(T), (size_t)p * sizeof(T), (size_t)q,
-                                         hipMemcpyDeviceToDevice, ctx->stream));
+                QIL_TRY(qil_dev_zero2d(ctx, Uiso, (size_t)ldu * sizeof(T), (size_t)k * sizeof(T), (size_t)k));
+                QIL_TRY((qil_klaunch<set_identity_k<T>>(ctx, dim3(gk), dim3(256), 0, Uiso, ldu, (int)k)));
+                QIL_TRY(qil_dev_copy2d(ctx, SVh, (size_t)ldsvh * sizeof(T), B, (size_t)ldb * sizeof(T), (size_t)p * sizeof(T), (size_t)q));
             }
             QIL_HIP(hipGetLastError());
             lap("certificate: QR gauge");
@@ -2947,13 +3036,13 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         }
         lap("certificate: declined");
     }
+    qil_progress_phase(ctx, 4);
     QIL_TRY(qil_ctx_alloc(ctx, 512, &flag));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * sizeof(double), &nrm));
     if (negl_rel > 0.0) {
         QIL_TRY(qil_ctx_alloc(ctx, 256, &negl));
-        hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)k), dim3(256), 0, ctx->stream, (const T*)X, k, k, (double*)nrm);
-        hipLaunchKernelGGL(negligible_threshold, dim3(1), dim3(256), 0, ctx->stream, (const double*)nrm, (int)k, negl_rel,
-                           (double*)negl);
+        QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)k), dim3(256), 0, (const T*)X, k, k, (double*)nrm)));
+        QIL_TRY((qil_klaunch<negligible_threshold_k>(ctx, dim3(1), dim3(256), 0, (const double*)nrm, (int)k, negl_rel, (double*)negl)));
     }
     const double tol = std::max(1e-15, 4.0 * 1.1e-16 * std::sqrt((double)k));
     const int nblk = (int)(((k + bb - 1) / bb + 1) / 2 * 2);
@@ -2991,7 +3080,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         QIL_TRY(qil_ctx_flag_host(ctx, (size_t)2 * MAXS * sizeof(int), &hostv));
         volatile int* hv = static_cast<volatile int*>(hostv);
         int* dflag = static_cast<int*>(flag);                    // [MAXS][2]
-        QIL_HIP(hipMemsetAsync(dflag, 0, (size_t)2 * MAXS * sizeof(int), ctx->stream));
+        QIL_TRY(qil_dev_zero(ctx, dflag, (size_t)2 * MAXS * sizeof(int)));
         hipEvent_t ev[2] = {nullptr, nullptr};
         QIL_TRY(qil_ctx_event(ctx, &ev[0]));
         QIL_TRY(qil_ctx_event(ctx, &ev[1]));
@@ -3003,8 +3092,8 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
                 else
                     QIL_TRY((launch_gram_round<T, 8>(ctx, X, k, (int)k, nblk, round, tol, dflag + 2 * sw, prev, (const double*)negl)));
             }
-            QIL_HIP(hipMemcpyAsync(const_cast<int*>(hv) + 2 * sw, dflag + 2 * sw, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            QIL_HIP(hipEventRecord(ev[sw & 1], ctx->stream));
+            QIL_HIP(hipMemcpyAsync(const_cast<int*>(hv) + 2 * sw, dflag + 2 * sw, 2 * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
+            QIL_HIP(hipEventRecord(ev[sw & 1], qil_stream(ctx)));
             return QIL_OK;
         };
         int st = enqueue(0);
@@ -3023,19 +3112,20 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         QIL_TRY(st);
     } else
     for (; sweeps < 40; ++sweeps) {
-        QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
+        QIL_TRY(qil_dev_zero(ctx, flag, 2 * sizeof(int)));
         QIL_TRY(launch_rounds());
         int hv[2] = {0, 0};
-        QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));
         if (dbg) fprintf(stderr, "[svd-left] sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[0], hv[1]);
         if (!hv[1]) break;
     }
     lap("sweeps");
-    hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)k), dim3(256), 0, ctx->stream, (const T*)X, k, k, (double*)nrm);
+    qil_progress_phase(ctx, 5);
+    QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)k), dim3(256), 0, (const T*)X, k, k, (double*)nrm)));
     std::vector<double> sig((size_t)k);
-    QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     std::vector<int> perm((size_t)k);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return sig[(size_t)a] > sig[(size_t)b]; });
@@ -3051,7 +3141,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     QIL_TRY(qil_ctx_desc_acquire(ctx, up, &hp, &dp, &slot));
     memcpy(hp, inv.data(), (size_t)k * sizeof(double));
     memcpy(static_cast<char*>(hp) + (size_t)k * sizeof(double), perm.data(), (size_t)k * sizeof(int));
-    QIL_HIP(hipMemcpyAsync(dp, hp, up, hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dp, hp, up, hipMemcpyHostToDevice, qil_stream(ctx)));
     const double* scd = static_cast<const double*>(dp);
     const int* permd = reinterpret_cast<const int*>(static_cast<const char*>(dp) + (size_t)k * sizeof(double));
     // W = normalised rotated columns in sorted order
@@ -3064,7 +3154,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         Wm = Uiso;
         ldw = ldu;
     }
-    hipLaunchKernelGGL(gather_cols<T>, dim3(gk), dim3(256), 0, ctx->stream, (const T*)X, k, k, permd, scd, Wm, ldw, (int)k, 0);
+    QIL_TRY((qil_klaunch<gather_cols_k<T>>(ctx, dim3(gk), dim3(256), 0, (const T*)X, k, k, permd, scd, Wm, ldw, (int)k, 0)));
     QIL_TRY(qil_ctx_desc_commit(ctx, slot));
     if (tall) {
         QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, qrows, k, k, Qm, ldq, Wm, ldw, Uiso, ldu));          // Uiso = Q W
@@ -3095,7 +3185,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!dbg) return;
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)qil_stream_sync(ctx);
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[svd] %lld x %lld: %s %.1f ms\n", m, n, what,
                 std::chrono::duration<double, std::milli>(now - t_prev).count());
@@ -3111,8 +3201,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         ldw = n;
         rows = n;
         cols = m;
-        hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)),
-                           dim3(256), 0, ctx->stream, A, lda, m, n, Wk, ldw);
+        QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)), dim3(256), 0, A, lda, m, n, Wk, ldw)));
     }
     // tall-skinny: Wk = Q R, rotate R instead.  Large column counts (block path): always, and rotate R^H --
     // the rows of a triangular factor are far closer to orthogonal than its columns, which saves sweeps
@@ -3155,8 +3244,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         }
         if (rt) {
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &rtbuf));
-            hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
-                               dim3(256), 0, ctx->stream, (const T*)Wk, ldw, cols, cols, static_cast<T*>(rtbuf), cols);
+            QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)), dim3(256), 0, (const T*)Wk, ldw, cols, cols, static_cast<T*>(rtbuf), cols)));
             Wk = static_cast<T*>(rtbuf);
         }
     }
@@ -3183,35 +3271,19 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     // L2 is slower than the tournament launches, which spread the pairs over the chip
     if (ncol <= 96 && rows * cols <= (1LL << 19) &&
         (lds_av <= 150 * 1024 || (a_in_lds && rows <= 128 && lds_a <= 150 * 1024) || fused_global)) {
-        static bool attr_set[3] = {false, false, false};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
         if (lds_av <= 150 * 1024) {
-            if (!attr_set[1]) {
-                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_fused<T, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-                attr_set[1] = true;
-            }
-            hipLaunchKernelGGL((jacobi_fused<T, 1>), dim3(1), dim3(1024), lds_av, ctx->stream, Wk, ldw, (int)rows, V, cols,
-                               ncol, tol, 40, (double*)nrm, negl_rel);
+            QIL_TRY((qil_klaunch<jacobi_fused_k<T, 1>>(ctx, dim3(1), dim3(1024), lds_av, Wk, ldw, (int)rows, V, cols, ncol, tol, 40, (double*)nrm, negl_rel)));
         } else if (a_in_lds && rows <= 128 && lds_a <= 150 * 1024) {   // one DPP row per pair only up to 128 rows
-            if (!attr_set[2]) {
-                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_fused<T, 2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-                attr_set[2] = true;
-            }
-            hipLaunchKernelGGL((jacobi_fused<T, 2>), dim3(1), dim3(1024), lds_a, ctx->stream, Wk, ldw, (int)rows, V, cols,
-                               ncol, tol, 40, (double*)nrm, negl_rel);
+            QIL_TRY((qil_klaunch<jacobi_fused_k<T, 2>>(ctx, dim3(1), dim3(1024), lds_a, Wk, ldw, (int)rows, V, cols, ncol, tol, 40, (double*)nrm, negl_rel)));
         } else {
-            hipLaunchKernelGGL((jacobi_fused<T, 0>), dim3(1), dim3(1024), 0, ctx->stream, Wk, ldw, (int)rows, V, cols, ncol,
-                               tol, 40, (double*)nrm, negl_rel);
+            QIL_TRY((qil_klaunch<jacobi_fused_k<T, 0>>(ctx, dim3(1), dim3(1024), 0, Wk, ldw, (int)rows, V, cols, ncol, tol, 40, (double*)nrm, negl_rel)));
         }
     } else {
         bool bj_done = false;
         if (negl_rel > 0.0) {
             QIL_TRY(qil_ctx_alloc(ctx, 256, &negl));
-            hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)cols), dim3(256), 0, ctx->stream, (const T*)Wk, ldw, rows,
-                               (double*)nrm);
-            hipLaunchKernelGGL(negligible_threshold, dim3(1), dim3(256), 0, ctx->stream, (const double*)nrm, (int)cols,
-                               negl_rel, (double*)negl);
+            QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)cols), dim3(256), 0, (const T*)Wk, ldw, rows, (double*)nrm)));
+            QIL_TRY((qil_klaunch<negligible_threshold_k>(ctx, dim3(1), dim3(256), 0, (const double*)nrm, (int)cols, negl_rel, (double*)negl)));
         }
         if (blocked) {
             // GEMM-shaped block sweeps; the scalar tournament below only runs if they hit their sweep limit
@@ -3225,8 +3297,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
             nj = cpad;
             lap("block sweeps");
         } else {
-            hipLaunchKernelGGL(set_identity<T>, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)),
-                               dim3(256), 0, ctx->stream, V, cols, (int)cols);
+            QIL_TRY((qil_klaunch<set_identity_k<T>>(ctx, dim3((unsigned)std::min<long long>((cols * cols + 255) / 256, 65536)), dim3(256), 0, V, cols, (int)cols)));
         }
         const int nn = (int)nj, npad = nn + (nn & 1);
         // in-LDS block rounds when 2 BB columns of A and V fit one CU's LDS (not after the GEMM-shaped block sweeps:
@@ -3240,49 +3311,29 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
             else if (8 * per_col <= 150 * 1024) bb = 4;
         }
         const int nblk = bb ? (int)(((cols + bb - 1) / bb + 1) / 2 * 2) : 0;
-        if (bb) {
-            static bool attr8 = false, attr4 = false;
-            if (bb == 8 && !attr8) {
-                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round<T, 8>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-                attr8 = true;
-            }
-            if (bb == 4 && !attr4) {
-                QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_block_round<T, 4>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-                attr4 = true;
-            }
-        }
         for (int sweep = 0; sweep < 40 && nn > 1 && !bj_done; ++sweep) {
-            QIL_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
+            QIL_TRY(qil_dev_zero(ctx, flag, 2 * sizeof(int)));
             if (bb) {
                 const size_t lds = (size_t)2 * bb * ((rows | 1) + (cols | 1)) * sizeof(T);
                 for (int round = 0; round < nblk - 1; ++round) {
                     if (bb == 8)
-                        hipLaunchKernelGGL((jacobi_block_round<T, 8>), dim3(nblk / 2), dim3(512), lds, ctx->stream, Wk, ldw,
-                                           (int)rows, V, ldv, (int)cols, nn, nblk, round, round == 0 ? 1 : 0, tol,
-                                           (int*)flag, (const double*)negl);
+                        QIL_TRY((qil_klaunch<jacobi_block_round_k<T, 8>>(ctx, dim3(nblk / 2), dim3(512), lds, Wk, ldw, (int)rows, V, ldv, (int)cols, nn, nblk, round, round == 0 ? 1 : 0, tol, (int*)flag, (const double*)negl)));
                     else
-                        hipLaunchKernelGGL((jacobi_block_round<T, 4>), dim3(nblk / 2), dim3(256), lds, ctx->stream, Wk, ldw,
-                                           (int)rows, V, ldv, (int)cols, nn, nblk, round, round == 0 ? 1 : 0, tol,
-                                           (int*)flag, (const double*)negl);
+                        QIL_TRY((qil_klaunch<jacobi_block_round_k<T, 4>>(ctx, dim3(nblk / 2), dim3(256), lds, Wk, ldw, (int)rows, V, ldv, (int)cols, nn, nblk, round, round == 0 ? 1 : 0, tol, (int*)flag, (const double*)negl)));
                 }
             }
             for (int round = 0; round < npad - 1 && !bb; ++round)
-                hipLaunchKernelGGL(jacobi_round<T>, dim3(npad / 2), dim3(256), 0, ctx->stream, Wk, ldw, rows, V,
-                                   ldv, (int)cols, nn, npad, round, tol, (int*)flag, (const double*)negl);
+                QIL_TRY((qil_klaunch<jacobi_round_k<T>>(ctx, dim3(npad / 2), dim3(256), 0, Wk, ldw, rows, V, ldv, (int)cols, nn, npad, round, tol, (int*)flag, (const double*)negl)));
             int hv[2] = {0, 0};
-            QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
+            QIL_HIP(qil_stream_sync(ctx));
             if (getenv("QIL_SVD_DEBUG")) fprintf(stderr, "[svd] scalar sweep %d (cols %lld): rotated=%d above-quadratic=%d\n", sweep, nj, hv[0], hv[1]);
             static const bool early = true;
             if (!(early ? hv[1] : hv[0])) break;   // nothing rotated, or only pairs already below the quadratic-phase level
         }
-        hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)nj), dim3(256), 0, ctx->stream, Wk, ldw, rows,
-                           (double*)nrm);
+        QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)nj), dim3(256), 0, Wk, ldw, rows, (double*)nrm)));
         if (blocked)   // padding columns are zero in the V part too; genuine columns have unit V columns
-            hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)nj), dim3(256), 0, ctx->stream, (const T*)V, ldv, cols,
-                               (double*)nrm + nj);
+            QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)nj), dim3(256), 0, (const T*)V, ldv, cols, (double*)nrm + nj)));
     }
     lap("scalar sweeps");
     std::vector<double> sig((size_t)nj * 2, 1.0);
@@ -3292,12 +3343,12 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
             void *hp = nullptr, *dp = nullptr;
             int slot = -1;
             QIL_TRY(qil_ctx_desc_acquire(ctx, down, &hp, &dp, &slot));
-            QIL_HIP(hipMemcpyAsync(hp, nrm, down, hipMemcpyDeviceToHost, ctx->stream));
-            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            QIL_HIP(hipMemcpyAsync(hp, nrm, down, hipMemcpyDeviceToHost, qil_stream(ctx)));
+            QIL_HIP(qil_stream_sync(ctx));
             memcpy(sig.data(), hp, down);
         } else {
-            QIL_HIP(hipMemcpyAsync(sig.data(), nrm, down, hipMemcpyDeviceToHost, ctx->stream));
-            QIL_HIP(hipStreamSynchronize(ctx->stream));
+            QIL_HIP(hipMemcpyAsync(sig.data(), nrm, down, hipMemcpyDeviceToHost, qil_stream(ctx)));
+            QIL_HIP(qil_stream_sync(ctx));
         }
     }
     std::vector<int> perm((size_t)nj);
@@ -3324,14 +3375,14 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         QIL_TRY(qil_ctx_desc_acquire(ctx, up_bytes, &hp, &dp, &ring_slot));
         memcpy(hp, inv.data(), (size_t)cols * sizeof(double));
         memcpy(static_cast<char*>(hp) + (size_t)cols * sizeof(double), perm.data(), (size_t)cols * sizeof(int));
-        QIL_HIP(hipMemcpyAsync(dp, hp, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+        QIL_HIP(hipMemcpyAsync(dp, hp, up_bytes, hipMemcpyHostToDevice, qil_stream(ctx)));
         qil_ctx_free(ctx, scd);
         qil_ctx_free(ctx, permd);
         scd = dp;
         permd = static_cast<char*>(dp) + (size_t)cols * sizeof(double);
     } else {
-        QIL_HIP(hipMemcpyAsync(permd, perm.data(), (size_t)cols * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        QIL_HIP(hipMemcpyAsync(scd, inv.data(), (size_t)cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        QIL_HIP(hipMemcpyAsync(permd, perm.data(), (size_t)cols * sizeof(int), hipMemcpyHostToDevice, qil_stream(ctx)));
+        QIL_HIP(hipMemcpyAsync(scd, inv.data(), (size_t)cols * sizeof(double), hipMemcpyHostToDevice, qil_stream(ctx)));
     }
     // Work problem: Wk[:, perm] = Fw diag(S), Fw orthonormal columns, and Fv = V[:, perm]:  Wk = Fw S Fv^H.
     //   plain:        oriented A = Wk            = (Fw)   S (Fv)^H
@@ -3345,30 +3396,29 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     };
     const small_factor fw{Wk, ldw, rows, (const double*)scd}, fv{V, ldv, cols, nullptr};
     const small_factor ls = rt ? fv : fw, rs = rt ? fw : fv;      // small left / right factors
-    auto gather = [&](const small_factor& f, T* dst, long long ldd, int conjT) {
+    auto gather = [&](const small_factor& f, T* dst, long long ldd, int conjT) -> int {
         const unsigned g = (unsigned)std::min<long long>((f.nrows * cols + 255) / 256, 65536);
-        hipLaunchKernelGGL(gather_cols<T>, dim3(g), dim3(256), 0, ctx->stream, f.p, f.ld, f.nrows, (const int*)permd,
-                           f.scale, dst, ldd, (int)cols, conjT);
+        return qil_klaunch<gather_cols_k<T>>(ctx, dim3(g), dim3(256), 0, f.p, f.ld, f.nrows, (const int*)permd, f.scale, dst, ldd, (int)cols, conjT);
     };
     void* lbuf = nullptr;
     const long long lrows = Q ? qrows : rows;
     if (Q) {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(cols * cols) * sizeof(T), &lbuf));
-        gather(ls, static_cast<T*>(lbuf), cols, 0);
+        QIL_TRY(gather(ls, static_cast<T*>(lbuf), cols, 0));
     }
     if (!flip) {
         if (Q)
             QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, lrows, cols, cols, Q, ldq, static_cast<T*>(lbuf), cols, U, ldu));
         else
-            gather(ls, U, ldu, 0);
-        gather(rs, Vh, ldvh, 1);
+            QIL_TRY(gather(ls, U, ldu, 0));
+        QIL_TRY(gather(rs, Vh, ldvh, 1));
     } else {
-        gather(rs, U, ldu, 0);
+        QIL_TRY(gather(rs, U, ldu, 0));
         if (Q)   // Vh (cols x lrows) = (Q * small)^H = small^H * Q^H
             QIL_TRY(gemm_dispatch<T>(ctx, sizeof(T) == 16 ? 2 : 1, sizeof(T) == 16 ? 2 : 1, cols, lrows, cols,
                                      static_cast<T*>(lbuf), cols, Q, ldq, Vh, ldvh));
         else
-            gather(ls, Vh, ldvh, 1);
+            QIL_TRY(gather(ls, Vh, ldvh, 1));
     }
     QIL_HIP(hipGetLastError());
     if (ring_slot >= 0) {
@@ -3376,7 +3426,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
         scd = permd = nullptr;                                   // ring memory, not pool blocks
     } else {
         // perm/inv are host vectors read by async copies: finish before they go out of scope
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_HIP(qil_stream_sync(ctx));
     }
     lap("factors out");
     if (tbuf) qil_ctx_free(ctx, tbuf);
@@ -3397,16 +3447,24 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
 // ------------------------------------------------------------------ Gram-Schmidt QR (CGS2), positive diagonal
 // R[0:k, j0:j0+b] += C (k x b)
 template <class T>
-__global__ void add_block(T* __restrict__ R, long long ldr, const T* __restrict__ C, long long ldc, int k,
+__device__ __forceinline__ void add_block_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ R, long long ldr, const T* __restrict__ C, long long ldc, int k,
                           int b) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < k * b; t += gridDim.x * blockDim.x) {
         const int i = t % k, j = t / k;
         R[i + ldr * j] = add_t(R[i + ldr * j], C[i + ldc * j]);
     }
 }
+template <class T>
+struct add_block_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        add_block_body<T>(b, g, a...);
+    }
+};
 // Column norms of a tall matrix: partial sums of squares per (chunk, column), then one small reduction.
 template <class T>
-__global__ __launch_bounds__(256) void col_sumsq_chunks(const T* __restrict__ A, long long lda, long long m,
+__device__ __forceinline__ void col_sumsq_chunks_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ A, long long lda, long long m,
                                                         long long chunk_rows, double* __restrict__ part) {
     __shared__ double red[4];
     const long long r0 = blockIdx.y * chunk_rows, r1 = min(m, r0 + chunk_rows);
@@ -3416,7 +3474,15 @@ __global__ __launch_bounds__(256) void col_sumsq_chunks(const T* __restrict__ A,
     block_sum<1>(v, red);
     if (threadIdx.x == 0) part[blockIdx.y + (long long)gridDim.y * blockIdx.x] = v[0];
 }
-__global__ __launch_bounds__(256) void sqrt_sum_chunks(const double* __restrict__ part, int nch,
+template <class T>
+struct col_sumsq_chunks_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        col_sumsq_chunks_body<T>(b, g, a...);
+    }
+};
+__device__ __forceinline__ void sqrt_sum_chunks_body(const uint3 blockIdx, const uint3 gridDim, const double* __restrict__ part, int nch,
                                                        double* __restrict__ out) {
     __shared__ double red[4];
     double v[1] = {0};
@@ -3424,10 +3490,17 @@ __global__ __launch_bounds__(256) void sqrt_sum_chunks(const double* __restrict_
     block_sum<1>(v, red);
     if (threadIdx.x == 0) out[blockIdx.x] = sqrt(v[0]);
 }
+struct sqrt_sum_chunks_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        sqrt_sum_chunks_body(b, g, a...);
+    }
+};
 template <class T>
 int col_norms_any(qil_context* ctx, const T* A, long long lda, long long m, long long n, double* out) {
     if (m < (1LL << 16)) {
-        hipLaunchKernelGGL(col_norms<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, A, lda, m, out);
+        QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)n), dim3(256), 0, A, lda, m, out)));
         QIL_HIP(hipGetLastError());
         return QIL_OK;
     }
@@ -3435,9 +3508,8 @@ int col_norms_any(qil_context* ctx, const T* A, long long lda, long long m, long
     const int nch = (int)((m + chunk - 1) / chunk);
     void* part = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nch * n) * sizeof(double), &part));
-    hipLaunchKernelGGL(col_sumsq_chunks<T>, dim3((unsigned)n, (unsigned)nch), dim3(256), 0, ctx->stream, A, lda, m,
-                       chunk, (double*)part);
-    hipLaunchKernelGGL(sqrt_sum_chunks, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const double*)part, nch, out);
+    QIL_TRY((qil_klaunch<col_sumsq_chunks_k<T>>(ctx, dim3((unsigned)n, (unsigned)nch), dim3(256), 0, A, lda, m, chunk, (double*)part)));
+    QIL_TRY((qil_klaunch<sqrt_sum_chunks_k>(ctx, dim3((unsigned)n), dim3(256), 0, (const double*)part, nch, out)));
     QIL_HIP(hipGetLastError());
     qil_ctx_free(ctx, part);
     return QIL_OK;
@@ -3446,7 +3518,7 @@ int col_norms_any(qil_context* ctx, const T* A, long long lda, long long m, long
 // P[rows of chunk c, :] <- P[rows of chunk c, :] * Q2[c*b : (c+1)*b, :]   (second half of the tree: the
 // chunk-local orthonormal factors times the factor of the stacked triangles)
 template <class T, int B>
-__global__ __launch_bounds__(256) void tsqr_apply_q2(T* __restrict__ P, long long lda, long long m, int b,
+__device__ __forceinline__ void tsqr_apply_q2_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ P, long long lda, long long m, int b,
                                                      const T* __restrict__ Q2, long long ldq,
                                                      long long chunk_rows) {
     __shared__ T q2[B * B];
@@ -3473,6 +3545,14 @@ __global__ __launch_bounds__(256) void tsqr_apply_q2(T* __restrict__ P, long lon
             if (j < b) P[r + lda * j] = out[j];
     }
 }
+template <class T, int B>
+struct tsqr_apply_q2_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        tsqr_apply_q2_body<T, B>(b, g, a...);
+    }
+};
 
 // Tall-skinny QR of an m x b panel (b <= 16): a two-level tree.  ~512 workgroups orthonormalise their own
 // row chunks (CGS2, same dependence rule, measured against the GLOBAL column norms so a chunk never
@@ -3491,12 +3571,11 @@ int tsqr_panel(qil_context* ctx, long long m, int b, T* P, long long lda, T* R, 
     T* Rs = static_cast<T*>(rs);
     QIL_TRY(gs_fused_launch<T>(ctx, (unsigned)nch, P, lda, m, b, Rs, nch * b, ref_norm, chunk));
     QIL_TRY(gs_fused_launch<T>(ctx, 1u, Rs, nch * b, nch * b, b, static_cast<T*>(r2), (long long)b, ref_norm, 0LL));
-    hipLaunchKernelGGL((tsqr_apply_q2<T, 16>), dim3((unsigned)std::min<long long>((chunk + 255) / 256, 64), (unsigned)nch),
-                       dim3(256), 0, ctx->stream, P, lda, m, b, (const T*)Rs, nch * b, chunk);
+    QIL_TRY((qil_klaunch<tsqr_apply_q2_k<T, 16>>(ctx, dim3((unsigned)std::min<long long>((chunk + 255) / 256, 64), (unsigned)nch), dim3(256), 0, P, lda, m, b, (const T*)Rs, nch * b, chunk)));
     QIL_HIP(hipGetLastError());
     if (R)
-        QIL_HIP(hipMemcpy2DAsync(R, (size_t)ldr * sizeof(T), r2, (size_t)b * sizeof(T), (size_t)b * sizeof(T),
-                                 (size_t)b, hipMemcpyDeviceToDevice, ctx->stream));
+        QIL_TRY(qil_dev_copy2d(ctx, R, (size_t)ldr * sizeof(T), r2, (size_t)b * sizeof(T), (size_t)b * sizeof(T),
+                                 (size_t)b));
     qil_ctx_free(ctx, rs);
     qil_ctx_free(ctx, r2);
     return QIL_OK;
@@ -3555,7 +3634,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     static const int pb_max = 32;
     const bool wide = pb_max >= 32 && !tree && ((size_t)64 + (size_t)(m | 1) * 32) * sizeof(T) <= 150 * 1024;
     const int PB = wide ? 32 : 16;
-    if (R) QIL_HIP(hipMemsetAsync(R, 0, (size_t)(ldr * n) * sizeof(T), ctx->stream));
+    if (R) QIL_TRY(qil_dev_zero(ctx, R, (size_t)(ldr * n) * sizeof(T)));
     void *cbuf = nullptr, *nbuf = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &nbuf));
     // original column norms, measured before any projection (reference for the dependence test)
@@ -3572,8 +3651,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
             proj.subtract = 1;
             QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, b, j0, A, lda, C, n, P, lda, proj));  // P -= Q C
             if (R)
-                hipLaunchKernelGGL(add_block<T>, dim3(8), dim3(256), 0, ctx->stream, R + ldr * j0, ldr, (const T*)C,
-                                   n, (int)j0, b);
+                QIL_TRY((qil_klaunch<add_block_k<T>>(ctx, dim3(8), dim3(256), 0, R + ldr * j0, ldr, (const T*)C, n, (int)j0, b)));
         }
         // intra-panel CGS2 (one launch); its b x b triangular factor goes straight to R[j0:, j0:]
         T* Rjj = R ? R + j0 + ldr * j0 : (T*)nullptr;
@@ -3590,9 +3668,75 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     return QIL_OK;
 }
 
+// ------------------------------------------------------------------ device copies / fills as (combinable) kernels
+// hipMemcpyAsync / hipMemsetAsync inside a truncation chain are separate commands of the stream: in a lock-step batch they
+// would be issued once per chain (3-4 us each, one after another).  As kernels they ride the combined launches.
+__device__ __forceinline__ void copy2d_body(const uint3 blockIdx, const uint3 gridDim, double* __restrict__ dst, long long dpitch,
+                                            const double* __restrict__ src, long long spitch, long long w, long long h) {
+    // pitches and width in 8-byte words
+    const long long total = w * h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long r = t % w, c = t / w;
+        dst[r + dpitch * c] = src[r + spitch * c];
+    }
+}
+struct copy2d_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        copy2d_body(b, g, a...);
+    }
+};
+__device__ __forceinline__ void zero2d_body(const uint3 blockIdx, const uint3 gridDim, unsigned* __restrict__ dst, long long pitch,
+                                            long long w, long long h) {
+    // pitch and width in 4-byte words
+    const long long total = w * h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x)
+        dst[(t % w) + pitch * (t / w)] = 0u;
+}
+struct zero2d_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        zero2d_body(b, g, a...);
+    }
+};
+
+}  // namespace
+
+int qil_dev_copy2d(qil_context* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    if (width == 0 || height == 0) return QIL_OK;
+    const bool words = ((dpitch | spitch | width | (size_t)(uintptr_t)dst | (size_t)(uintptr_t)src) & 7) == 0;
+    if (!words || width * height > ((size_t)64 << 20)) {         // odd shapes / bulk data: the copy engine path
+        QIL_TRY(qil_dev_copy2d(ctx, dst, dpitch, src, spitch, width, height));
+        return QIL_OK;
+    }
+    const long long total = (long long)(width / 8) * (long long)height;
+    return qil_klaunch<copy2d_k>(ctx, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0,
+                                 static_cast<double*>(dst), (long long)(dpitch / 8), static_cast<const double*>(src),
+                                 (long long)(spitch / 8), (long long)(width / 8), (long long)height);
+}
+int qil_dev_copy(qil_context* ctx, void* dst, const void* src, size_t bytes) {
+    return qil_dev_copy2d(ctx, dst, bytes, src, bytes, bytes, 1);
+}
+int qil_dev_zero2d(qil_context* ctx, void* dst, size_t pitch, size_t width, size_t height) {
+    if (width == 0 || height == 0) return QIL_OK;
+    const bool words = ((pitch | width | (size_t)(uintptr_t)dst) & 3) == 0;
+    if (!words || width * height > ((size_t)64 << 20)) {
+        QIL_TRY(qil_dev_zero2d(ctx, dst, pitch, width, height));
+        return QIL_OK;
+    }
+    const long long total = (long long)(width / 4) * (long long)height;
+    return qil_klaunch<zero2d_k>(ctx, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0,
+                                 static_cast<unsigned*>(dst), (long long)(pitch / 4), (long long)(width / 4), (long long)height);
+}
+int qil_dev_zero(qil_context* ctx, void* dst, size_t bytes) { return qil_dev_zero2d(ctx, dst, bytes, bytes, 1); }
+
+namespace {
+
 // ------------------------------------------------------------------ misc kernels
 template <class T>
-__global__ void scale_kernel(T* __restrict__ A, long long lda, long long m, long long n,
+__device__ __forceinline__ void scale_kernel_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ A, long long lda, long long m, long long n,
                              const double* __restrict__ s, int side) {
     const long long total = m * n;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
@@ -3601,6 +3745,14 @@ __global__ void scale_kernel(T* __restrict__ A, long long lda, long long m, long
         A[i + lda * j] = scale_t(A[i + lda * j], side ? s[j] : s[i]);
     }
 }
+template <class T>
+struct scale_kernel_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        scale_kernel_body<T>(b, g, a...);
+    }
+};
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -3648,13 +3800,13 @@ extern "C" int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(lda * a_cols) * e, &dA));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(ldb * b_cols) * e, &dB));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(ldc * n) * e, &dC));
-    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(lda * a_cols) * e, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipMemcpyAsync(dB, B, (size_t)(ldb * b_cols) * e, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipMemsetAsync(dC, 0, (size_t)(ldc * n) * e, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(lda * a_cols) * e, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_HIP(hipMemcpyAsync(dB, B, (size_t)(ldb * b_cols) * e, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_TRY(qil_dev_zero(ctx, dC, (size_t)(ldc * n) * e));
+    QIL_HIP(qil_stream_sync(ctx));
     QIL_TRY(qil_dev_gemm(ctx, dtype, opA, opB, m, n, k, dA, lda, dB, ldb, dC, ldc));
-    QIL_HIP(hipMemcpyAsync(C, dC, (size_t)(ldc * n) * e, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(C, dC, (size_t)(ldc * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, dA);
     qil_ctx_free(ctx, dB);
     qil_ctx_free(ctx, dC);
@@ -3671,12 +3823,12 @@ extern "C" int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n
     void *dA = nullptr, *dR = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * e, &dR));
-    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     QIL_TRY(qil_dev_qr_positive(ctx, dtype, m, n, dA, m, dR, n, true));
-    QIL_HIP(hipMemcpyAsync(Q, dA, (size_t)(m * n) * e, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipMemcpyAsync(R, dR, (size_t)(n * n) * e, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(Q, dA, (size_t)(m * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(hipMemcpyAsync(R, dR, (size_t)(n * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, dA);
     qil_ctx_free(ctx, dR);
     return QIL_OK;
@@ -3701,9 +3853,9 @@ extern "C" int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int op
     hipEvent_t e0, e1;
     QIL_HIP(hipEventCreate(&e0));
     QIL_HIP(hipEventCreate(&e1));
-    QIL_HIP(hipEventRecord(e0, ctx->stream));
+    QIL_HIP(hipEventRecord(e0, qil_stream(ctx)));
     for (int r = 0; r < reps; ++r) QIL_TRY(qil_dev_gemm(ctx, dtype, opA, opB, m, n, k, dA, a_rows, dB, b_rows, dC, m));
-    QIL_HIP(hipEventRecord(e1, ctx->stream));
+    QIL_HIP(hipEventRecord(e1, qil_stream(ctx)));
     QIL_HIP(hipEventSynchronize(e1));
     float f = 0;
     QIL_HIP(hipEventElapsedTime(&f, e0, e1));
@@ -3742,14 +3894,11 @@ int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t 
     const unsigned g = (unsigned)std::min<long long>((m * n + 255) / 256, 65536);
     if (dtype == QIL_C64) {
         if (conj)
-            hipLaunchKernelGGL((conj_transpose<c64, true>), dim3(g), dim3(256), 0, ctx->stream, (const c64*)A, lda,
-                               m, n, (c64*)At, ldt);
+            QIL_TRY((qil_klaunch<conj_transpose_k<c64, true>>(ctx, dim3(g), dim3(256), 0, (const c64*)A, lda, m, n, (c64*)At, ldt)));
         else
-            hipLaunchKernelGGL((conj_transpose<c64, false>), dim3(g), dim3(256), 0, ctx->stream, (const c64*)A, lda,
-                               m, n, (c64*)At, ldt);
+            QIL_TRY((qil_klaunch<conj_transpose_k<c64, false>>(ctx, dim3(g), dim3(256), 0, (const c64*)A, lda, m, n, (c64*)At, ldt)));
     } else {
-        hipLaunchKernelGGL((conj_transpose<double, false>), dim3(g), dim3(256), 0, ctx->stream, (const double*)A,
-                           lda, m, n, (double*)At, ldt);
+        QIL_TRY((qil_klaunch<conj_transpose_k<double, false>>(ctx, dim3(g), dim3(256), 0, (const double*)A, lda, m, n, (double*)At, ldt)));
     }
     QIL_HIP(hipGetLastError());
     return QIL_OK;
@@ -3781,11 +3930,9 @@ static int qr_certified_t(qil_context* ctx, long long m, long long n, const T* A
                           bool* certified) {
     const long long rows = std::max(m, n), k = std::min(m, n);
     if (m >= n)
-        QIL_HIP(hipMemcpy2DAsync(Qout, (size_t)rows * sizeof(T), A, (size_t)lda * sizeof(T), (size_t)m * sizeof(T), (size_t)n,
-                                 hipMemcpyDeviceToDevice, ctx->stream));
+        QIL_TRY(qil_dev_copy2d(ctx, Qout, (size_t)rows * sizeof(T), A, (size_t)lda * sizeof(T), (size_t)m * sizeof(T), (size_t)n));
     else
-        hipLaunchKernelGGL(conj_transpose<T>, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)), dim3(256), 0,
-                           ctx->stream, A, lda, m, n, Qout, rows);
+        QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)), dim3(256), 0, A, lda, m, n, Qout, rows)));
     QIL_TRY(qr_impl<T>(ctx, rows, k, Qout, rows, Rout, k));
     bool ok = true;
     QIL_TRY(qr_reorthogonalise<T>(ctx, rows, k, Qout, rows, Rout, k, false, &ok));
@@ -3795,8 +3942,8 @@ static int qr_certified_t(qil_context* ctx, long long m, long long n, const T* A
 }
 int qil_dev_set_identity(qil_context* ctx, int dtype, void* V, int64_t ldv, int64_t n) {
     const unsigned g = (unsigned)std::min<long long>((n * n + 255) / 256, 65536);
-    if (dtype == QIL_C64) hipLaunchKernelGGL(set_identity<c64>, dim3(g), dim3(256), 0, ctx->stream, static_cast<c64*>(V), ldv, (int)n);
-    else hipLaunchKernelGGL(set_identity<double>, dim3(g), dim3(256), 0, ctx->stream, static_cast<double*>(V), ldv, (int)n);
+    if (dtype == QIL_C64) QIL_TRY((qil_klaunch<set_identity_k<c64>>(ctx, dim3(g), dim3(256), 0, static_cast<c64*>(V), ldv, (int)n)));
+    else QIL_TRY((qil_klaunch<set_identity_k<double>>(ctx, dim3(g), dim3(256), 0, static_cast<double*>(V), ldv, (int)n)));
     QIL_HIP(hipGetLastError());
     return QIL_OK;
 }
@@ -3856,19 +4003,17 @@ int qil_dev_scale(qil_context* ctx, int dtype, int side, int64_t m, int64_t n, v
         void* hp = nullptr;
         QIL_TRY(qil_ctx_desc_acquire(ctx, (size_t)len * sizeof(double), &hp, &sd, &ring_slot));
         memcpy(hp, s_host, (size_t)len * sizeof(double));
-        QIL_HIP(hipMemcpyAsync(sd, hp, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        QIL_HIP(hipMemcpyAsync(sd, hp, (size_t)len * sizeof(double), hipMemcpyHostToDevice, qil_stream(ctx)));
     } else {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)len * sizeof(double), &sd));
-        QIL_HIP(hipMemcpyAsync(sd, s_host, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        QIL_HIP(hipStreamSynchronize(ctx->stream));  // s_host is caller memory
+        QIL_HIP(hipMemcpyAsync(sd, s_host, (size_t)len * sizeof(double), hipMemcpyHostToDevice, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));  // s_host is caller memory
     }
     const unsigned g = (unsigned)std::min<long long>((m * n + 255) / 256, 65536);
     if (dtype == QIL_C64)
-        hipLaunchKernelGGL(scale_kernel<c64>, dim3(g), dim3(256), 0, ctx->stream, (c64*)A, lda, m, n,
-                           (const double*)sd, side);
+        QIL_TRY((qil_klaunch<scale_kernel_k<c64>>(ctx, dim3(g), dim3(256), 0, (c64*)A, lda, m, n, (const double*)sd, side)));
     else
-        hipLaunchKernelGGL(scale_kernel<double>, dim3(g), dim3(256), 0, ctx->stream, (double*)A, lda, m, n,
-                           (const double*)sd, side);
+        QIL_TRY((qil_klaunch<scale_kernel_k<double>>(ctx, dim3(g), dim3(256), 0, (double*)A, lda, m, n, (const double*)sd, side)));
     QIL_HIP(hipGetLastError());
     if (ring_slot >= 0) return qil_ctx_desc_commit(ctx, ring_slot);
     qil_ctx_free(ctx, sd);
@@ -3881,7 +4026,7 @@ int qil_dev_fill_normal(qil_context* ctx, int dtype, void* p, int64_t n_elems, u
     // complex entries: re, im i.i.d. N(0, 1/2) * scale so that E|z|^2 = scale^2
     const double sc = dtype == QIL_C64 ? scale * M_SQRT1_2 : scale;
     hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)std::min<long long>((nd + 255) / 256, 65536)), dim3(256),
-                       0, ctx->stream, (double*)p, nd, seed, sc);
+                       0, qil_stream(ctx), (double*)p, nd, seed, sc);
     QIL_HIP(hipGetLastError());
     return QIL_OK;
 }

@@ -290,8 +290,8 @@ int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64
     for (int64_t q0 = 0; q0 < nb && st == QIL_OK; q0 += chunk) {
         const int64_t nq = std::min<int64_t>(chunk, nb - q0);
         const unsigned g1 = (unsigned)std::min<long long>((nq + 255) / 256, 4096);
-        if (dt == QIL_C64) hipLaunchKernelGGL(fill_ones<c64>, dim3(g1), dim3(256), 0, ctx->stream, (c64*)M0, (long long)nq);
-        else hipLaunchKernelGGL(fill_ones<double>, dim3(g1), dim3(256), 0, ctx->stream, (double*)M0, (long long)nq);
+        if (dt == QIL_C64) hipLaunchKernelGGL(fill_ones<c64>, dim3(g1), dim3(256), 0, qil_stream(ctx), (c64*)M0, (long long)nq);
+        else hipLaunchKernelGGL(fill_ones<double>, dim3(g1), dim3(256), 0, qil_stream(ctx), (double*)M0, (long long)nq);
         void *Mc = M0, *Mn = M1;
         for (int64_t i = 0; i < n && st == QIL_OK; ++i) {
             const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
@@ -301,18 +301,18 @@ int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64
                 const unsigned g = (unsigned)std::min<long long>((Dl * 4 * Dr + 255) / 256, 4096);
                 const void* Ws = W->site[(size_t)i];
                 if (dt == QIL_F64)
-                    hipLaunchKernelGGL((mpo_site_bit_major<double, double>), dim3(g), dim3(256), 0, ctx->stream,
+                    hipLaunchKernelGGL((mpo_site_bit_major<double, double>), dim3(g), dim3(256), 0, qil_stream(ctx),
                                        (const double*)Ws, (double*)Wc, (int)Dl, (int)Dr);
                 else if (wc)
-                    hipLaunchKernelGGL((mpo_site_bit_major<c64, c64>), dim3(g), dim3(256), 0, ctx->stream, (const c64*)Ws,
+                    hipLaunchKernelGGL((mpo_site_bit_major<c64, c64>), dim3(g), dim3(256), 0, qil_stream(ctx), (const c64*)Ws,
                                        (c64*)Wc, (int)Dl, (int)Dr);
                 else
-                    hipLaunchKernelGGL((mpo_site_bit_major<double, c64>), dim3(g), dim3(256), 0, ctx->stream,
+                    hipLaunchKernelGGL((mpo_site_bit_major<double, c64>), dim3(g), dim3(256), 0, qil_stream(ctx),
                                        (const double*)Ws, (c64*)Wc, (int)Dl, (int)Dr);
             }
             if (Ac) {
                 hipLaunchKernelGGL(widen_to_c64<double>, dim3((unsigned)std::min<long long>((cl * 2 * cr + 255) / 256, 4096)),
-                                   dim3(256), 0, ctx->stream, (const double*)Ap, (c64*)Ac, cl * 2 * cr);
+                                   dim3(256), 0, qil_stream(ctx), (const double*)Ap, (c64*)Ac, cl * 2 * cr);
                 Ap = Ac;
             }
             qil_gemm_batch b1, b2;
@@ -332,10 +332,10 @@ int lazy_gemm_path(qil_context* ctx, const qil_mpo* W, const qil_mps* psi, int64
         }
         if (st != QIL_OK) break;
         if (dt == QIL_C64)
-            hipLaunchKernelGGL(lazy_finish<c64>, dim3(g1), dim3(256), 0, ctx->stream, (const c64*)Mc, (long long)nq,
+            hipLaunchKernelGGL(lazy_finish<c64>, dim3(g1), dim3(256), 0, qil_stream(ctx), (const c64*)Mc, (long long)nq,
                                psi->amplitude, dout + q0);
         else
-            hipLaunchKernelGGL(lazy_finish<double>, dim3(g1), dim3(256), 0, ctx->stream, (const double*)Mc, (long long)nq,
+            hipLaunchKernelGGL(lazy_finish<double>, dim3(g1), dim3(256), 0, qil_stream(ctx), (const double*)Mc, (long long)nq,
                                psi->amplitude, dout + q0);
         if (hipGetLastError() != hipSuccess) st = qil_fail(QIL_EHIP, "lazy coefficient (GEMM form): launch failed");
     }
@@ -353,8 +353,8 @@ int upload_bits(qil_context* ctx, int64_t nb, int64_t n, const uint8_t* bits, ui
                     max_bit);
     void* p = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nb * n), &p));
-    hipError_t e = hipMemcpyAsync(p, bits, (size_t)(nb * n), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `bits` is caller memory
+    hipError_t e = hipMemcpyAsync(p, bits, (size_t)(nb * n), hipMemcpyHostToDevice, qil_stream(ctx));
+    if (e == hipSuccess) e = qil_stream_sync(ctx);  // `bits` is caller memory
     if (e != hipSuccess) {
         qil_ctx_free(ctx, p);
         return qil_fail(QIL_EHIP, "bit upload failed: %s", hipGetErrorString(e));
@@ -407,23 +407,23 @@ static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* db
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * nb * maxchi) * esz, &Tm));
         const bool cx = psi->dtype == QIL_C64;
         const unsigned g1 = (unsigned)std::min<long long>((nb + 255) / 256, 4096);
-        if (cx) hipLaunchKernelGGL(fill_ones<c64>, dim3(g1), dim3(256), 0, ctx->stream, (c64*)V, (long long)nb);
-        else hipLaunchKernelGGL(fill_ones<double>, dim3(g1), dim3(256), 0, ctx->stream, (double*)V, (long long)nb);
+        if (cx) hipLaunchKernelGGL(fill_ones<c64>, dim3(g1), dim3(256), 0, qil_stream(ctx), (c64*)V, (long long)nb);
+        else hipLaunchKernelGGL(fill_ones<double>, dim3(g1), dim3(256), 0, qil_stream(ctx), (double*)V, (long long)nb);
         for (int64_t i = 0; i < n; ++i) {
             const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
             QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 0, 0, nb, 2 * cr, cl, V, nb, psi->site[(size_t)i], cl, Tm, nb));
             const unsigned g = (unsigned)std::min<long long>((nb * cr + 255) / 256, 65536);
             if (cx)
-                hipLaunchKernelGGL(select_slice<c64>, dim3(g), dim3(256), 0, ctx->stream, (const c64*)Tm,
+                hipLaunchKernelGGL(select_slice<c64>, dim3(g), dim3(256), 0, qil_stream(ctx), (const c64*)Tm,
                                    (long long)nb, (int)cr, dbits, (int)n, (int)i, (c64*)Vn);
             else
-                hipLaunchKernelGGL(select_slice<double>, dim3(g), dim3(256), 0, ctx->stream, (const double*)Tm,
+                hipLaunchKernelGGL(select_slice<double>, dim3(g), dim3(256), 0, qil_stream(ctx), (const double*)Tm,
                                    (long long)nb, (int)cr, dbits, (int)n, (int)i, (double*)Vn);
             std::swap(V, Vn);
         }
-        if (cx) hipLaunchKernelGGL(finish_coeff<c64>, dim3(g1), dim3(256), 0, ctx->stream, (const c64*)V,
+        if (cx) hipLaunchKernelGGL(finish_coeff<c64>, dim3(g1), dim3(256), 0, qil_stream(ctx), (const c64*)V,
                                    (long long)nb, psi->amplitude, (c64*)dout);
-        else hipLaunchKernelGGL(finish_coeff<double>, dim3(g1), dim3(256), 0, ctx->stream, (const double*)V,
+        else hipLaunchKernelGGL(finish_coeff<double>, dim3(g1), dim3(256), 0, qil_stream(ctx), (const double*)V,
                                 (long long)nb, psi->amplitude, (c64*)dout);
         QIL_HIP(hipGetLastError());
         qil_ctx_free(ctx, V);
@@ -436,13 +436,13 @@ static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* db
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * nb * maxchi) * esz, &scratch));
     QIL_TRY(qil_ctx_desc_acquire(ctx, tab.size() * sizeof(ChainSite), &pin, &dtab, &slot));
     memcpy(pin, tab.data(), tab.size() * sizeof(ChainSite));
-    QIL_HIP(hipMemcpyAsync(dtab, pin, tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dtab, pin, tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, qil_stream(ctx)));
     if (psi->dtype == QIL_C64)
-        hipLaunchKernelGGL(coefficient_chain<c64>, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream,
+        hipLaunchKernelGGL(coefficient_chain<c64>, dim3((unsigned)nb), dim3(kThreads), 0, qil_stream(ctx),
                            (const ChainSite*)dtab, (int)n, dbits, (c64*)scratch, maxchi, (c64*)dout,
                            psi->amplitude);
     else
-        hipLaunchKernelGGL(coefficient_chain<double>, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream,
+        hipLaunchKernelGGL(coefficient_chain<double>, dim3((unsigned)nb), dim3(kThreads), 0, qil_stream(ctx),
                            (const ChainSite*)dtab, (int)n, dbits, (double*)scratch, maxchi, (c64*)dout,
                            psi->amplitude);
     QIL_HIP(hipGetLastError());
@@ -462,8 +462,8 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
     void* dout = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout));
     QIL_TRY(coefficient_enqueue(psi, nb, dbits, dout));
-    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, dout);
     qil_ctx_free(ctx, dbits);
     return QIL_OK;
@@ -525,8 +525,8 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
     } else {
         for (int64_t j = 0; j < nw; ++j) QIL_TRY(one(Ws[j], psi, j));
     }
-    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)(nw * nb) * 16, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)(nw * nb) * 16, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, dout);
     qil_ctx_free(ctx, dbits);
     return QIL_OK;
@@ -566,9 +566,9 @@ extern "C" int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi,
     static const long long lazy_min = 1024;   // measured crossover: 1.0 vs 2.0 ms at 1024, 0.85 vs 0.77 at 512
     if (nb >= 16 && msz >= lazy_min) {
         int st = lazy_gemm_path(ctx, W, psi, nb, dbits, (c64*)dout);
-        if (st == QIL_OK && hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        if (st == QIL_OK && hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, qil_stream(ctx)) != hipSuccess)
             st = qil_fail(QIL_EHIP, "apply_coefficient: download failed");
-        if (st == QIL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = qil_fail(QIL_EHIP, "sync failed");
+        if (st == QIL_OK && qil_stream_sync(ctx) != hipSuccess) st = qil_fail(QIL_EHIP, "sync failed");
         qil_ctx_free(ctx, dout);
         qil_ctx_free(ctx, dbits);
         return st;
@@ -576,10 +576,10 @@ extern "C" int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi,
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(4 * nb * msz) * 16, &scratch));
     QIL_TRY(qil_ctx_desc_acquire(ctx, tab.size() * sizeof(ChainSite), &pin, &dtab, &slot));
     memcpy(pin, tab.data(), tab.size() * sizeof(ChainSite));
-    QIL_HIP(hipMemcpyAsync(dtab, pin, tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dtab, pin, tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, qil_stream(ctx)));
     const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;
 #define LAUNCH_LAZY(TW, TA)                                                                             \
-    hipLaunchKernelGGL((lazy_coefficient_chain<TW, TA>), dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, \
+    hipLaunchKernelGGL((lazy_coefficient_chain<TW, TA>), dim3((unsigned)nb), dim3(kThreads), 0, qil_stream(ctx), \
                        (const ChainSite*)dtab, (int)n, dbits, (c64*)scratch, msz, (c64*)dout, psi->amplitude)
     if (wc && ac) LAUNCH_LAZY(c64, c64);
     else if (wc) LAUNCH_LAZY(c64, double);
@@ -588,8 +588,8 @@ extern "C" int qil_apply_coefficient_batch(const qil_mpo* W, const qil_mps* psi,
 #undef LAUNCH_LAZY
     QIL_HIP(hipGetLastError());
     QIL_TRY(qil_ctx_desc_commit(ctx, slot));
-    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, scratch);
     qil_ctx_free(ctx, dout);
     qil_ctx_free(ctx, dbits);
@@ -629,8 +629,8 @@ extern "C" int qil_mps_block(const qil_mps* psi, const uint8_t* spec, int revers
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxel * e, &bufB));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxslice * e, &sl));
     const double one[2] = {1.0, 0.0};
-    QIL_HIP(hipMemcpyAsync(bufA, one, e, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(bufA, one, e, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     // the fixed / summed sites BEHIND the last free one fold into a right boundary vector first (O(chi^2) each,
     // instead of dragging the 2^F rows of T through them)
     int64_t last_free = -1;
@@ -641,17 +641,17 @@ extern "C" int qil_mps_block(const qil_mps* psi, const uint8_t* spec, int revers
     void *rv = nullptr, *rv2 = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxchi * e, &rv));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)maxchi * e, &rv2));
-    QIL_HIP(hipMemcpyAsync(rv, one, e, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(rv, one, e, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     auto site_slice = [&](int64_t i, const void** B, long long* ldb) -> int {   // the (chi_l x chi_r) factor of site i
         const long long cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
         const char* A = static_cast<const char*>(psi->site[(size_t)i]);
         if (spec[i] == 2) {
             const unsigned g = (unsigned)std::min<long long>((cl * cr + 255) / 256, 4096);
             if (dt == QIL_C64)
-                hipLaunchKernelGGL(slice_sum<c64>, dim3(g), dim3(256), 0, ctx->stream, (const c64*)A, (int)cl, (int)cr, (c64*)sl);
+                hipLaunchKernelGGL(slice_sum<c64>, dim3(g), dim3(256), 0, qil_stream(ctx), (const c64*)A, (int)cl, (int)cr, (c64*)sl);
             else
-                hipLaunchKernelGGL(slice_sum<double>, dim3(g), dim3(256), 0, ctx->stream, (const double*)A, (int)cl, (int)cr,
+                hipLaunchKernelGGL(slice_sum<double>, dim3(g), dim3(256), 0, qil_stream(ctx), (const double*)A, (int)cl, (int)cr,
                                    (double*)sl);
             *B = sl;
             *ldb = cl;
@@ -692,14 +692,14 @@ extern "C" int qil_mps_block(const qil_mps* psi, const uint8_t* spec, int revers
     // natural order: the first free site is the LOWEST bit of idx
     const unsigned g = (unsigned)std::min<long long>((rows + 255) / 256, 65536);
     if (dt == QIL_C64)
-        hipLaunchKernelGGL(bit_reverse_scale<c64>, dim3(g), dim3(256), 0, ctx->stream, (const c64*)cur, (c64*)nxt, nfree,
+        hipLaunchKernelGGL(bit_reverse_scale<c64>, dim3(g), dim3(256), 0, qil_stream(ctx), (const c64*)cur, (c64*)nxt, nfree,
                            psi->amplitude, reverse ? 0 : 1);
     else
-        hipLaunchKernelGGL(bit_reverse_scale<double>, dim3(g), dim3(256), 0, ctx->stream, (const double*)cur, (double*)nxt,
+        hipLaunchKernelGGL(bit_reverse_scale<double>, dim3(g), dim3(256), 0, qil_stream(ctx), (const double*)cur, (double*)nxt,
                            nfree, psi->amplitude, reverse ? 0 : 1);
     QIL_HIP(hipGetLastError());
-    QIL_HIP(hipMemcpyAsync(host_out, nxt, (size_t)rows * e, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(host_out, nxt, (size_t)rows * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, bufA);
     qil_ctx_free(ctx, bufB);
     qil_ctx_free(ctx, sl);
@@ -733,8 +733,8 @@ extern "C" int qil_norm(const qil_mps* psi, double* out) {
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(maxchi * maxchi) * esz, &En));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * maxchi * maxchi) * esz, &T));
     const double one[2] = {1.0, 0.0};
-    QIL_HIP(hipMemcpyAsync(E, one, esz, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(E, one, esz, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     for (int64_t i = 0; i < n; ++i) {
         const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
         // T (cl x 2cr) = E (cl x cl) * A (cl x 2cr);   E[alpha', alpha]
@@ -744,8 +744,8 @@ extern "C" int qil_norm(const qil_mps* psi, double* out) {
         std::swap(E, En);
     }
     double h[2] = {0, 0};
-    QIL_HIP(hipMemcpyAsync(h, E, esz, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(h, E, esz, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     *out = sqrt(sqrt(h[0] * h[0] + h[1] * h[1]));
     qil_ctx_free(ctx, E);
     qil_ctx_free(ctx, En);

@@ -14,6 +14,7 @@
 #include <cmath>
 
 #include "qil_internal.h"
+#include "qil_launch.h"
 
 namespace {
 
@@ -38,14 +39,13 @@ int copy_2d(qil_context* ctx, int dtype, int64_t rows, int64_t cols, const void*
             int64_t ldd) {
     if (rows == 0 || cols == 0) return QIL_OK;
     const size_t e = qil_elem_size(dtype);
-    QIL_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * e, src, (size_t)lds_ * e, (size_t)rows * e, (size_t)cols,
-                             hipMemcpyDeviceToDevice, ctx->stream));
+    QIL_TRY(qil_dev_copy2d(ctx, dst, (size_t)ldd * e, src, (size_t)lds_ * e, (size_t)rows * e, (size_t)cols));
     return QIL_OK;
 }
 
 // out[2 * block] += |A - D|_F^2 over this block's elements, out[2 * block + 1] += |A|_F^2   (A: lda, D: ldd; doubles viewed
 // as reals: nre = 1 real / 2 complex values per element)
-__global__ __launch_bounds__(256) void residual_sumsq(const double* __restrict__ A, long long lda, const double* __restrict__ D,
+__device__ __forceinline__ void residual_sumsq_body(const uint3 blockIdx, const uint3 gridDim, const double* __restrict__ A, long long lda, const double* __restrict__ D,
                                                        long long ldd, long long m, long long n, int nre,
                                                        double* __restrict__ out) {
     __shared__ double red[8];
@@ -72,6 +72,13 @@ __global__ __launch_bounds__(256) void residual_sumsq(const double* __restrict__
         out[2 * blockIdx.x + 1] = (red[4] + red[5]) + (red[6] + red[7]);
     }
 }
+struct residual_sumsq_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        residual_sumsq_body(b, g, a...);
+    }
+};
 
 int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, double cutoff,
                   bool use_cutoff, int64_t maxdim, int64_t mindim, int absorb, int64_t* rank, void** U_out,
@@ -116,11 +123,10 @@ static int svd_trunc_lowrank(qil_context* ctx, int dtype, int64_t m, int64_t n, 
         QIL_TRY(qil_dev_gemm(ctx, dtype, 0, 0, m, n, k, Y, m, B, k, D, m));                          // D = Q B
         const unsigned nblk_ = (unsigned)std::min<long long>((m * n * nre + 255) / 256, 1024);
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)nblk_ * 2 * sizeof(double), &part));
-        hipLaunchKernelGGL(residual_sumsq, dim3(nblk_), dim3(256), 0, ctx->stream, (const double*)A, (long long)lda,
-                           (const double*)D, (long long)m, (long long)m, (long long)n, nre, (double*)part);
+        QIL_TRY((qil_klaunch<residual_sumsq_k>(ctx, dim3(nblk_), dim3(256), 0, (const double*)A, (long long)lda, (const double*)D, (long long)m, (long long)m, (long long)n, nre, (double*)part)));
         std::vector<double> hp((size_t)nblk_ * 2);
-        QIL_HIP(hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        QIL_HIP(hipStreamSynchronize(ctx->stream));
+        QIL_HIP(hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));
         double rho = 0, tot = 0;
         for (unsigned b = 0; b < nblk_; ++b) {
             rho += hp[2 * b];
@@ -187,7 +193,7 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
                     QIL_TRY(copy_2d(ctx, dtype, m, r0, Qb, rows, U, m));
                     QIL_TRY(copy_2d(ctx, dtype, r0, n, Rb, r0, Vh, r0));
                 } else {                             // every row direction is kept: U = I, the rest = A
-                    QIL_HIP(hipMemsetAsync(U, 0, (size_t)(m * r0) * e, ctx->stream));
+                    QIL_TRY(qil_dev_zero(ctx, U, (size_t)(m * r0) * e));
                     QIL_TRY(qil_dev_set_identity(ctx, dtype, U, m, r0));
                     QIL_TRY(copy_2d(ctx, dtype, m, n, A, lda, Vh, r0));
                 }
@@ -196,7 +202,7 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
                     QIL_TRY(qil_dev_transpose(ctx, dtype, 1, rows, r0, Qb, rows, Vh, r0));
                     QIL_TRY(qil_dev_transpose(ctx, dtype, 1, r0, r0, Rb, r0, U, m));
                 } else {                             // every column direction is kept: Vh = I, U S = A
-                    QIL_HIP(hipMemsetAsync(Vh, 0, (size_t)(r0 * n) * e, ctx->stream));
+                    QIL_TRY(qil_dev_zero(ctx, Vh, (size_t)(r0 * n) * e));
                     QIL_TRY(qil_dev_set_identity(ctx, dtype, Vh, r0, r0));
                     QIL_TRY(copy_2d(ctx, dtype, m, n, A, lda, U, m));
                 }
@@ -340,6 +346,7 @@ int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cuto
         const int64_t c = center == 0 ? N : center;
         QIL_REQUIRE(c >= 1 && c <= N, QIL_EDOMAIN, "Center out of range [1,%lld]", (long long)N);
         for (int64_t i = 0; i + 1 < c; ++i) {  // mps.jl:802-817
+            qil_progress_step(ctx, i == 0, i);                                  // lock-step batches: where this chain is
             const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
             const int64_t cr2 = psi->dims[(size_t)i + 2];
             if (gauge_qr && pd * cl >= cr) {
@@ -361,7 +368,10 @@ int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cuto
     } else if (direction == QIL_DIR_LEFT) {
         const int64_t c = center == 0 ? 1 : center;
         QIL_REQUIRE(c >= 1 && c <= N, QIL_EDOMAIN, "Center out of range [1,%lld]", (long long)N);
-        for (int64_t i = N - 1; i >= c; --i) QIL_TRY(gauge_site_left(psi, i, cutoff, maxdim, gauge_qr));  // mps.jl:822-837
+        for (int64_t i = N - 1; i >= c; --i) {                                                             // mps.jl:822-837
+            qil_progress_step(ctx, i == N - 1, N - 1 - i);
+            QIL_TRY(gauge_site_left(psi, i, cutoff, maxdim, gauge_qr));
+        }
     } else {
         return qil_fail(QIL_EINVAL_ARG, "Direction must be :right or :left");
     }
@@ -371,7 +381,7 @@ int canonicalize_impl(qil_chain* psi, int direction, int64_t center, double cuto
 // ---------------------------------------------------------------- helper kernels (layout permutations)
 // site A[alpha + cl*(s + 2*k)] = Vyh[k + ldv*(s + 2*alpha)]      (signal_mps :svd, see below)
 template <class T>
-__global__ void site_from_vh(const T* __restrict__ Vyh, long long ldv, int cl, int k, T* __restrict__ A) {
+__device__ __forceinline__ void site_from_vh_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ Vyh, long long ldv, int cl, int k, T* __restrict__ A) {
     const long long total = 2LL * cl * k;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {
@@ -382,10 +392,18 @@ __global__ void site_from_vh(const T* __restrict__ Vyh, long long ldv, int cl, i
         A[t] = Vyh[kk + ldv * (s + 2LL * alpha)];
     }
 }
+template <class T>
+struct site_from_vh_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        site_from_vh_body<T>(b, g, a...);
+    }
+};
 
 // canonical site A[lb + cl*(s + 2*rb)] from the chunk layout X[rb + cr*(s + 2*lb)]
 template <class T>
-__global__ void site_from_chunk(const T* __restrict__ X, int cl, int cr, T* __restrict__ A) {
+__device__ __forceinline__ void site_from_chunk_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ X, int cl, int cr, T* __restrict__ A) {
     const long long total = 2LL * cl * cr;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {
@@ -396,10 +414,18 @@ __global__ void site_from_chunk(const T* __restrict__ X, int cl, int cr, T* __re
         A[t] = X[rb + (long long)cr * (s + 2LL * lb)];
     }
 }
+template <class T>
+struct site_from_chunk_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        site_from_chunk_body<T>(b, g, a...);
+    }
+};
 
 // T[(alpha, m), (c, beta)] = A[alpha, m, beta] * delta(m, c)   (signal_ztmps, SignalConverters.jl:263)
 template <class T>
-__global__ void fuse_delta(const T* __restrict__ A, int cl, int cr, T* __restrict__ Tm) {
+__device__ __forceinline__ void fuse_delta_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ A, int cl, int cr, T* __restrict__ Tm) {
     const long long total = 4LL * cl * cr;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {
@@ -410,11 +436,19 @@ __global__ void fuse_delta(const T* __restrict__ A, int cl, int cr, T* __restric
         Tm[t] = (m == c) ? A[alpha + (long long)cl * (m + 2 * beta)] : T{};
     }
 }
+template <class T>
+struct fuse_delta_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        fuse_delta_body<T>(b, g, a...);
+    }
+};
 
 inline unsigned nblk(long long total) { return (unsigned)std::min<long long>((total + 255) / 256, 65536); }
 
 // per-workgroup partial sums of squares (fixed grid => the host-side final sum has a fixed order)
-__global__ __launch_bounds__(256) void sumsq_partial(const double* __restrict__ x, long long n,
+__device__ __forceinline__ void sumsq_partial_body(const uint3 blockIdx, const uint3 gridDim, const double* __restrict__ x, long long n,
                                                      double* __restrict__ part) {
     __shared__ double red[4];
     double v = 0;
@@ -425,11 +459,25 @@ __global__ __launch_bounds__(256) void sumsq_partial(const double* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ void scale_inplace(double* __restrict__ x, long long n, double s) {
+struct sumsq_partial_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        sumsq_partial_body(b, g, a...);
+    }
+};
+__device__ __forceinline__ void scale_inplace_body(const uint3 blockIdx, const uint3 gridDim, double* __restrict__ x, long long n, double s) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n;
          t += (long long)gridDim.x * blockDim.x)
         x[t] *= s;
 }
+struct scale_inplace_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        scale_inplace_body(b, g, a...);
+    }
+};
 
 // ---------------------------------------------------------------- rsvd on a device operand
 // `Z` holds M^T (plain transpose) column-major: Z is (n x m) for the m x n operand M ("M stored
@@ -452,7 +500,7 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
         // the bisection encoder ends up here (SignalConverters.jl:161: m or n <= k + p).
         void* Zc = nullptr;
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &Zc));
-        QIL_HIP(hipMemcpyAsync(Zc, Z, (size_t)(m * n) * e, hipMemcpyDeviceToDevice, ctx->stream));
+        QIL_TRY(qil_dev_copy(ctx, Zc, Z, (size_t)(m * n) * e));
         int64_t r = 0;
         void *UzS = nullptr, *Vzh = nullptr;
         QIL_TRY(svd_trunc_dev(ctx, dt, n, m, Zc, n, cutoff, true, maxdim, mindim, 1, &r, &UzS, &Vzh, S_out));
@@ -467,7 +515,7 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!dbg) return;
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)qil_stream_sync(ctx);
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[rsvd] %lld x %lld, l = %lld: %s %.2f ms\n", (long long)m, (long long)n, (long long)l, what,
                 std::chrono::duration<double, std::milli>(now - t_prev).count());
@@ -543,11 +591,9 @@ int compress_tt(qil_context* ctx, int dt, void* X, int64_t lb, int64_t rb, int64
         void* A = nullptr;
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(lb * 2 * rb) * e, &A));
         if (dt == QIL_C64)
-            hipLaunchKernelGGL(site_from_chunk<c64>, dim3(nblk(2 * lb * rb)), dim3(256), 0, ctx->stream,
-                               (const c64*)X, (int)lb, (int)rb, (c64*)A);
+            QIL_TRY((qil_klaunch<site_from_chunk_k<c64>>(ctx, dim3(nblk(2 * lb * rb)), dim3(256), 0, (const c64*)X, (int)lb, (int)rb, (c64*)A)));
         else
-            hipLaunchKernelGGL(site_from_chunk<double>, dim3(nblk(2 * lb * rb)), dim3(256), 0, ctx->stream,
-                               (const double*)X, (int)lb, (int)rb, (double*)A);
+            QIL_TRY((qil_klaunch<site_from_chunk_k<double>>(ctx, dim3(nblk(2 * lb * rb)), dim3(256), 0, (const double*)X, (int)lb, (int)rb, (double*)A)));
         QIL_HIP(hipGetLastError());
         sites[(size_t)first] = A;
         dims[(size_t)first] = lb;
@@ -647,11 +693,9 @@ int svd_sweep(qil_context* ctx, int dt, void* X, int64_t n, const EncodeParams& 
         void* A = nullptr;
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * 2 * k) * e, &A));
         if (dt == QIL_C64)
-            hipLaunchKernelGGL(site_from_vh<c64>, dim3(nblk(2 * r * k)), dim3(256), 0, ctx->stream,
-                               (const c64*)Vyh, (long long)k, (int)r, (int)k, (c64*)A);
+            QIL_TRY((qil_klaunch<site_from_vh_k<c64>>(ctx, dim3(nblk(2 * r * k)), dim3(256), 0, (const c64*)Vyh, (long long)k, (int)r, (int)k, (c64*)A)));
         else
-            hipLaunchKernelGGL(site_from_vh<double>, dim3(nblk(2 * r * k)), dim3(256), 0, ctx->stream,
-                               (const double*)Vyh, (long long)k, (int)r, (int)k, (double*)A);
+            QIL_TRY((qil_klaunch<site_from_vh_k<double>>(ctx, dim3(nblk(2 * r * k)), dim3(256), 0, (const double*)Vyh, (long long)k, (int)r, (int)k, (double*)A)));
         QIL_HIP(hipGetLastError());
         qil_ctx_free(ctx, Vyh);
         sites[(size_t)i] = A;
@@ -663,11 +707,9 @@ int svd_sweep(qil_context* ctx, int dt, void* X, int64_t n, const EncodeParams& 
     void* A = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * 2) * e, &A));
     if (dt == QIL_C64)
-        hipLaunchKernelGGL(site_from_chunk<c64>, dim3(1), dim3(256), 0, ctx->stream, (const c64*)X, (int)r, 1,
-                           (c64*)A);
+        QIL_TRY((qil_klaunch<site_from_chunk_k<c64>>(ctx, dim3(1), dim3(256), 0, (const c64*)X, (int)r, 1, (c64*)A)));
     else
-        hipLaunchKernelGGL(site_from_chunk<double>, dim3(1), dim3(256), 0, ctx->stream, (const double*)X, (int)r,
-                           1, (double*)A);
+        QIL_TRY((qil_klaunch<site_from_chunk_k<double>>(ctx, dim3(1), dim3(256), 0, (const double*)X, (int)r, 1, (double*)A)));
     QIL_HIP(hipGetLastError());
     qil_ctx_free(ctx, X);
     sites[(size_t)n - 1] = A;
@@ -696,17 +738,16 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
     void* X = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)N * e, &X));
     // `x` may live on the host or already in HBM (unified addressing resolves the direction)
-    QIL_HIP(hipMemcpyAsync(X, x, (size_t)len * e, hipMemcpyDefault, ctx->stream));
+    QIL_HIP(hipMemcpyAsync(X, x, (size_t)len * e, hipMemcpyDefault, qil_stream(ctx)));
     if (len < N)
-        QIL_HIP(hipMemsetAsync(static_cast<char*>(X) + (size_t)len * e, 0, (size_t)(N - len) * e, ctx->stream));
+        QIL_TRY(qil_dev_zero(ctx, static_cast<char*>(X) + (size_t)len * e, (size_t)(N - len) * e));
     void* part = nullptr;
     constexpr int kPartBlocks = 1024;
     QIL_TRY(qil_ctx_alloc(ctx, kPartBlocks * sizeof(double), &part));
-    hipLaunchKernelGGL(sumsq_partial, dim3(kPartBlocks), dim3(256), 0, ctx->stream, (const double*)X,
-                       (long long)(N * ncomp), (double*)part);
+    QIL_TRY((qil_klaunch<sumsq_partial_k>(ctx, dim3(kPartBlocks), dim3(256), 0, (const double*)X, (long long)(N * ncomp), (double*)part)));
     std::vector<double> ph(kPartBlocks);
-    QIL_HIP(hipMemcpyAsync(ph.data(), part, kPartBlocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));   // also completes the upload of caller memory `x`
+    QIL_HIP(hipMemcpyAsync(ph.data(), part, kPartBlocks * sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));   // also completes the upload of caller memory `x`
     qil_ctx_free(ctx, part);
     double ss = 0;
     for (double v : ph) ss += v;                  // fixed order: deterministic
@@ -715,8 +756,7 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
         qil_ctx_free(ctx, X);
         return qil_fail(QIL_EINVAL_ARG, "signal_mps: signal has zero or non-finite norm");
     }
-    hipLaunchKernelGGL(scale_inplace, dim3(nblk(N * ncomp)), dim3(256), 0, ctx->stream, (double*)X,
-                       (long long)(N * ncomp), 1.0 / amp);
+    QIL_TRY((qil_klaunch<scale_inplace_k>(ctx, dim3(nblk(N * ncomp)), dim3(256), 0, (double*)X, (long long)(N * ncomp), 1.0 / amp)));
     QIL_HIP(hipGetLastError());
     std::vector<void*> sites((size_t)n, nullptr);
     std::vector<int64_t> dims((size_t)n + 1, 1);
@@ -760,7 +800,7 @@ __device__ __forceinline__ double zadd(double a, double b) { return a + b; }
 
 // X[r, a, s', beta] = sum_alpha Rm[r, alpha, a] * A[alpha, s', beta]      (Rm index: r + R*(alpha + cl*a))
 template <class TO, class TA>
-__global__ void zip_stage1(const TO* __restrict__ Rm, const TA* __restrict__ A, TO* __restrict__ X, int R, int Dl,
+__device__ __forceinline__ void zip_stage1_body(const uint3 blockIdx, const uint3 gridDim, const TO* __restrict__ Rm, const TA* __restrict__ A, TO* __restrict__ X, int R, int Dl,
                            int cl, int cr) {
     const long long total = (long long)R * Dl * 2 * cr;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
@@ -779,10 +819,18 @@ __global__ void zip_stage1(const TO* __restrict__ Rm, const TA* __restrict__ A, 
         X[t] = acc;
     }
 }
+template <class TO, class TA>
+struct zip_stage1_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        zip_stage1_body<TO, TA>(b, g, a...);
+    }
+};
 
 // theta[(r, s), (beta, b)] = sum_{a, s'} X[r, a, s', beta] * W[a, s', s, b]
 template <class TO, class TW>
-__global__ void zip_stage2(const TO* __restrict__ X, const TW* __restrict__ W, TO* __restrict__ theta, int R, int Dl,
+__device__ __forceinline__ void zip_stage2_body(const uint3 blockIdx, const uint3 gridDim, const TO* __restrict__ X, const TW* __restrict__ W, TO* __restrict__ theta, int R, int Dl,
                            int Dr, int cr) {
     const long long total = (long long)R * 2 * cr * Dr;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
@@ -803,6 +851,14 @@ __global__ void zip_stage2(const TO* __restrict__ X, const TW* __restrict__ W, T
         theta[t] = acc;
     }
 }
+template <class TO, class TW>
+struct zip_stage2_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        zip_stage2_body<TO, TW>(b, g, a...);
+    }
+};
 
 template <class TO, class TW, class TA>
 int zip_theta(qil_context* ctx, const void* Rm, const void* W, const void* A, int R, int Dl, int Dr, int cl, int cr,
@@ -810,10 +866,8 @@ int zip_theta(qil_context* ctx, const void* Rm, const void* W, const void* A, in
     void *X = nullptr, *th = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)R * Dl * 2 * cr * sizeof(TO), &X));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)R * 2 * cr * Dr * sizeof(TO), &th));
-    hipLaunchKernelGGL((zip_stage1<TO, TA>), dim3(nblk((long long)R * Dl * 2 * cr)), dim3(256), 0, ctx->stream,
-                       (const TO*)Rm, (const TA*)A, (TO*)X, R, Dl, cl, cr);
-    hipLaunchKernelGGL((zip_stage2<TO, TW>), dim3(nblk((long long)R * 2 * cr * Dr)), dim3(256), 0, ctx->stream,
-                       (const TO*)X, (const TW*)W, (TO*)th, R, Dl, Dr, cr);
+    QIL_TRY((qil_klaunch<zip_stage1_k<TO, TA>>(ctx, dim3(nblk((long long)R * Dl * 2 * cr)), dim3(256), 0, (const TO*)Rm, (const TA*)A, (TO*)X, R, Dl, cl, cr)));
+    QIL_TRY((qil_klaunch<zip_stage2_k<TO, TW>>(ctx, dim3(nblk((long long)R * 2 * cr * Dr)), dim3(256), 0, (const TO*)X, (const TW*)W, (TO*)th, R, Dl, Dr, cr)));
     QIL_HIP(hipGetLastError());
     qil_ctx_free(ctx, X);
     *theta_out = th;
@@ -823,7 +877,7 @@ int zip_theta(qil_context* ctx, const void* Rm, const void* W, const void* A, in
 // Z[(alpha, a), (s, r')] = sum_{s', b} Y[alpha, s', b, r'] W[a, s', s, b]     (right environment of the fit sweep)
 //   Y index (alpha + cl s') + 2 cl (b + Dr r'),  W index a + Dl (s' + 2 (s + 2 b)),  Z index (alpha + cl a) + cl Dl (s + 2 r')
 template <class T>
-__global__ void fit_env_stage(const T* __restrict__ Y, const T* __restrict__ W, T* __restrict__ Z, int cl, int Dl,
+__device__ __forceinline__ void fit_env_stage_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ Y, const T* __restrict__ W, T* __restrict__ Z, int cl, int Dl,
                               int Dr, int rp) {
     const long long total = (long long)cl * Dl * 2 * rp;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
@@ -844,11 +898,26 @@ __global__ void fit_env_stage(const T* __restrict__ Y, const T* __restrict__ W, 
         Z[t] = acc;
     }
 }
+template <class T>
+struct fit_env_stage_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        fit_env_stage_body<T>(b, g, a...);
+    }
+};
 
-__global__ void widen_f64(const double* __restrict__ in, c64* __restrict__ out, long long n) {
+__device__ __forceinline__ void widen_f64_body(const uint3 blockIdx, const uint3 gridDim, const double* __restrict__ in, c64* __restrict__ out, long long n) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
         out[t] = c64{in[t], 0.0};
 }
+struct widen_f64_k {
+    static constexpr int NT = 1024, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        widen_f64_body(b, g, a...);
+    }
+};
 
 }  // namespace
 
@@ -956,16 +1025,14 @@ static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* 
             const long long ne = phi->site_elems(i);
             void* p = nullptr;
             if ((st = take((size_t)ne * e, &p)) != QIL_OK) break;
-            hipLaunchKernelGGL(widen_f64, dim3(nblk(ne)), dim3(256), 0, ctx->stream, (const double*)phi->site[(size_t)i],
-                               (c64*)p, ne);
+            QIL_TRY((qil_klaunch<widen_f64_k>(ctx, dim3(nblk(ne)), dim3(256), 0, (const double*)phi->site[(size_t)i], (c64*)p, ne)));
             Asite[(size_t)i] = p;
         }
         if (odt == QIL_C64 && !wc) {
             const long long ne = W->site_elems(i);
             void* p = nullptr;
             if ((st = take((size_t)ne * e, &p)) != QIL_OK) break;
-            hipLaunchKernelGGL(widen_f64, dim3(nblk(ne)), dim3(256), 0, ctx->stream, (const double*)W->site[(size_t)i],
-                               (c64*)p, ne);
+            QIL_TRY((qil_klaunch<widen_f64_k>(ctx, dim3(nblk(ne)), dim3(256), 0, (const double*)W->site[(size_t)i], (c64*)p, ne)));
             Wsite[(size_t)i] = p;
         }
     }
@@ -984,9 +1051,9 @@ static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* 
     auto one = [&](void** p) {                       // 1 x 1 environment
         int s2 = take(e, p);
         const double v[2] = {1.0, 0.0};
-        if (s2 == QIL_OK && hipMemcpyAsync(*p, v, e, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        if (s2 == QIL_OK && hipMemcpyAsync(*p, v, e, hipMemcpyHostToDevice, qil_stream(ctx)) != hipSuccess)
             s2 = qil_fail(QIL_EHIP, "apply_compress: upload failed");
-        if (s2 == QIL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s2 = qil_fail(QIL_EHIP, "sync failed");
+        if (s2 == QIL_OK && qil_stream_sync(ctx) != hipSuccess) s2 = qil_fail(QIL_EHIP, "sync failed");
         return s2;
     };
     res = new qil_mps();
@@ -1002,7 +1069,7 @@ static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* 
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!fdbg) return;
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)qil_stream_sync(ctx);
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[apply_compress] %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
@@ -1086,11 +1153,9 @@ static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* 
         if (st != QIL_OK) return cleanup(st);
         if ((st = take((size_t)cl * Dl * 2 * rp * e, &Z)) != QIL_OK) return cleanup(st);
         if (odt == QIL_F64)
-            hipLaunchKernelGGL(fit_env_stage<double>, dim3(nblk((long long)cl * Dl * 2 * rp)), dim3(256), 0, ctx->stream,
-                               (const double*)Y, (const double*)Wsite[(size_t)i], (double*)Z, cl, Dl, Dr, rp);
+            QIL_TRY((qil_klaunch<fit_env_stage_k<double>>(ctx, dim3(nblk((long long)cl * Dl * 2 * rp)), dim3(256), 0, (const double*)Y, (const double*)Wsite[(size_t)i], (double*)Z, cl, Dl, Dr, rp)));
         else
-            hipLaunchKernelGGL(fit_env_stage<c64>, dim3(nblk((long long)cl * Dl * 2 * rp)), dim3(256), 0, ctx->stream,
-                               (const c64*)Y, (const c64*)Wsite[(size_t)i], (c64*)Z, cl, Dl, Dr, rp);
+            QIL_TRY((qil_klaunch<fit_env_stage_k<c64>>(ctx, dim3(nblk((long long)cl * Dl * 2 * rp)), dim3(256), 0, (const c64*)Y, (const c64*)Wsite[(size_t)i], (c64*)Z, cl, Dl, Dr, rp)));
         if (hipGetLastError() != hipSuccess) return cleanup(qil_fail(QIL_EHIP, "apply_compress: launch failed"));
         if ((st = take((size_t)cl * Dl * K * e, &Rn)) != QIL_OK) return cleanup(st);
         // R_{i-1}[(alpha, a), k] = sum_{s, r'} Z[(alpha, a), (s, r')] conj(phi_i[k, (s, r')])
@@ -1237,15 +1302,15 @@ extern "C" int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t
     const size_t e = qil_elem_size(dtype);
     void* dA = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
-    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     int64_t r = 0;
     void *dU = nullptr, *dVh = nullptr;
     std::vector<double> Sv;
     QIL_TRY(svd_trunc_dev(ctx, dtype, m, n, dA, m, cutoff, cutoff >= 0, maxdim, mindim, 0, &r, &dU, &dVh, &Sv));
-    QIL_HIP(hipMemcpyAsync(U, dU, (size_t)(m * r) * e, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipMemcpyAsync(Vh, dVh, (size_t)(r * n) * e, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(U, dU, (size_t)(m * r) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(hipMemcpyAsync(Vh, dVh, (size_t)(r * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     for (int64_t i = 0; i < r; ++i) S[i] = Sv[(size_t)i];
     *rank = r;
     qil_ctx_free(ctx, dA);
@@ -1268,8 +1333,8 @@ extern "C" int qil_rsvd(qil_context* ctx, const void* A, int64_t m, int64_t n, i
     void *dA = nullptr, *Z = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &dA));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * e, &Z));
-    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(dA, A, (size_t)(m * n) * e, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     QIL_TRY(qil_dev_transpose(ctx, dtype, 0, m, n, dA, m, Z, n));               // Z = A^T ("A row-major")
     qil_ctx_free(ctx, dA);
     if (maxdim <= 0) maxdim = k;                                                 // maxdim = k default (rsvd.jl:47)
@@ -1288,9 +1353,9 @@ extern "C" int qil_rsvd(qil_context* ctx, const void* A, int64_t m, int64_t n, i
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * n) * e, &dVh));
     QIL_TRY(qil_dev_transpose(ctx, dtype, 0, r, m, L, r, dU, m));
     QIL_TRY(qil_dev_transpose(ctx, dtype, 0, n, r, R, n, dVh, r));
-    QIL_HIP(hipMemcpyAsync(U, dU, (size_t)(m * r) * e, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipMemcpyAsync(Vh, dVh, (size_t)(r * n) * e, hipMemcpyDeviceToHost, ctx->stream));
-    QIL_HIP(hipStreamSynchronize(ctx->stream));
+    QIL_HIP(hipMemcpyAsync(U, dU, (size_t)(m * r) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(hipMemcpyAsync(Vh, dVh, (size_t)(r * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
+    QIL_HIP(qil_stream_sync(ctx));
     for (int64_t i = 0; i < r; ++i) S[i] = Sv[(size_t)i];
     *rank = r;
     qil_ctx_free(ctx, L);
@@ -1334,11 +1399,9 @@ extern "C" int qil_signal_ztmps(qil_context* ctx, const void* x, int64_t len, in
         status = qil_ctx_alloc(ctx, (size_t)(4 * cl * cr) * e, &T);
         if (status != QIL_OK) break;
         if (dtype == QIL_C64)
-            hipLaunchKernelGGL(fuse_delta<c64>, dim3(nblk(4 * cl * cr)), dim3(256), 0, ctx->stream,
-                               (const c64*)sig->site[(size_t)i], (int)cl, (int)cr, (c64*)T);
+            QIL_TRY((qil_klaunch<fuse_delta_k<c64>>(ctx, dim3(nblk(4 * cl * cr)), dim3(256), 0, (const c64*)sig->site[(size_t)i], (int)cl, (int)cr, (c64*)T)));
         else
-            hipLaunchKernelGGL(fuse_delta<double>, dim3(nblk(4 * cl * cr)), dim3(256), 0, ctx->stream,
-                               (const double*)sig->site[(size_t)i], (int)cl, (int)cr, (double*)T);
+            QIL_TRY((qil_klaunch<fuse_delta_k<double>>(ctx, dim3(nblk(4 * cl * cr)), dim3(256), 0, (const double*)sig->site[(size_t)i], (int)cl, (int)cr, (double*)T)));
         int64_t r = 0;
         void *U = nullptr, *SV = nullptr;
         status = svd_trunc_dev(ctx, dtype, 2 * cl, 2 * cr, T, 2 * cl, P.cutoff, true, P.maxdim, 1, 2, &r, &U, &SV,

@@ -10,8 +10,8 @@ template <class T, int BB>
 static void run(int k, const char* name) {
     const int nblk = ((k + BB - 1) / BB + 1) / 2 * 2;
     const size_t lds = gram_round_lds<T, BB>(k);
-    auto kern_ap = &gram_block_round<T, BB, true>;
-    auto kern_x = &gram_block_round<T, BB, false>;
+    auto kern_ap = &qil_k1<gram_block_round_k<T, BB, true>, gram_round_args<T>>;
+    auto kern_x = &qil_k1<gram_block_round_k<T, BB, false>, gram_round_args<T>>;
     long long* prof;
     (void)hipMalloc(&prof, 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_ap), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

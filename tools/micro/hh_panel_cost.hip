@@ -7,7 +7,7 @@
 
 template <class T, int KM>
 static void run(int m, int b, const char* name) {
-    auto kern = &hh_panel<T, KM, true>;
+    auto kern = &qil_k1<hh_panel_k<T, KM, true>, T*, long long, int, int, T*, long long, const double*, long long*>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     const size_t lds = (size_t)((m + 1) | 1) * b * sizeof(T) + 2048;
     long long* prof;

@@ -10,8 +10,8 @@ template <class T, int BB, int KM, int G>
 static void run(int k, const char* name) {
     const int nblk = ((k + BB - 1) / BB + 1) / 2 * 2;
     const size_t lds = block_round_nov_lds<T, BB, KM, G>();
-    auto kern_ap = &jacobi_block_round_nov<T, BB, KM, G, true, true>;
-    auto kern_x = &jacobi_block_round_nov<T, BB, KM, G, false, true>;
+    auto kern_ap = &qil_k1<jacobi_block_round_nov_k<T, BB, KM, G, true, true>, T*, long long, int, int, int, int, double, int*, const double*, long long*>;
+    auto kern_x = &qil_k1<jacobi_block_round_nov_k<T, BB, KM, G, false, true>, T*, long long, int, int, int, int, double, int*, const double*, long long*>;
     long long* prof;
     (void)hipMalloc(&prof, 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_ap), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
