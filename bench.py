@@ -224,6 +224,7 @@ def truncate_block(qil, ctx, reps=3, cpu=True):
         return [qil.SignalMPS.alloc(sat(24, 256), dtype=np.float64).fill_random(5 + i) for i in range(k)]
 
     t_one = t_eight = None
+    t_many = {}
     one_host = None
     for _ in range(2):                                                   # first round warms the pool and the worker streams
         one, eight = chains(1)[0], chains(8)
@@ -238,7 +239,16 @@ def truncate_block(qil, ctx, reps=3, cpu=True):
         qil.compress_batch(eight, maxdim=128, tol=1e-10)
         ctx.synchronize()
         t_eight = time.perf_counter() - t0
-    del one, eight
+        del eight
+        for nbig in (16, 32):
+            many = chains(nbig)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            qil.compress_batch(many, maxdim=128, tol=1e-10)
+            ctx.synchronize()
+            t_many[nbig] = time.perf_counter() - t0
+            del many
+    del one
     bits = np.random.default_rng(3).integers(0, 2, size=(256, 2 * n)).astype(np.uint8)
     c_f, c_e = qil.coefficient_batch(fused, bits), qil.coefficient_batch(prod, bits)
     c_x = qil.apply_coefficient_batch(W, psi, bits)
@@ -298,6 +308,9 @@ def truncate_block(qil, ctx, reps=3, cpu=True):
         "err_exact_route_vs_exact_product": float(np.abs(c_e - c_x).max() / scale),
         "compress_chi256_to_128_24_sites_ms": t_one * 1e3, "compress_batch_of_8_ms": t_eight * 1e3,
         "batch_of_8_over_single": t_eight / t_one,
+        "compress_batch_of_16_ms": t_many[16] * 1e3, "batch_of_16_over_single": t_many[16] / t_one,
+        "compress_batch_of_32_ms": t_many[32] * 1e3, "batch_of_32_over_single": t_many[32] / t_one,
+        "chains_per_s_batch_of_32": 32 / t_many[32], "chains_per_s_single": 1 / t_one,
         "cpu_baseline": cpu_res,
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS,
                      "achieved": f_exact / t_exact / 1e12, "frac": f_exact / t_exact / 1e12 / F64_MFMA_PEAK_TFLOPS,
