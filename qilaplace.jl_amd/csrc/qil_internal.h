@@ -110,6 +110,7 @@ inline hipStream_t qil_stream(qil_context* ctx) {
 // hipStreamSynchronize for chain code: inside a lock-step batch the slots share one stream that the launcher keeps feeding, so
 // the chain waits for an event recorded behind ITS last operation instead of for the whole stream to run dry
 hipError_t qil_stream_sync(qil_context* ctx);
+hipError_t qil_event_sync(qil_context* ctx, hipEvent_t ev);    // hipEventSynchronize that tells the batch's launcher the chain is parked
 int qil_ctx_activate(qil_context* ctx);  // hipSetDevice
 int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out);
 int qil_ctx_free(qil_context* ctx, void* p);

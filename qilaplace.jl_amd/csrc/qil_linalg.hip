@@ -3100,7 +3100,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         for (; st == QIL_OK && sweeps < MAXS; ++sweeps) {
             if (sweeps + 1 < MAXS) st = enqueue(sweeps + 1);
             if (st != QIL_OK) break;
-            if (hipEventSynchronize(ev[sweeps & 1]) != hipSuccess) {
+            if (qil_event_sync(ctx, ev[sweeps & 1]) != hipSuccess) {
                 st = qil_fail(QIL_EHIP, "hipEventSynchronize failed in the Jacobi sweeps");
                 break;
             }
