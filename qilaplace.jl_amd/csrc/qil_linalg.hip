@@ -2490,10 +2490,13 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
 //   2. G = P^H P (W x W) on the matrix cores: 16 x 16 tiles, the K range (the rows) split over the 8 waves, partial tiles
 //      summed in a fixed order (deterministic);
 //   3. a sweep of TWO-SIDED rotations on G in LDS -- the BB cross pairs per inner round (AP: all pairs of the 2 BB columns,
-//      2 BB - 1 inner rounds: the first outer round of a sweep, which also covers the pairs inside a block) -- with one
-//      thread per 2 x 2 block (k1, k2) of G: it takes the rotations of pairs k1 and k2 from the current diagonal 2 x 2 blocks
-//      itself (no dot products, no reductions, no exchange of rotation parameters) and writes R1^H B R2 into the other
-//      buffer of G: ONE barrier per inner round; the other four waves accumulate J <- J R;
+//      2 BB - 1 inner rounds: the first outer round of a sweep, which also covers the pairs inside a block): threads
+//      0 .. BB - 1 derive the rotations from the current diagonal 2 x 2 blocks (no dot products, no reductions), one thread
+//      per 2 x 2 block (k1, k2) of G then applies R1^H B R2 in place and the other four waves accumulate J <- J R; two
+//      barriers per inner round.  Measured (tools/micro/gram_round_cost.hip, 256 columns f64): ~1 300 cycles per inner
+//      round whether every block thread derives its two rotations itself (one barrier, double-buffered G) or they are
+//      derived once and shared (two barriers) -- the round is a latency chain (LDS read, rotation, LDS write, barrier, LDS
+//      reads, update, barrier), not an issue or bandwidth limit;
 //   4. P <- P J on the matrix cores (issued as (J^T tile)(P^T tile) so that every 16 lanes store 128 / 256 contiguous bytes),
 //      straight to global memory.
 // Convergence flags come from the FRESH Gram matrix (relative to the columns' own norms): flag[0] = some pair above tol,
@@ -2517,7 +2520,7 @@ constexpr size_t gram_round_lds(int m) {
     constexpr int W = 2 * BB, LDG = W + 1, NC = sizeof(T) == 16 ? 2 : 1;
     const int mpad = (m + 15) & ~15;
     return (size_t)W * (mpad + 2) * sizeof(T)             // the column pair
-           + (size_t)2 * NC * W * LDG * sizeof(double)    // G, two buffers, re / im planes
+           + (size_t)NC * W * LDG * sizeof(double)        // G, re / im planes
            + (size_t)NC * W * W * sizeof(double)          // J
            + (size_t)8 * NC * 256 * sizeof(double)        // partial Gram tiles of the 8 waves
            + 64;
@@ -2537,8 +2540,8 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
     const int mpad = (m + 15) & ~15, LDR = mpad + 2;
     extern __shared__ __attribute__((aligned(16))) char gr_smem[];
     T* Xs = reinterpret_cast<T*>(gr_smem);                           // [W][LDR]
-    double* Gb = reinterpret_cast<double*>(Xs + (size_t)W * LDR);    // [2][NC][W * LDG]
-    double* Jm = Gb + 2 * NC * W * LDG;                              // [NC][W * W], J[c][j] at c * W + j
+    double* Gb = reinterpret_cast<double*>(Xs + (size_t)W * LDR);    // [NC][W * LDG]
+    double* Jm = Gb + NC * W * LDG;                                  // [NC][W * W], J[c][j] at c * W + j
     double* Pp = Jm + NC * W * W;                                    // [8][NC][256]
     int* sflag = reinterpret_cast<int*>(Pp + 8 * NC * 256);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2730,31 +2733,39 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
             si = 0.0;
         }
     };
+    // Every pair's rotation is derived ONCE (threads 0 .. BB - 1, from the current diagonal 2 x 2 blocks) and handed to the
+    // block / J threads through LDS: two barriers per inner round.
+    double* rotc = Pp;                                               // the partial-tile area is free again: c, sr, si per pair
+    double* rotr = Pp + BB;
+    double* roti = Pp + 2 * BB;
+    int* rotp = reinterpret_cast<int*>(Pp + 3 * BB);                 // and its two columns
+    int* rotq = rotp + BB;
     const bool gthr = tid < BB * BB;
     const int k1 = tid % BB, k2 = (tid / BB) % BB;                   // block (k1, k2) of G
     const bool jthr = tid >= 256 && tid < 256 + BB * (W / 2);
     const int jk = (tid - 256) % BB, ji = ((tid - 256) / BB) * 2;    // pair jk, rows ji, ji + 1 of J
-    int cur = 0;
+    double* G = Gb;                                                  // updated in place: every entry belongs to one block thread
     for (int t = 0; t < nin; ++t) {
-        const double* G = Gb + (size_t)cur * NC * W * LDG;
-        double* Gn = Gb + (size_t)(cur ^ 1) * NC * W * LDG;
+        if (tid < BB) {
+            int p, q;
+            pair_of(tid, t, p, q);
+            double c, sr, si;
+            rot_of(G, p, q, c, sr, si);
+            rotc[tid] = c;
+            rotr[tid] = sr;
+            if constexpr (CX) roti[tid] = si;
+            rotp[tid] = p;
+            rotq[tid] = q;
+        }
+        __syncthreads();
         if (gthr) {
-            int p1, q1, p2, q2;
-            pair_of(k1, t, p1, q1);
-            pair_of(k2, t, p2, q2);
-            double c1, s1r, s1i, c2, s2r, s2i;
-            rot_of(G, p1, q1, c1, s1r, s1i);
-            if (k1 == k2) {
-                c2 = c1;
-                s2r = s1r;
-                s2i = s1i;
-            } else {
-                rot_of(G, p2, q2, c2, s2r, s2i);
-            }
+            const int p1 = rotp[k1], q1 = rotq[k1], p2 = rotp[k2], q2 = rotq[k2];
+            const double c1 = rotc[k1], s1r = rotr[k1], c2 = rotc[k2], s2r = rotr[k2];
+            const double s1i = CX ? roti[k1] : 0.0, s2i = CX ? roti[k2] : 0.0;
             // B = [[G p1p2, G p1q2], [G q1p2, G q1q2]]
             const double b00r = G[p1 * LDG + p2], b01r = G[p1 * LDG + q2], b10r = G[q1 * LDG + p2], b11r = G[q1 * LDG + q2];
             if constexpr (CX) {
-                const double* Gi = G + W * LDG;
+                double* Gi = G + W * LDG;
                 const double b00i = Gi[p1 * LDG + p2], b01i = Gi[p1 * LDG + q2], b10i = Gi[q1 * LDG + p2], b11i = Gi[q1 * LDG + q2];
                 // columns: M = B R2:  M[:,0] = c2 B[:,0] - conj(s2) B[:,1];  M[:,1] = s2 B[:,0] + c2 B[:,1]
                 const double m00r = c2 * b00r - (s2r * b01r + s2i * b01i), m00i = c2 * b00i - (s2r * b01i - s2i * b01r);
@@ -2762,28 +2773,25 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
                 const double m01r = (s2r * b00r - s2i * b00i) + c2 * b01r, m01i = (s2r * b00i + s2i * b00r) + c2 * b01i;
                 const double m11r = (s2r * b10r - s2i * b10i) + c2 * b11r, m11i = (s2r * b10i + s2i * b10r) + c2 * b11i;
                 // rows: R1^H M:  row0 = c1 M0 - s1 M1;  row1 = conj(s1) M0 + c1 M1
-                double* Gni = Gn + W * LDG;
-                Gn[p1 * LDG + p2] = c1 * m00r - (s1r * m10r - s1i * m10i);
-                Gni[p1 * LDG + p2] = c1 * m00i - (s1r * m10i + s1i * m10r);
-                Gn[p1 * LDG + q2] = c1 * m01r - (s1r * m11r - s1i * m11i);
-                Gni[p1 * LDG + q2] = c1 * m01i - (s1r * m11i + s1i * m11r);
-                Gn[q1 * LDG + p2] = (s1r * m00r + s1i * m00i) + c1 * m10r;
-                Gni[q1 * LDG + p2] = (s1r * m00i - s1i * m00r) + c1 * m10i;
-                Gn[q1 * LDG + q2] = (s1r * m01r + s1i * m01i) + c1 * m11r;
-                Gni[q1 * LDG + q2] = (s1r * m01i - s1i * m01r) + c1 * m11i;
+                G[p1 * LDG + p2] = c1 * m00r - (s1r * m10r - s1i * m10i);
+                Gi[p1 * LDG + p2] = c1 * m00i - (s1r * m10i + s1i * m10r);
+                G[p1 * LDG + q2] = c1 * m01r - (s1r * m11r - s1i * m11i);
+                Gi[p1 * LDG + q2] = c1 * m01i - (s1r * m11i + s1i * m11r);
+                G[q1 * LDG + p2] = (s1r * m00r + s1i * m00i) + c1 * m10r;
+                Gi[q1 * LDG + p2] = (s1r * m00i - s1i * m00r) + c1 * m10i;
+                G[q1 * LDG + q2] = (s1r * m01r + s1i * m01i) + c1 * m11r;
+                Gi[q1 * LDG + q2] = (s1r * m01i - s1i * m01r) + c1 * m11i;
             } else {
                 const double m00 = fma(c2, b00r, -s2r * b01r), m01 = fma(s2r, b00r, c2 * b01r);
                 const double m10 = fma(c2, b10r, -s2r * b11r), m11 = fma(s2r, b10r, c2 * b11r);
-                Gn[p1 * LDG + p2] = fma(c1, m00, -s1r * m10);
-                Gn[p1 * LDG + q2] = fma(c1, m01, -s1r * m11);
-                Gn[q1 * LDG + p2] = fma(s1r, m00, c1 * m10);
-                Gn[q1 * LDG + q2] = fma(s1r, m01, c1 * m11);
+                G[p1 * LDG + p2] = fma(c1, m00, -s1r * m10);
+                G[p1 * LDG + q2] = fma(c1, m01, -s1r * m11);
+                G[q1 * LDG + p2] = fma(s1r, m00, c1 * m10);
+                G[q1 * LDG + q2] = fma(s1r, m01, c1 * m11);
             }
         } else if (jthr) {
-            int p, q;
-            pair_of(jk, t, p, q);
-            double c, sr, si;
-            rot_of(G, p, q, c, sr, si);
+            const int p = rotp[jk], q = rotq[jk];
+            const double c = rotc[jk], sr = rotr[jk], si = CX ? roti[jk] : 0.0;
             if (sr != 0.0 || si != 0.0) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -2805,7 +2813,6 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
             }
         }
         __syncthreads();
-        cur ^= 1;
     }
     if (a.prof) st[4] = __builtin_amdgcn_s_memtime();
     // ---- 4. X <- X J (as (J^T)(X^T): D[j][r]), wave -> row tiles
