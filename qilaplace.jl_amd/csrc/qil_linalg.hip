@@ -1824,6 +1824,9 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
         if (!(worst > 1e-11) || pass == 2) break;
         QIL_TRY(qr_impl<T>(ctx, m, n, Q, ldq, static_cast<T*>(gbuf), n));                  // Q <- Q2, gbuf = R2
         if (R) {
+            if (ctx->rinv) qil_ctx_free(ctx, ctx->rinv);         // R changes: an inverse kept for the certificate is stale
+            ctx->rinv = nullptr;
+            ctx->rinv_for = nullptr;
             void* rnew = nullptr;
             QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * sizeof(T), &rnew));
             QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, n, n, n, static_cast<const T*>(gbuf), n, (const T*)R, ldr,
@@ -2189,6 +2192,13 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     }
     QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, n, n, Q1, m, X2, n, A, lda));
     if (R) QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, n, n, n, R2, n, R1, n, R, ldr));
+    if (R && ctx->want_rinv) {                                   // R^-1 = R1^-1 R2^-1 for the certificate that follows
+        if (ctx->rinv) qil_ctx_free(ctx, ctx->rinv);
+        ctx->rinv = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, nn, &ctx->rinv));
+        QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, n, n, n, X1, n, X2, n, static_cast<T*>(ctx->rinv), n));
+        ctx->rinv_for = R;
+    }
     release();
     *done = true;
     return QIL_OK;
@@ -2198,6 +2208,14 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
 template <class T>
 int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, double cutoff, bool* certified) {
     *certified = false;
+    struct drop_rinv {                                           // whatever happens, no inverse outlives this call
+        qil_context* c;
+        ~drop_rinv() {
+            if (c->rinv) qil_ctx_free(c, c->rinv);
+            c->rinv = nullptr;
+            c->rinv_for = nullptr;
+        }
+    } guard{ctx};
     const bool enabled = !(getenv("QIL_SVD_CERT") && atoi(getenv("QIL_SVD_CERT")) == 0);   // tuning aid (read per call: the tests toggle it)
     if (!enabled || !(cutoff > 0.0) || k < 2) return QIL_OK;
     void *st = nullptr, *xinv = nullptr;
@@ -2224,8 +2242,14 @@ int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, do
         qil_ctx_free(ctx, st);
         return QIL_OK;
     }
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * k * sizeof(T), &xinv));
-    QIL_TRY(trtri_upper<T>(ctx, R, ldr, k, static_cast<T*>(xinv)));
+    if (ctx->rinv && ctx->rinv_for == R) {                       // CholeskyQR2 left R^-1 behind (packed, ld k)
+        xinv = ctx->rinv;
+        ctx->rinv = nullptr;
+        ctx->rinv_for = nullptr;
+    } else {
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * k * sizeof(T), &xinv));
+        QIL_TRY(trtri_upper<T>(ctx, R, ldr, k, static_cast<T*>(xinv)));
+    }
     QIL_TRY(stats(static_cast<const T*>(xinv), (long long)k));
     qil_ctx_free(ctx, xinv);
     qil_ctx_free(ctx, st);
@@ -2939,6 +2963,9 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     auto release = [&]() {
         for (void* b : {rbuf, xbuf, bh, flag, nrm, negl, wbuf})
             if (b) qil_ctx_free(ctx, b);
+        if (ctx->rinv) qil_ctx_free(ctx, ctx->rinv);             // (an inverse CholeskyQR2 left for a certificate that did not run)
+        ctx->rinv = nullptr;
+        ctx->rinv_for = nullptr;
     };
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * k) * sizeof(T), &rbuf));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * k) * sizeof(T), &xbuf));
@@ -2947,7 +2974,10 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     T* Qm = nullptr;
     long long ldq = 0, qrows = 0;
     if (tall) {
-        QIL_TRY(qr_impl<T>(ctx, p, q, B, ldb, R, k));
+        ctx->want_rinv = cert_cutoff > 0.0;
+        const int qst = qr_impl<T>(ctx, p, q, B, ldb, R, k);
+        ctx->want_rinv = false;
+        QIL_TRY(qst);
         bool ok = true;
         QIL_TRY(qr_reorthogonalise<T>(ctx, p, q, B, ldb, R, k, dbg, &ok));
         if (!ok) {                                   // B = Q R reproduces the operand: hand it back intact
@@ -3940,11 +3970,19 @@ static int qr_certified_t(qil_context* ctx, long long m, long long n, const T* A
         QIL_TRY(qil_dev_copy2d(ctx, Qout, (size_t)rows * sizeof(T), A, (size_t)lda * sizeof(T), (size_t)m * sizeof(T), (size_t)n));
     else
         QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3((unsigned)std::min<long long>((m * n + 255) / 256, 65536)), dim3(256), 0, A, lda, m, n, Qout, rows)));
-    QIL_TRY(qr_impl<T>(ctx, rows, k, Qout, rows, Rout, k));
+    ctx->want_rinv = cutoff > 0.0;
+    const int qst = qr_impl<T>(ctx, rows, k, Qout, rows, Rout, k);
+    ctx->want_rinv = false;
+    QIL_TRY(qst);
     bool ok = true;
     QIL_TRY(qr_reorthogonalise<T>(ctx, rows, k, Qout, rows, Rout, k, false, &ok));
     *certified = false;
-    if (!ok) return QIL_OK;
+    if (!ok) {
+        if (ctx->rinv) qil_ctx_free(ctx, ctx->rinv);
+        ctx->rinv = nullptr;
+        ctx->rinv_for = nullptr;
+        return QIL_OK;
+    }
     return certify_no_truncation<T>(ctx, Rout, k, (int)k, cutoff, certified);
 }
 int qil_dev_set_identity(qil_context* ctx, int dtype, void* V, int64_t ldv, int64_t n) {
