@@ -1997,16 +1997,16 @@ int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
 // 180 us at n = 128 against ~25 here).  Then R = D^-1/2 S (its rows are final when they are published) and
 // R^-1 = E^H D^-1/2.  A pivot that is not above piv_rel times its original diagonal entry raises *flag (the caller then takes
 // the Householder route; everything written is discarded).
-template <class T, int TS>
+template <class T, int TS, int TG>
 __device__ __forceinline__ void chol_inv_block_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ G, long long ldg, int nb, T* __restrict__ Rout,
                                                        long long ldr, T* __restrict__ Xout, long long ldx, double piv_rel,
                                                        int* __restrict__ flag) {
-    constexpr int NBK = 32 * TS;
+    constexpr int NBK = TG * TS;
     __shared__ __attribute__((aligned(16))) T srow[2][NBK];
     __shared__ __attribute__((aligned(16))) T erow[2][NBK];
     __shared__ double dg[NBK], d0[NBK];
     __shared__ int s_bad;
-    const int tid = threadIdx.x, tc = tid & 31, tr = tid >> 5;
+    const int tid = threadIdx.x, tc = tid % TG, tr = tid / TG;
     T w[TS][TS], e2[TS][TS];          // w: S tile (tc >= tr) or E tile (tc < tr); e2: E tile of the diagonal threads
     auto one = []() {
         T v{};
@@ -2116,27 +2116,27 @@ __device__ __forceinline__ void chol_inv_block_body(const uint3 blockIdx, const 
             if (tc == tr && k <= i) Xout[k + ldx * i] = scale_t(conj_t(e2[a][b]), rs);
         }
 }
-template <class T, int TS>
+template <class T, int TS, int TG>
 struct chol_inv_block_k {
-    static constexpr int NT = 1024, MINW = 1;
+    static constexpr int NT = TG * TG, MINW = 1;
     template <class... QA>
     static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
-        chol_inv_block_body<T, TS>(b, g, a...);
+        chol_inv_block_body<T, TS, TG>(b, g, a...);
     }
 };
 
 // G (n x n, ld n, Hermitian positive definite; DESTROYED) = R^H R;  Rm (upper triangular, ld n) and Xm = R^-1 (ld n), both
 // zero below the diagonal; *flag (device) is raised on a bad pivot.  Diagonal blocks of 32 TS columns in one workgroup each,
 // the rest by MFMA GEMMs.
-template <class T, int TS>
+template <class T, int TS, int TG>
 int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
-    constexpr int NBK = 32 * TS;
+    constexpr int NBK = TG * TS;
     QIL_TRY(qil_dev_zero(ctx, Rm, (size_t)n * n * sizeof(T)));
     QIL_TRY(qil_dev_zero(ctx, Xm, (size_t)n * n * sizeof(T)));
     const int opH = sizeof(T) == 16 ? 2 : 1;
     for (int j0 = 0; j0 < n; j0 += NBK) {
         const int nbj = std::min(NBK, n - j0), rest = n - j0 - nbj;
-        QIL_TRY((qil_klaunch<chol_inv_block_k<T, TS>>(ctx, dim3(1), dim3(1024), 0, (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
+        QIL_TRY((qil_klaunch<chol_inv_block_k<T, TS, TG>>(ctx, dim3(1), dim3(TG * TG), 0, (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
         QIL_HIP(hipGetLastError());
         if (rest > 0) {
             T* Rjr = Rm + j0 + (long long)n * (j0 + nbj);
@@ -2153,7 +2153,8 @@ int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
 // 166.8, TS 1: 179.1, Householder panels: 197.8), c64 212.6 ms (214.0 / 229.2 / 341.6); chi 256 -> 128: 68.2 / 69.5 / 73.2 / 70.7
 template <class T>
 int chol_inv(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
-    return chol_inv_ts<T, 2>(ctx, G, n, Rm, Xm, flag);
+    // (4 x 4 tiles on 16 x 16 threads, same 64 columns: chi 256 69.8 against 66.8 ms; 2 x 2 tiles on 16 x 16 threads, 32 columns: 74.1)
+    return chol_inv_ts<T, 2, 32>(ctx, G, n, Rm, Xm, flag);
 }
 
 // A (m x n, m >= n) -> Q in place, R (n x n, ldr; may be null) with positive diagonal.  *done = false: the operand is not
