@@ -207,20 +207,24 @@ int qil_mpo_compress(qil_mpo* W, int direction, double cutoff, int64_t maxdim);
 /* Batches of independent chains (the serial loops over signals / damping values of
  * scripts/benchmark/zt_full_runtime.jl:151-221 and docs/src/tutorials/zt.jl:300-348 call compress! /
  * zip_to_compress_mpo once per item).  Item j receives exactly qil_compress(items[j], ...) resp.
- * qil_mpo_compress(items[j], ...), in place; the nb chains run concurrently on worker streams of their common
- * context (each is a latency chain of small factorisations that fills a few percent of the chip), and the call
+ * qil_mpo_compress(items[j], ...), in place; the nb chains run concurrently (each is a latency chain of small
+ * factorisations that fills a few percent of the chip): up to 4 on streams of their own, larger batches as four lock-step
+ * groups whose chains share ONE table launch per step; bit-identical to the item-by-item calls; the call
  * returns when all are done.  All items must live in one context and be distinct handles (QIL_EINVAL_ARG);
  * the first failing item's status is returned, the other items are still processed.                        */
 int qil_compress_batch(qil_mps* const* items, int64_t nb, int64_t maxdim, double tol, int sweeps);
 int qil_mpo_compress_batch(qil_mpo* const* items, int64_t nb, int direction, double cutoff, int64_t maxdim);
 
-/* Fused apply-and-truncate: the result of compress!(apply(W, psi); maxdim, tol, sweeps)
- * (apply.jl:75-122 followed by mps.jl:913-973) without materialising the (D chi)^2 product: a zip-up sweep
- * with intermediate bond cap zip_maxdim (<= 0: max(1.5 maxdim, maxdim + 16)) followed by the exact-gauge compress!.  Same error
- * codes as qil_apply / qil_compress.  Not a reference entry point (the reference's apply ignores its
- * cutoff/maxdim kwargs); qil_apply keeps that behaviour.  Accuracy: as for every zip-up, the intermediate
- * truncations are near-optimal for decaying spectra (transform MPOs on encoded signals) and can lose more
- * than the exact route on flat-spectrum operands; qil_apply + qil_compress is the exact route.            */
+/* Fused apply-and-truncate: compress!(apply(W, psi); maxdim, tol, sweeps) (apply.jl:75-122 followed by
+ * mps.jl:913-973) without materialising the (D chi)^2 product: psi is brought to right-canonical gauge by exact QRs, a zip-up
+ * sweep with intermediate bond cap zip_maxdim (<= 0: max(1.5 maxdim, maxdim + 16)) builds a basis per bond (sketched on capped
+ * bonds), ONE variational sweep replaces every site by the best tensor given the others, then the exact-gauge compress!
+ * runs.  Same error codes as qil_apply / qil_compress.  Not a reference entry point (the reference's apply ignores its
+ * cutoff / maxdim kwargs); qil_apply keeps that behaviour.  Accuracy against qil_apply + qil_compress (the exact route):
+ * identical bond dimensions and a state error <= 2x the truncation's own on random flat-spectrum products; on transform
+ * pipelines identical bonds at tol >= 1e-4 and, below that, bonds that are never larger with a SMALLER error than the exact
+ * route, whose gauge passes carry canonicalize!'s fixed cutoff 1e-12 (tests/test_gpu_parity.py,
+ * test_apply_compress_*_against_oracle).                                                                          */
 int qil_apply_compress(const qil_mpo* W, const qil_mps* psi, int64_t maxdim, double tol, int sweeps,
                        int64_t zip_maxdim, qil_mps** out);
 /* The same for nb independent (operator, state) pairs of one context -- the (signal, damping value) items of a sweep;
