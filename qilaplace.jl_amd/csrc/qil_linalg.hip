@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <utility>
 
 #include "qil_internal.h"
 #include "qil_launch.h"
@@ -2125,6 +2126,304 @@ struct chol_inv_block_k {
     }
 };
 
+// chol_inv_block16: the same 64-column diagonal block (R and R^-1 of a Hermitian positive definite block) with the column
+// chain cut to 16 columns at a time.  The register-tiled elimination above pays one workgroup barrier and an LDS round trip
+// per COLUMN (64 x ~1300 cycles = 35 us per block, the largest single item of a CholeskyQR2 gauge step); here the block
+// lives in LDS as a full Hermitian 64 x 64 array and is factored by 16-column sub-blocks:
+//   D(b)  ONE wave eliminates the 16 x 16 diagonal sub-block of [S | I] in registers (lane (i, g) = four columns of row i):
+//         a step is one reciprocal, the multipliers and the pivot row passed lane to lane (chol16_step) and 8 FMAs -- no
+//         barrier, no LDS; R_bb = D^-1/2 U and X_bb = R_bb^-1 = E^H D^-1/2 go back to LDS;
+//   P(b)  R(b, c) = X_bb^H S(b, c), c > b                (one 16 x 16 x 16 matrix-core tile per wave)
+//   T(b)  S(c, d) -= R(b, c)^H R(b, d), b < c <= d       (matrix-core tiles over the four waves)
+// and R^-1's off-diagonal sub-blocks by two levels of [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1] merges on the matrix
+// cores.  12 barriers + 64 short register steps instead of 64 barrier-separated column steps.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+typedef unsigned qil_v2u __attribute__((ext_vector_type(2)));
+// lane J of every 16-lane row to all lanes of that row (DPP row_newbcast: a plain VALU move, no scalar-register round trip)
+template <int J>
+__device__ __forceinline__ double row_bcast_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + J, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + J, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// row GS of the wave (lanes 16 GS .. 16 GS + 15) to all four rows, lane by lane (gfx950 v_permlane32_swap + v_permlane16_swap:
+// swap(v, v) of the first returns [r0 r1 r0 r1] / [r2 r3 r2 r3], of the second [w0 w0 w2 w2] / [w1 w1 w3 w3];
+// tools/micro/permlane_probe.hip prints both)
+template <int GS>
+__device__ __forceinline__ unsigned rowgroup_bcast_u32(unsigned v) {
+    const qil_v2u a = __builtin_amdgcn_permlane32_swap(v, v, true, false);
+    const unsigned w = a[GS >> 1];
+    const qil_v2u b = __builtin_amdgcn_permlane16_swap(w, w, true, false);
+    return b[GS & 1];
+}
+template <int GS>
+__device__ __forceinline__ double rowgroup_bcast_f64(double v) {
+    const unsigned lo = rowgroup_bcast_u32<GS>((unsigned)__double2loint(v)), hi = rowgroup_bcast_u32<GS>((unsigned)__double2hiint(v));
+    return __hiloint2double((int)hi, (int)lo);
+}
+// One column step of the 16 x 16 elimination of [S | I] held by ONE wave: lane (i = lane & 15, g = lane >> 4) keeps columns
+// 4 g .. 4 g + 3 of row i of S and of E.  Pivot d_J through a scalar register, the multipliers m_i = S(i, J) / d_J from row
+// group J / 4 to all four, the pivot row within each row group by DPP; 8 FMAs per lane (complex: 32).
+template <bool CX, int J, int B>
+__device__ __forceinline__ void chol16_elem(double (&sr)[4], double (&si)[4], double (&er)[4], double (&ei)[4], double mr, double mi) {
+    if constexpr (12 + B > J) {                                      // some row group still has column 4 g + B > J
+        const double pr = row_bcast_f64<J>(sr[B]);
+        if constexpr (CX) {
+            const double pi = row_bcast_f64<J>(si[B]);
+            sr[B] = fma(mi, pi, fma(-mr, pr, sr[B]));
+            si[B] = fma(-mi, pr, fma(-mr, pi, si[B]));
+        } else {
+            sr[B] = fma(-mr, pr, sr[B]);
+        }
+    }
+    if constexpr (B <= J) {                                          // E(J, k) = 0 beyond k = J
+        const double pr = row_bcast_f64<J>(er[B]);
+        if constexpr (CX) {
+            const double pi = row_bcast_f64<J>(ei[B]);
+            er[B] = fma(mi, pi, fma(-mr, pr, er[B]));
+            ei[B] = fma(-mi, pr, fma(-mr, pi, ei[B]));
+        } else {
+            er[B] = fma(-mr, pr, er[B]);
+        }
+    }
+}
+template <bool CX, int J>
+__device__ __forceinline__ void chol16_step(double (&sr)[4], double (&si)[4], double (&er)[4], double (&ei)[4], int li, double d0l,
+                                            double piv_rel, double& dgl, double& worst) {
+    constexpr int GJ = J >> 2, BJ = J & 3;
+    asm volatile("" : "+v"(li));                                     // (keeps the 32 lane masks of the 16 steps from being hoisted: scalar-register spills)
+    const double d = readlane_f64(sr[BJ], J + 16 * GJ);
+    const double margin = fma(-piv_rel, readlane_f64(d0l, J), d);   // the pivot must stay above piv_rel times its original diagonal entry
+    worst = fmin(worst, margin);
+    const bool dead = !(margin > 0.0);
+    const double inv = dead ? 0.0 : rcp_refined(d);
+    const double mcr = rowgroup_bcast_f64<GJ>(sr[BJ]);
+    double mci = 0.0;
+    if constexpr (CX) mci = rowgroup_bcast_f64<GJ>(si[BJ]);
+    const double sel = li > J ? inv : 0.0;
+    if (li == J) dgl = dead ? 1.0 : d;
+    const double mr = mcr * sel, mi = mci * sel;
+    chol16_elem<CX, J, 0>(sr, si, er, ei, mr, mi);
+    chol16_elem<CX, J, 1>(sr, si, er, ei, mr, mi);
+    chol16_elem<CX, J, 2>(sr, si, er, ei, mr, mi);
+    chol16_elem<CX, J, 3>(sr, si, er, ei, mr, mi);
+}
+template <bool CX, int... J>
+__device__ __forceinline__ void chol16_steps(double (&sr)[4], double (&si)[4], double (&er)[4], double (&ei)[4], int li, double d0l,
+                                             double piv_rel, double& dgl, double& worst, std::integer_sequence<int, J...>) {
+    (chol16_step<CX, J>(sr, si, er, ei, li, d0l, piv_rel, dgl, worst), ...);
+}
+template <class T>
+constexpr size_t chol16_lds() {
+    return (size_t)(sizeof(T) / 8) * (2 * 64 * 65 + 32 * 33) * sizeof(double);
+}
+template <class T>
+__device__ __forceinline__ void chol_inv_block16_body(const uint3, const uint3, const T* __restrict__ G, long long ldg, int nb,
+                                                      T* __restrict__ Rout, long long ldr, T* __restrict__ Xout, long long ldx,
+                                                      double piv_rel, int* __restrict__ flag) {
+    constexpr bool CX = sizeof(T) == 16;
+    constexpr int NP = CX ? 2 : 1;
+    constexpr int N = 64, LD = 65, PL = N * LD, LT = 33, PT = 32 * LT;
+    extern __shared__ __attribute__((aligned(16))) char c16_smem[];
+    double* S = reinterpret_cast<double*>(c16_smem);                 // [NP][PL]: S, then R in its upper sub-blocks
+    double* Si = S + (CX ? PL : 0);
+    double* X = S + NP * PL;                                         // [NP][PL]: R^-1
+    double* Xi = X + (CX ? PL : 0);
+    double* Tm = X + NP * PL;                                        // [NP][PT]: the merges' B C^-1
+    double* Ti = Tm + (CX ? PT : 0);
+    __shared__ double d0[N];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nb16 = (nb + 15) >> 4;
+    if (tid == 0) s_bad = 0;
+    // ---- the block as a full Hermitian array (rows / columns beyond nb: identity), X = 0
+    for (int t = tid; t < N * N; t += 256) {
+        const int i = t & 63, k = t >> 6;
+        X[i * LD + k] = 0.0;
+        if constexpr (CX) Xi[i * LD + k] = 0.0;
+        if (i > k) continue;
+        double vr = (i == k) ? 1.0 : 0.0, vi = 0.0;
+        if (k < nb) {
+            const double* g = reinterpret_cast<const double*>(G + i + ldg * k);
+            vr = g[0];
+            if (CX && i != k) vi = g[1];
+        }
+        S[i * LD + k] = vr;
+        S[k * LD + i] = vr;
+        if constexpr (CX) {
+            Si[i * LD + k] = vi;
+            Si[k * LD + i] = -vi;
+        }
+        if (i == k) d0[i] = vr;
+    }
+    __syncthreads();
+    for (int b = 0; b < nb16; ++b) {
+        const int r0 = 16 * b;
+        // ---- D(b)
+        if (wave == 0) {
+            double sr[4], si[4], er[4], ei[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * lk + q;
+                sr[q] = S[(r0 + li) * LD + r0 + k];
+                si[q] = CX ? Si[(r0 + li) * LD + r0 + k] : 0.0;
+                er[q] = (k == li) ? 1.0 : 0.0;
+                ei[q] = 0.0;
+            }
+            const double d0l = d0[r0 + li];
+            double dgl = 1.0;
+            double worst = 1.0;
+            chol16_steps<CX>(sr, si, er, ei, li, d0l, piv_rel, dgl, worst, std::make_integer_sequence<int, 16>{});
+            if (!(worst > 0.0) && lane == 0) s_bad = 1;
+            const double rs = rsqrt(dgl), sq = sqrt(dgl);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // R(i, k) = U(i, k) / sqrt(d_i) (k > i), sqrt(d_i) on the diagonal;  X(k, i) = conj(E(i, k)) / sqrt(d_i) (k <= i)
+                const int k = 4 * lk + q;
+                S[(r0 + li) * LD + r0 + k] = k > li ? sr[q] * rs : (k == li ? sq : 0.0);
+                if constexpr (CX) Si[(r0 + li) * LD + r0 + k] = k > li ? si[q] * rs : 0.0;
+                X[(r0 + k) * LD + r0 + li] = k <= li ? er[q] * rs : 0.0;
+                if constexpr (CX) Xi[(r0 + k) * LD + r0 + li] = k <= li ? -ei[q] * rs : 0.0;
+            }
+        }
+        __syncthreads();
+        if (b + 1 >= nb16) break;
+        // ---- P(b): R(b, c) = X_bb^H S(b, c); wave -> c = b + 1 + wave.  out(p, q): first operand [p = li][k = lk], second [k = lk][q = li]
+        {
+            const int c = b + 1 + wave;
+            if (c < nb16) {
+                d4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int t = r0 + 4 * ks + lk;
+                    const double ar = X[t * LD + r0 + li], br = S[t * LD + 16 * c + li];
+                    rr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, rr, 0, 0, 0);
+                    if constexpr (CX) {
+                        // conj(x) s = (xr sr + xi si) + i (xr si - xi sr)
+                        const double ai = Xi[t * LD + r0 + li], bi = Si[t * LD + 16 * c + li];
+                        rr = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, rr, 0, 0, 0);
+                        ri = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ri, 0, 0, 0);
+                        ii = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ii, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    S[(r0 + lk + 4 * r) * LD + 16 * c + li] = rr[r];
+                    if constexpr (CX) Si[(r0 + lk + 4 * r) * LD + 16 * c + li] = ri[r] - ii[r];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- T(b): S(c, d) -= R(b, c)^H R(b, d), b < c <= d
+        {
+            int idx = 0;
+            for (int c = b + 1; c < nb16; ++c)
+                for (int d = c; d < nb16; ++d, ++idx) {
+                    if ((idx & 3) != wave) continue;
+                    d4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int t = r0 + 4 * ks + lk;
+                        const double ar = S[t * LD + 16 * c + li], br = S[t * LD + 16 * d + li];
+                        rr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, rr, 0, 0, 0);
+                        if constexpr (CX) {
+                            const double ai = Si[t * LD + 16 * c + li], bi = Si[t * LD + 16 * d + li];
+                            rr = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, rr, 0, 0, 0);
+                            ri = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ri, 0, 0, 0);
+                            ii = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ii, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        S[(16 * c + lk + 4 * r) * LD + 16 * d + li] -= rr[r];
+                        if constexpr (CX) Si[(16 * c + lk + 4 * r) * LD + 16 * d + li] -= ri[r] - ii[r];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    // ---- R^-1: merges of neighbouring sub-blocks, then of the two halves.  X(A, C) = -X(A, A) [R(A, C) X(C, C)]
+    for (int lvl = 0; lvl < 2; ++lvl) {
+        const int sz = lvl == 0 ? 16 : 32;
+        const int nmerge = lvl == 0 ? 2 : 1;
+        // this wave's tile: level 0: merge = wave (one tile); level 1: tile (wave >> 1, wave & 1) of the one merge
+        const int mg = lvl == 0 ? wave : 0, ti = lvl == 0 ? 0 : (wave >> 1), tj = lvl == 0 ? 0 : (wave & 1);
+        const int a0 = 2 * sz * mg, c0 = a0 + sz;
+        const bool act = mg < nmerge && c0 + 16 * tj < 16 * nb16;
+        if (16 * nb16 <= sz) break;
+        if (act) {
+            d4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0};
+            for (int ks = 0; ks < sz / 4; ++ks) {
+                const int t = c0 + 4 * ks + lk;
+                const double ar = S[(a0 + 16 * ti + li) * LD + t], br = X[t * LD + c0 + 16 * tj + li];
+                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, rr, 0, 0, 0);
+                if constexpr (CX) {
+                    const double ai = Si[(a0 + 16 * ti + li) * LD + t], bi = Xi[t * LD + c0 + 16 * tj + li];
+                    ii = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, ii, 0, 0, 0);
+                    ri = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ri, 0, 0, 0);
+                    ri = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ri, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Tm[(16 * (lvl == 0 ? mg : ti) + lk + 4 * r) * LT + 16 * tj + li] = CX ? rr[r] - ii[r] : rr[r];
+                if constexpr (CX) Ti[(16 * (lvl == 0 ? mg : ti) + lk + 4 * r) * LT + 16 * tj + li] = ri[r];
+            }
+        }
+        __syncthreads();
+        if (act) {
+            d4 rr = {0, 0, 0, 0}, ii = {0, 0, 0, 0}, ri = {0, 0, 0, 0};
+            for (int ks = 0; ks < sz / 4; ++ks) {
+                const int t = 4 * ks + lk;
+                const double ar = X[(a0 + 16 * ti + li) * LD + a0 + t];
+                const double br = Tm[(16 * (lvl == 0 ? mg : 0) + t) * LT + 16 * tj + li];
+                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, rr, 0, 0, 0);
+                if constexpr (CX) {
+                    const double ai = Xi[(a0 + 16 * ti + li) * LD + a0 + t];
+                    const double bi = Ti[(16 * (lvl == 0 ? mg : 0) + t) * LT + 16 * tj + li];
+                    ii = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, ii, 0, 0, 0);
+                    ri = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ri, 0, 0, 0);
+                    ri = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ri, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                X[(a0 + 16 * ti + lk + 4 * r) * LD + c0 + 16 * tj + li] = CX ? ii[r] - rr[r] : -rr[r];
+                if constexpr (CX) Xi[(a0 + 16 * ti + lk + 4 * r) * LD + c0 + 16 * tj + li] = -ri[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && s_bad) atomicOr(flag, 1);
+    for (int t = tid; t < N * N; t += 256) {
+        const int i = t & 63, k = t >> 6;
+        if (i >= nb || k >= nb) continue;
+        T rv{}, xv{};
+        if (i <= k) {
+            reinterpret_cast<double*>(&rv)[0] = S[i * LD + k];
+            reinterpret_cast<double*>(&xv)[0] = X[i * LD + k];
+            if constexpr (CX) {
+                reinterpret_cast<double*>(&rv)[1] = Si[i * LD + k];
+                reinterpret_cast<double*>(&xv)[1] = Xi[i * LD + k];
+            }
+        }
+        Rout[i + ldr * k] = rv;
+        Xout[i + ldx * k] = xv;
+    }
+}
+template <class T>
+struct chol_inv_block16_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        chol_inv_block16_body<T>(b, g, a...);
+    }
+};
+
 // G (n x n, ld n, Hermitian positive definite; DESTROYED) = R^H R;  Rm (upper triangular, ld n) and Xm = R^-1 (ld n), both
 // zero below the diagonal; *flag (device) is raised on a bad pivot.  Diagonal blocks of 32 TS columns in one workgroup each,
 // the rest by MFMA GEMMs.
@@ -2136,7 +2435,11 @@ int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
     const int opH = sizeof(T) == 16 ? 2 : 1;
     for (int j0 = 0; j0 < n; j0 += NBK) {
         const int nbj = std::min(NBK, n - j0), rest = n - j0 - nbj;
-        QIL_TRY((qil_klaunch<chol_inv_block_k<T, TS, TG>>(ctx, dim3(1), dim3(TG * TG), 0, (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
+        static const bool sub16 = !(getenv("QIL_CHOL16") && atoi(getenv("QIL_CHOL16")) == 0);
+        if (sub16 && NBK == 64)
+            QIL_TRY((qil_klaunch<chol_inv_block16_k<T>>(ctx, dim3(1), dim3(256), chol16_lds<T>(), (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
+        else
+            QIL_TRY((qil_klaunch<chol_inv_block_k<T, TS, TG>>(ctx, dim3(1), dim3(TG * TG), 0, (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
         QIL_HIP(hipGetLastError());
         if (rest > 0) {
             T* Rjr = Rm + j0 + (long long)n * (j0 + nbj);
@@ -2156,6 +2459,43 @@ int chol_inv(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
     // (4 x 4 tiles on 16 x 16 threads, same 64 columns: chi 256 69.8 against 66.8 ms; 2 x 2 tiles on 16 x 16 threads, 32 columns: 74.1)
     return chol_inv_ts<T, 2, 32>(ctx, G, n, Rm, Xm, flag);
 }
+
+// The second pass of CholeskyQR2 factors G2 = Q1^H Q1 = I + E with |E| ~ kappa(A)^2 eps.  For |E| this small the factor is
+// known to first order without any column chain: R2 = I + U, R2^-1 = I - U with U = striu(E) + diag(E) / 2 (E = U + U^H), the
+// neglected terms are O(|E|^2).  One elementwise launch writes both and raises bit 2 of *flag when some |e_ik| exceeds
+// `thresh` (the caller then factors G2, which is left intact, properly).
+template <class T>
+__device__ __forceinline__ void chol_near_identity_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ G, int n, T* __restrict__ R2, T* __restrict__ X2, double thresh, int* __restrict__ flag) {
+    bool over = false;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < (long long)n * n; t += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(t % n), k = (int)(t / n);
+        T e = G[t], r{}, x{};
+        double* ep = reinterpret_cast<double*>(&e);
+        if (i == k) {
+            ep[0] -= 1.0;
+            if (sizeof(T) == 16) ep[1] = 0.0;
+        }
+        over |= !(abs2_t(e) <= thresh * thresh);
+        if (i < k) {
+            r = e;
+            x = neg_t(e);
+        } else if (i == k) {
+            reinterpret_cast<double*>(&r)[0] = 1.0 + 0.5 * ep[0];
+            reinterpret_cast<double*>(&x)[0] = 1.0 - 0.5 * ep[0];
+        }
+        R2[t] = r;
+        X2[t] = x;
+    }
+    if (over) atomicOr(flag, 2);
+}
+template <class T>
+struct chol_near_identity_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        chol_near_identity_body<T>(b, g, a...);
+    }
+};
 
 // A (m x n, m >= n) -> Q in place, R (n x n, ldr; may be null) with positive diagonal.  *done = false: the operand is not
 // well enough conditioned (or not positive definite to rounding) -- A and R are untouched, the caller factors it by reflectors.
@@ -2183,10 +2523,21 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     QIL_TRY(chol_inv<T>(ctx, G, (int)n, R1, X1, (int*)fl));
     QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, n, n, A, lda, X1, n, Q1, m));
     QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, n, n, m, Q1, m, Q1, m, G, n));
-    QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
+    // second pass: G = I + E; first-order factor while n max |e| <= 3e-8 (|U|^2 below rounding), else the real thing
+    static const bool near_id = !(getenv("QIL_CHOL_NEAR") && atoi(getenv("QIL_CHOL_NEAR")) == 0);
+    if (near_id)
+        QIL_TRY((qil_klaunch<chol_near_identity_k<T>>(ctx, dim3((unsigned)std::min<long long>((n * n + 255) / 256, 1024)), dim3(256), 0, (const T*)G, (int)n, R2, X2, 3e-8 / (double)n, (int*)fl)));
+    else
+        QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
     int bad = 0;
     QIL_HIP(hipMemcpyAsync(&bad, fl, sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
     QIL_HIP(qil_stream_sync(ctx));
+    if (!(bad & 1) && (bad & 2)) {
+        QIL_TRY(qil_dev_zero(ctx, fl, sizeof(int)));
+        QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
+        QIL_HIP(hipMemcpyAsync(&bad, fl, sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));
+    }
     if (bad) {
         release();
         return QIL_OK;
