@@ -115,6 +115,9 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->flag_host) hipHostFree(ctx->flag_host);
+    if (ctx->rb_host) hipHostFree(ctx->rb_host);
+    if (ctx->st_host) hipHostFree(ctx->st_host);
+    if (ctx->st_dev) hipFree(ctx->st_dev);
     if (ctx->sync_event) hipEventDestroy(ctx->sync_event);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);

@@ -71,6 +71,22 @@ struct qil_context {
     void* rinv = nullptr;
     const void* rinv_for = nullptr;
     void* flag_host = nullptr;    // 4 KB pinned: convergence flags the host reads while the stream runs on (qil_ctx_flag_host)
+    // small device -> host read-backs without a copy command or a stream synchronisation (qil_read_back): kRbSlots slots of
+    // kRbSlotBytes in pinned, device-visible memory + a ticket word a kernel writes behind the data; the host polls the word
+    static constexpr int kRbSlots = 4;
+    static constexpr size_t kRbSlotBytes = 8192;
+    void* rb_host = nullptr;
+    uint64_t rb_ticket = 0, rb_done = 0;                          // posted / seen complete
+    // small host -> device uploads of a chain (permutations, scale vectors) without a copy command or an event: filled in a
+    // pinned slot, moved by a (combinable) copy kernel; a slot is reused once a read-back posted after its consumers has
+    // completed (qil_stage_*)
+    static constexpr int kStSlots = 16;
+    static constexpr size_t kStSlotBytes = 32768;
+    void* st_host = nullptr;
+    void* st_dev = nullptr;
+    uint64_t st_born[kStSlots] = {};
+    bool st_used[kStSlots] = {};
+    int st_next = 0;
     void* dev_scratch = nullptr;  // per-call device workspace (stream-ordered reuse)
     size_t dev_scratch_bytes = 0;
     // ring of small host(pinned)/device descriptor slots for grouped launches: a slot is reused
@@ -128,6 +144,17 @@ int qil_ctx_desc_commit(qil_context* ctx, int slot);
 int qil_ctx_event(qil_context* ctx, hipEvent_t* e);            // from the context's event pool
 void qil_ctx_event_release(qil_context* ctx, hipEvent_t e);
 int qil_ctx_flag_host(qil_context* ctx, size_t bytes, void** out);
+// `bytes` (a multiple of 4, 4-byte aligned source) of device memory to the host, ordered after everything this context has
+// launched: qil_read_back = post + wait; posted read-backs complete in order, at most kRbSlots - 1 may be outstanding.
+// Larger blocks than a slot take the copy-command + stream-synchronisation route.
+int qil_read_back_post(qil_context* ctx, const void* dev_src, size_t bytes, uint64_t* ticket);
+int qil_read_back_wait(qil_context* ctx, uint64_t ticket, void* host_dst, size_t bytes);
+int qil_read_back(qil_context* ctx, void* host_dst, const void* dev_src, size_t bytes);
+// acquire a slot (host = pinned side to fill, dev = what the kernels read), push = launch the copy, commit = the consumers
+// have been launched
+int qil_stage_acquire(qil_context* ctx, size_t bytes, void** host, void** dev, int* slot);
+int qil_stage_push(qil_context* ctx, int slot, size_t bytes);
+void qil_stage_commit(qil_context* ctx, int slot);
 int qil_ctx_prof_begin(qil_context* ctx);
 int qil_ctx_prof_end(qil_context* ctx);
 

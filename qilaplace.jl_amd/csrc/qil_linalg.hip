@@ -1728,8 +1728,7 @@ int block_jacobi(qil_context* ctx, long long rows, long long cols, const T* Wk, 
             std::swap(Xc, Xn);
         }
         int hh[2] = {0, 0};
-        QIL_HIP(hipMemcpyAsync(hh, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
-        QIL_HIP(qil_stream_sync(ctx));
+        QIL_TRY(qil_read_back(ctx, hh, flag, 2 * sizeof(int)));
         float worst;
         memcpy(&worst, &hh[1], sizeof(float));
         if (getenv("QIL_SVD_DEBUG"))
@@ -1818,8 +1817,7 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
         QIL_TRY(gemm_dispatch<T>(ctx, sizeof(T) == 16 ? 2 : 1, 0, n, n, m, Q, ldq, Q, ldq, static_cast<T*>(gbuf), n));
         QIL_TRY((qil_klaunch<offdiag_max_k<T>>(ctx, dim3((unsigned)std::min<long long>((n * n + 255) / 256, 1024)), dim3(256), 0, (const T*)gbuf, n, n, (unsigned long long*)mx)));
         double worst = 0;
-        QIL_HIP(hipMemcpyAsync(&worst, mx, sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
-        QIL_HIP(qil_stream_sync(ctx));
+        QIL_TRY(qil_read_back(ctx, &worst, mx, sizeof(double)));
         if (dbg) fprintf(stderr, "[qr] max |Q^H Q - I| off-diagonal %.3g\n", worst);
         if (orthonormal) *orthonormal = !(worst > 1e-9);
         if (!(worst > 1e-11) || pass == 2) break;
@@ -1955,14 +1953,37 @@ int trtri_merge(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv, int
     void* tmp = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * k * sizeof(T), &tmp));
     T* Tm = static_cast<T*>(tmp);
+    // (the off-diagonal blocks of Xinv are zero on entry: X12 = 0 - A^-1 T needs no separate negation; the equal-sized merges of
+    // a level go out as ONE strided batch per product)
+    gemm_batch sub;
+    sub.subtract = 1;
     while (cur.size() > 1) {
         std::vector<Blk> next;
+        const size_t npairs = cur.size() / 2;
+        size_t nuni = 0;
+        const int sz = cur[0].size;
+        while (nuni < npairs && cur[2 * nuni].size == sz && cur[2 * nuni + 1].size == sz) ++nuni;
+        if (nuni < 2) nuni = 0;
+        if (nuni) {
+            const int a0 = cur[0].start, c0 = a0 + sz;
+            gemm_batch b1, b2 = sub;
+            b1.count = b2.count = (int)nuni;
+            b1.a_bs = 2LL * sz * (1 + ldr);
+            b1.b_bs = 2LL * sz * (1 + (long long)k);
+            b1.c_bs = (long long)sz * sz;
+            b2.a_bs = 2LL * sz * (1 + (long long)k);
+            b2.b_bs = (long long)sz * sz;
+            b2.c_bs = 2LL * sz * (1 + (long long)k);
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sz, sz, sz, R + a0 + ldr * (long long)c0, ldr, Xinv + c0 + (long long)k * c0, k, Tm, sz, b1));
+            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sz, sz, sz, Xinv + a0 + (long long)k * a0, k, Tm, sz, Xinv + a0 + (long long)k * c0, k, b2));
+        }
         for (size_t i = 0; i + 1 < cur.size(); i += 2) {
             const int a0 = cur[i].start, sa = cur[i].size, c0 = cur[i + 1].start, sc = cur[i + 1].size;
-            // T = B C^-1 (sa x sc), X12 = -(A^-1 T)
-            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sa, sc, sc, R + a0 + ldr * (long long)c0, ldr, Xinv + c0 + (long long)k * c0, k, Tm, sa));
-            QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sa, sc, sa, Xinv + a0 + (long long)k * a0, k, Tm, sa, Xinv + a0 + (long long)k * c0, k));
-            QIL_TRY((qil_klaunch<negate_block_k<T>>(ctx, dim3((unsigned)std::min<long long>(((long long)sa * sc + 255) / 256, 1024)), dim3(256), 0, Xinv + a0 + (long long)k * c0, (long long)k, sa, sc)));
+            if (i / 2 >= nuni) {
+                // T = B C^-1 (sa x sc), X12 = -(A^-1 T)
+                QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sa, sc, sc, R + a0 + ldr * (long long)c0, ldr, Xinv + c0 + (long long)k * c0, k, Tm, sa));
+                QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, sa, sc, sa, Xinv + a0 + (long long)k * a0, k, Tm, sa, Xinv + a0 + (long long)k * c0, k, sub));
+            }
             next.push_back(Blk{a0, sa + sc});
         }
         if (cur.size() & 1) next.push_back(cur.back());
@@ -2428,10 +2449,12 @@ struct chol_inv_block16_k {
 // zero below the diagonal; *flag (device) is raised on a bad pivot.  Diagonal blocks of 32 TS columns in one workgroup each,
 // the rest by MFMA GEMMs.
 template <class T, int TS, int TG>
-int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
+int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag, bool zeroed) {
     constexpr int NBK = TG * TS;
-    QIL_TRY(qil_dev_zero(ctx, Rm, (size_t)n * n * sizeof(T)));
-    QIL_TRY(qil_dev_zero(ctx, Xm, (size_t)n * n * sizeof(T)));
+    if (!zeroed) {
+        QIL_TRY(qil_dev_zero(ctx, Rm, (size_t)n * n * sizeof(T)));
+        QIL_TRY(qil_dev_zero(ctx, Xm, (size_t)n * n * sizeof(T)));
+    }
     const int opH = sizeof(T) == 16 ? 2 : 1;
     for (int j0 = 0; j0 < n; j0 += NBK) {
         const int nbj = std::min(NBK, n - j0), rest = n - j0 - nbj;
@@ -2455,9 +2478,9 @@ int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
 // 64-column diagonal blocks (TS = 2) measured best for both dtypes: compress! on 24 sites, chi 512 -> 256: f64 161.6 ms (TS 4:
 // 166.8, TS 1: 179.1, Householder panels: 197.8), c64 212.6 ms (214.0 / 229.2 / 341.6); chi 256 -> 128: 68.2 / 69.5 / 73.2 / 70.7
 template <class T>
-int chol_inv(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag) {
+int chol_inv(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag, bool zeroed = false) {
     // (4 x 4 tiles on 16 x 16 threads, same 64 columns: chi 256 69.8 against 66.8 ms; 2 x 2 tiles on 16 x 16 threads, 32 columns: 74.1)
-    return chol_inv_ts<T, 2, 32>(ctx, G, n, Rm, Xm, flag);
+    return chol_inv_ts<T, 2, 32>(ctx, G, n, Rm, Xm, flag, zeroed);
 }
 
 // The second pass of CholeskyQR2 factors G2 = Q1^H Q1 = I + E with |E| ~ kappa(A)^2 eps.  For |E| this small the factor is
@@ -2503,24 +2526,23 @@ template <class T>
 int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr, bool* done) {
     *done = false;
     const int opH = sizeof(T) == 16 ? 2 : 1;
-    void *g = nullptr, *r1 = nullptr, *x1 = nullptr, *r2 = nullptr, *x2 = nullptr, *q1 = nullptr, *fl = nullptr;
+    void *g = nullptr, *rx = nullptr, *r2 = nullptr, *x2 = nullptr, *q1 = nullptr;
     auto release = [&]() {
-        for (void* b : {g, r1, x1, r2, x2, q1, fl})
+        for (void* b : {g, rx, r2, x2, q1})
             if (b) qil_ctx_free(ctx, b);
     };
     const size_t nn = (size_t)(n * n) * sizeof(T);
     QIL_TRY(qil_ctx_alloc(ctx, nn, &g));
-    QIL_TRY(qil_ctx_alloc(ctx, nn, &r1));
-    QIL_TRY(qil_ctx_alloc(ctx, nn, &x1));
+    QIL_TRY(qil_ctx_alloc(ctx, 2 * nn + 256, &rx));              // R1 | X1 | flag: zeroed by ONE launch
     QIL_TRY(qil_ctx_alloc(ctx, nn, &r2));
     QIL_TRY(qil_ctx_alloc(ctx, nn, &x2));
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * n) * sizeof(T), &q1));
-    QIL_TRY(qil_ctx_alloc(ctx, 256, &fl));
-    QIL_TRY(qil_dev_zero(ctx, fl, sizeof(int)));
-    T *G = static_cast<T*>(g), *R1 = static_cast<T*>(r1), *X1 = static_cast<T*>(x1), *R2 = static_cast<T*>(r2),
-      *X2 = static_cast<T*>(x2), *Q1 = static_cast<T*>(q1);
+    QIL_TRY(qil_dev_zero(ctx, rx, 2 * nn + 256));
+    T *G = static_cast<T*>(g), *R1 = static_cast<T*>(rx), *X1 = R1 + n * n, *R2 = static_cast<T*>(r2), *X2 = static_cast<T*>(x2),
+      *Q1 = static_cast<T*>(q1);
+    void* fl = static_cast<void*>(X1 + n * n);
     QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, n, n, m, A, lda, A, lda, G, n));
-    QIL_TRY(chol_inv<T>(ctx, G, (int)n, R1, X1, (int*)fl));
+    QIL_TRY(chol_inv<T>(ctx, G, (int)n, R1, X1, (int*)fl, true));
     QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, n, n, A, lda, X1, n, Q1, m));
     QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, n, n, m, Q1, m, Q1, m, G, n));
     // second pass: G = I + E; first-order factor while n max |e| <= 3e-8 (|U|^2 below rounding), else the real thing
@@ -2530,13 +2552,11 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     else
         QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
     int bad = 0;
-    QIL_HIP(hipMemcpyAsync(&bad, fl, sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(qil_stream_sync(ctx));
+    QIL_TRY(qil_read_back(ctx, &bad, fl, sizeof(int)));
     if (!(bad & 1) && (bad & 2)) {
         QIL_TRY(qil_dev_zero(ctx, fl, sizeof(int)));
         QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
-        QIL_HIP(hipMemcpyAsync(&bad, fl, sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
-        QIL_HIP(qil_stream_sync(ctx));
+        QIL_TRY(qil_read_back(ctx, &bad, fl, sizeof(int)));
     }
     if (bad) {
         release();
@@ -2577,8 +2597,7 @@ int certify_no_truncation(qil_context* ctx, const T* R, long long ldr, int k, do
     double h[2];
     auto stats = [&](const T* M, long long ldm) -> int {
         QIL_TRY((qil_klaunch<tri_stats_k<T>>(ctx, dim3(NB), dim3(256), 0, M, ldm, k, 1, (double*)st)));
-        QIL_HIP(hipMemcpyAsync(hb, st, sizeof(hb), hipMemcpyDeviceToHost, qil_stream(ctx)));
-        QIL_HIP(qil_stream_sync(ctx));
+        QIL_TRY(qil_read_back(ctx, hb, st, sizeof(hb)));
         h[0] = 0;
         h[1] = 1e300;
         for (int b = 0; b < NB; ++b) {          // fixed order
@@ -3361,8 +3380,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             QIL_TRY(qil_ctx_alloc(ctx, 2 * NB * sizeof(double), &st));
             double hb[2 * NB];
             QIL_TRY((qil_klaunch<tri_stats_k<T>>(ctx, dim3(NB), dim3(256), 0, (const T*)R, k, (int)k, 1, (double*)st)));
-            QIL_HIP(hipMemcpyAsync(hb, st, sizeof(hb), hipMemcpyDeviceToHost, qil_stream(ctx)));
-            QIL_HIP(qil_stream_sync(ctx));
+            QIL_TRY(qil_read_back(ctx, hb, st, sizeof(hb)));
             qil_ctx_free(ctx, st);
             double fro2 = 0, dmin = 1e300;
             for (int bI = 0; bI < NB; ++bI) {
@@ -3465,14 +3483,9 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         // enqueued before the flags of sweep s have come back, each of its launches first looks at those flags on the device
         // and does nothing if sweep s had already converged -- the stream never waits for a host round trip.
         constexpr int MAXS = 40;
-        void* hostv = nullptr;
-        QIL_TRY(qil_ctx_flag_host(ctx, (size_t)2 * MAXS * sizeof(int), &hostv));
-        volatile int* hv = static_cast<volatile int*>(hostv);
         int* dflag = static_cast<int*>(flag);                    // [MAXS][2]
         QIL_TRY(qil_dev_zero(ctx, dflag, (size_t)2 * MAXS * sizeof(int)));
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        QIL_TRY(qil_ctx_event(ctx, &ev[0]));
-        QIL_TRY(qil_ctx_event(ctx, &ev[1]));
+        uint64_t ticket[2] = {0, 0};
         auto enqueue = [&](int sw) -> int {
             for (int round = 0; round < nblk - 1; ++round) {
                 const int* prev = sw > 0 ? dflag + 2 * (sw - 1) : nullptr;
@@ -3481,31 +3494,25 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
                 else
                     QIL_TRY((launch_gram_round<T, 8>(ctx, X, k, (int)k, nblk, round, tol, dflag + 2 * sw, prev, (const double*)negl)));
             }
-            QIL_HIP(hipMemcpyAsync(const_cast<int*>(hv) + 2 * sw, dflag + 2 * sw, 2 * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
-            QIL_HIP(hipEventRecord(ev[sw & 1], qil_stream(ctx)));
-            return QIL_OK;
+            return qil_read_back_post(ctx, dflag + 2 * sw, 2 * sizeof(int), &ticket[sw & 1]);
         };
         int st = enqueue(0);
         for (; st == QIL_OK && sweeps < MAXS; ++sweeps) {
             if (sweeps + 1 < MAXS) st = enqueue(sweeps + 1);
             if (st != QIL_OK) break;
-            if (qil_event_sync(ctx, ev[sweeps & 1]) != hipSuccess) {
-                st = qil_fail(QIL_EHIP, "hipEventSynchronize failed in the Jacobi sweeps");
-                break;
-            }
-            if (dbg) fprintf(stderr, "[svd-left] gram sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[2 * sweeps], hv[2 * sweeps + 1]);
-            if (!hv[2 * sweeps + 1]) break;
+            int hv[2] = {0, 0};
+            st = qil_read_back_wait(ctx, ticket[sweeps & 1], hv, sizeof(hv));
+            if (st != QIL_OK) break;
+            if (dbg) fprintf(stderr, "[svd-left] gram sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[0], hv[1]);
+            if (!hv[1]) break;
         }
-        qil_ctx_event_release(ctx, ev[0]);
-        qil_ctx_event_release(ctx, ev[1]);
         QIL_TRY(st);
     } else
     for (; sweeps < 40; ++sweeps) {
         QIL_TRY(qil_dev_zero(ctx, flag, 2 * sizeof(int)));
         QIL_TRY(launch_rounds());
         int hv[2] = {0, 0};
-        QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
-        QIL_HIP(qil_stream_sync(ctx));
+        QIL_TRY(qil_read_back(ctx, hv, flag, 2 * sizeof(int)));
         if (dbg) fprintf(stderr, "[svd-left] sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[0], hv[1]);
         if (!hv[1]) break;
     }
@@ -3513,8 +3520,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     qil_progress_phase(ctx, 5);
     QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)k), dim3(256), 0, (const T*)X, k, k, (double*)nrm)));
     std::vector<double> sig((size_t)k);
-    QIL_HIP(hipMemcpyAsync(sig.data(), nrm, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(qil_stream_sync(ctx));
+    QIL_TRY(qil_read_back(ctx, sig.data(), nrm, (size_t)k * sizeof(double)));
     std::vector<int> perm((size_t)k);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return sig[(size_t)a] > sig[(size_t)b]; });
@@ -3527,10 +3533,10 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     void *hp = nullptr, *dp = nullptr;
     int slot = -1;
     const size_t up = (size_t)k * (sizeof(double) + sizeof(int));
-    QIL_TRY(qil_ctx_desc_acquire(ctx, up, &hp, &dp, &slot));
+    QIL_TRY(qil_stage_acquire(ctx, up, &hp, &dp, &slot));
     memcpy(hp, inv.data(), (size_t)k * sizeof(double));
     memcpy(static_cast<char*>(hp) + (size_t)k * sizeof(double), perm.data(), (size_t)k * sizeof(int));
-    QIL_HIP(hipMemcpyAsync(dp, hp, up, hipMemcpyHostToDevice, qil_stream(ctx)));
+    QIL_TRY(qil_stage_push(ctx, slot, up));
     const double* scd = static_cast<const double*>(dp);
     const int* permd = reinterpret_cast<const int*>(static_cast<const char*>(dp) + (size_t)k * sizeof(double));
     // W = normalised rotated columns in sorted order
@@ -3544,7 +3550,7 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         ldw = ldu;
     }
     QIL_TRY((qil_klaunch<gather_cols_k<T>>(ctx, dim3(gk), dim3(256), 0, (const T*)X, k, k, permd, scd, Wm, ldw, (int)k, 0)));
-    QIL_TRY(qil_ctx_desc_commit(ctx, slot));
+    qil_stage_commit(ctx, slot);
     if (tall) {
         QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, qrows, k, k, Qm, ldq, Wm, ldw, Uiso, ldu));          // Uiso = Q W
         QIL_TRY(gemm_dispatch<T>(ctx, cj, 0, k, q, k, Wm, ldw, R, k, SVh, ldsvh));               // S V^H = W^H R
@@ -3714,8 +3720,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
             for (int round = 0; round < npad - 1 && !bb; ++round)
                 QIL_TRY((qil_klaunch<jacobi_round_k<T>>(ctx, dim3(npad / 2), dim3(256), 0, Wk, ldw, rows, V, ldv, (int)cols, nn, npad, round, tol, (int*)flag, (const double*)negl)));
             int hv[2] = {0, 0};
-            QIL_HIP(hipMemcpyAsync(hv, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, qil_stream(ctx)));
-            QIL_HIP(qil_stream_sync(ctx));
+            QIL_TRY(qil_read_back(ctx, hv, flag, 2 * sizeof(int)));
             if (getenv("QIL_SVD_DEBUG")) fprintf(stderr, "[svd] scalar sweep %d (cols %lld): rotated=%d above-quadratic=%d\n", sweep, nj, hv[0], hv[1]);
             static const bool early = true;
             if (!(early ? hv[1] : hv[0])) break;   // nothing rotated, or only pairs already below the quadratic-phase level
@@ -3728,17 +3733,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     std::vector<double> sig((size_t)nj * 2, 1.0);
     {
         const size_t down = (size_t)nj * (blocked && nj > 96 ? 2 : 1) * sizeof(double);
-        if (down <= qil_context::kDescSlotBytes) {      // through pinned memory: a pageable target is staged twice
-            void *hp = nullptr, *dp = nullptr;
-            int slot = -1;
-            QIL_TRY(qil_ctx_desc_acquire(ctx, down, &hp, &dp, &slot));
-            QIL_HIP(hipMemcpyAsync(hp, nrm, down, hipMemcpyDeviceToHost, qil_stream(ctx)));
-            QIL_HIP(qil_stream_sync(ctx));
-            memcpy(sig.data(), hp, down);
-        } else {
-            QIL_HIP(hipMemcpyAsync(sig.data(), nrm, down, hipMemcpyDeviceToHost, qil_stream(ctx)));
-            QIL_HIP(qil_stream_sync(ctx));
-        }
+        QIL_TRY(qil_read_back(ctx, sig.data(), nrm, down));
     }
     std::vector<int> perm((size_t)nj);
     std::iota(perm.begin(), perm.end(), 0);
@@ -3759,12 +3754,12 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     // whatever follows (chains of small SVDs are bound by exactly that)
     const size_t up_bytes = (size_t)cols * (sizeof(double) + sizeof(int));
     int ring_slot = -1;
-    if (up_bytes <= qil_context::kDescSlotBytes) {
+    if (up_bytes <= qil_context::kStSlotBytes) {
         void *hp = nullptr, *dp = nullptr;
-        QIL_TRY(qil_ctx_desc_acquire(ctx, up_bytes, &hp, &dp, &ring_slot));
+        QIL_TRY(qil_stage_acquire(ctx, up_bytes, &hp, &dp, &ring_slot));
         memcpy(hp, inv.data(), (size_t)cols * sizeof(double));
         memcpy(static_cast<char*>(hp) + (size_t)cols * sizeof(double), perm.data(), (size_t)cols * sizeof(int));
-        QIL_HIP(hipMemcpyAsync(dp, hp, up_bytes, hipMemcpyHostToDevice, qil_stream(ctx)));
+        QIL_TRY(qil_stage_push(ctx, ring_slot, up_bytes));
         qil_ctx_free(ctx, scd);
         qil_ctx_free(ctx, permd);
         scd = dp;
@@ -3811,7 +3806,7 @@ int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T*
     }
     QIL_HIP(hipGetLastError());
     if (ring_slot >= 0) {
-        QIL_TRY(qil_ctx_desc_commit(ctx, ring_slot));
+        qil_stage_commit(ctx, ring_slot);
         scd = permd = nullptr;                                   // ring memory, not pool blocks
     } else {
         // perm/inv are host vectors read by async copies: finish before they go out of scope
@@ -4091,13 +4086,108 @@ struct zero2d_k {
     }
 };
 
+// A small block of device memory into pinned host memory, then the ticket behind it (system-scope release): the host polls
+// the ticket word instead of issuing a copy command and synchronising the stream, and in a lock-step batch the read-backs of
+// the chains of a group are ONE launch instead of one copy command + event per chain on the stream they share.
+__device__ __forceinline__ void read_back_body(const uint3, const uint3, const unsigned* __restrict__ src, int nwords, unsigned* __restrict__ dst,
+                                               unsigned long long* __restrict__ ticket_word, unsigned long long ticket) {
+    for (int t = threadIdx.x; t < nwords; t += blockDim.x) dst[t] = src[t];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct read_back_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        read_back_body(b, g, a...);
+    }
+};
+
 }  // namespace
+
+int qil_read_back_post(qil_context* ctx, const void* dev_src, size_t bytes, uint64_t* ticket) {
+    QIL_REQUIRE(bytes > 0 && bytes <= qil_context::kRbSlotBytes && (bytes & 3) == 0 && ((uintptr_t)dev_src & 3) == 0, QIL_EINVAL_ARG,
+                "read-back of %zu bytes does not fit a slot", bytes);
+    if (!ctx->rb_host) {
+        QIL_HIP(hipHostMalloc(&ctx->rb_host, qil_context::kRbSlots * qil_context::kRbSlotBytes + 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ctx->rb_host, 0, qil_context::kRbSlots * qil_context::kRbSlotBytes + 64);
+    }
+    const uint64_t t = ++ctx->rb_ticket;
+    char* base = static_cast<char*>(ctx->rb_host);
+    unsigned* slot = reinterpret_cast<unsigned*>(base + (t % qil_context::kRbSlots) * qil_context::kRbSlotBytes);
+    unsigned long long* word = reinterpret_cast<unsigned long long*>(base + qil_context::kRbSlots * qil_context::kRbSlotBytes);
+    *ticket = t;
+    return qil_klaunch<read_back_k>(ctx, dim3(1), dim3(256), 0, static_cast<const unsigned*>(dev_src), (int)(bytes / 4), slot, word,
+                                    (unsigned long long)t);
+}
+int qil_read_back_wait(qil_context* ctx, uint64_t ticket, void* host_dst, size_t bytes) {
+    char* base = static_cast<char*>(ctx->rb_host);
+    const unsigned long long* word = reinterpret_cast<const unsigned long long*>(base + qil_context::kRbSlots * qil_context::kRbSlotBytes);
+    const auto t0 = std::chrono::steady_clock::now();
+    long long spins = 0;
+    while (__atomic_load_n(word, __ATOMIC_ACQUIRE) < ticket) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0) {                          // a launch that never ran must not hang the caller
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+                return qil_fail(QIL_EHIP, "read-back %llu did not arrive within 60 s (device error?)", (unsigned long long)ticket);
+            if (!ctx->lockstep) {
+                const hipError_t e = hipStreamQuery(ctx->stream);
+                if (e != hipSuccess && e != hipErrorNotReady) return qil_fail(QIL_EHIP, "stream error while waiting for a read-back: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    memcpy(host_dst, base + (ticket % qil_context::kRbSlots) * qil_context::kRbSlotBytes, bytes);
+    ctx->rb_done = std::max(ctx->rb_done, (uint64_t)ticket);
+    return QIL_OK;
+}
+int qil_read_back(qil_context* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    if (bytes == 0) return QIL_OK;
+    static const bool polled = !(getenv("QIL_READBACK") && atoi(getenv("QIL_READBACK")) == 0);
+    if (!polled || bytes > qil_context::kRbSlotBytes || (bytes & 3) || ((uintptr_t)dev_src & 3)) {
+        QIL_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, qil_stream(ctx)));
+        QIL_HIP(qil_stream_sync(ctx));
+        if (ctx->rb_done == ctx->rb_ticket) ctx->rb_done = ++ctx->rb_ticket;   // (nothing posted is outstanding: everything launched so far is complete)
+        return QIL_OK;
+    }
+    uint64_t t = 0;
+    QIL_TRY(qil_read_back_post(ctx, dev_src, bytes, &t));
+    return qil_read_back_wait(ctx, t, host_dst, bytes);
+}
+
+int qil_stage_acquire(qil_context* ctx, size_t bytes, void** host, void** dev, int* slot) {
+    QIL_REQUIRE(bytes <= qil_context::kStSlotBytes, QIL_EINVAL_ARG, "staged upload of %zu bytes exceeds the slot size", bytes);
+    if (!ctx->st_host) {
+        const size_t tot = qil_context::kStSlots * qil_context::kStSlotBytes;
+        QIL_HIP(hipHostMalloc(&ctx->st_host, tot, hipHostMallocMapped | hipHostMallocCoherent));
+        QIL_HIP(hipMalloc(&ctx->st_dev, tot));
+    }
+    const int k = ctx->st_next;
+    ctx->st_next = (k + 1) % qil_context::kStSlots;
+    if (ctx->st_used[k] && ctx->rb_done <= ctx->st_born[k]) {    // no read-back posted after its consumers has come back yet
+        unsigned word = 0;
+        QIL_TRY(qil_read_back(ctx, &word, ctx->st_dev, sizeof(word)));
+    }
+    ctx->st_used[k] = false;
+    *host = static_cast<char*>(ctx->st_host) + (size_t)k * qil_context::kStSlotBytes;
+    *dev = static_cast<char*>(ctx->st_dev) + (size_t)k * qil_context::kStSlotBytes;
+    *slot = k;
+    return QIL_OK;
+}
+int qil_stage_push(qil_context* ctx, int slot, size_t bytes) {
+    const size_t off = (size_t)slot * qil_context::kStSlotBytes;
+    return qil_dev_copy(ctx, static_cast<char*>(ctx->st_dev) + off, static_cast<const char*>(ctx->st_host) + off, (bytes + 7) & ~(size_t)7);
+}
+void qil_stage_commit(qil_context* ctx, int slot) {
+    ctx->st_born[slot] = ctx->rb_ticket;
+    ctx->st_used[slot] = true;
+}
 
 int qil_dev_copy2d(qil_context* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
     if (width == 0 || height == 0) return QIL_OK;
     const bool words = ((dpitch | spitch | width | (size_t)(uintptr_t)dst | (size_t)(uintptr_t)src) & 7) == 0;
     if (!words || width * height > ((size_t)64 << 20)) {         // odd shapes / bulk data: the copy engine path
-        QIL_TRY(qil_dev_copy2d(ctx, dst, dpitch, src, spitch, width, height));
+        QIL_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, qil_stream(ctx)));
         return QIL_OK;
     }
     const long long total = (long long)(width / 8) * (long long)height;
@@ -4112,7 +4202,7 @@ int qil_dev_zero2d(qil_context* ctx, void* dst, size_t pitch, size_t width, size
     if (width == 0 || height == 0) return QIL_OK;
     const bool words = ((pitch | width | (size_t)(uintptr_t)dst) & 3) == 0;
     if (!words || width * height > ((size_t)64 << 20)) {
-        QIL_TRY(qil_dev_zero2d(ctx, dst, pitch, width, height));
+        QIL_HIP(hipMemset2DAsync(dst, pitch, 0, width, height, qil_stream(ctx)));
         return QIL_OK;
     }
     const long long total = (long long)(width / 4) * (long long)height;
@@ -4194,8 +4284,7 @@ extern "C" int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m
     QIL_TRY(qil_dev_zero(ctx, dC, (size_t)(ldc * n) * e));
     QIL_HIP(qil_stream_sync(ctx));
     QIL_TRY(qil_dev_gemm(ctx, dtype, opA, opB, m, n, k, dA, lda, dB, ldb, dC, ldc));
-    QIL_HIP(hipMemcpyAsync(C, dC, (size_t)(ldc * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(qil_stream_sync(ctx));
+    QIL_TRY(qil_read_back(ctx, C, dC, (size_t)(ldc * n) * e));
     qil_ctx_free(ctx, dA);
     qil_ctx_free(ctx, dB);
     qil_ctx_free(ctx, dC);
@@ -4216,8 +4305,7 @@ extern "C" int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n
     QIL_HIP(qil_stream_sync(ctx));
     QIL_TRY(qil_dev_qr_positive(ctx, dtype, m, n, dA, m, dR, n, true));
     QIL_HIP(hipMemcpyAsync(Q, dA, (size_t)(m * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(hipMemcpyAsync(R, dR, (size_t)(n * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(qil_stream_sync(ctx));
+    QIL_TRY(qil_read_back(ctx, R, dR, (size_t)(n * n) * e));
     qil_ctx_free(ctx, dA);
     qil_ctx_free(ctx, dR);
     return QIL_OK;
@@ -4396,11 +4484,11 @@ int qil_dev_scale(qil_context* ctx, int dtype, int side, int64_t m, int64_t n, v
     const int64_t len = side ? n : m;
     void* sd = nullptr;
     int ring_slot = -1;
-    if ((size_t)len * sizeof(double) <= qil_context::kDescSlotBytes) {   // pinned ring: no synchronisation
+    if ((size_t)len * sizeof(double) <= qil_context::kStSlotBytes) {   // pinned ring: no synchronisation
         void* hp = nullptr;
-        QIL_TRY(qil_ctx_desc_acquire(ctx, (size_t)len * sizeof(double), &hp, &sd, &ring_slot));
+        QIL_TRY(qil_stage_acquire(ctx, (size_t)len * sizeof(double), &hp, &sd, &ring_slot));
         memcpy(hp, s_host, (size_t)len * sizeof(double));
-        QIL_HIP(hipMemcpyAsync(sd, hp, (size_t)len * sizeof(double), hipMemcpyHostToDevice, qil_stream(ctx)));
+        QIL_TRY(qil_stage_push(ctx, ring_slot, (size_t)len * sizeof(double)));
     } else {
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)len * sizeof(double), &sd));
         QIL_HIP(hipMemcpyAsync(sd, s_host, (size_t)len * sizeof(double), hipMemcpyHostToDevice, qil_stream(ctx)));
@@ -4412,7 +4500,10 @@ int qil_dev_scale(qil_context* ctx, int dtype, int side, int64_t m, int64_t n, v
     else
         QIL_TRY((qil_klaunch<scale_kernel_k<double>>(ctx, dim3(g), dim3(256), 0, (double*)A, lda, m, n, (const double*)sd, side)));
     QIL_HIP(hipGetLastError());
-    if (ring_slot >= 0) return qil_ctx_desc_commit(ctx, ring_slot);
+    if (ring_slot >= 0) {
+        qil_stage_commit(ctx, ring_slot);
+        return QIL_OK;
+    }
     qil_ctx_free(ctx, sd);
     return QIL_OK;
 }

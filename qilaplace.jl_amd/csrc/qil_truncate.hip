@@ -125,8 +125,7 @@ static int svd_trunc_lowrank(qil_context* ctx, int dtype, int64_t m, int64_t n, 
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)nblk_ * 2 * sizeof(double), &part));
         QIL_TRY((qil_klaunch<residual_sumsq_k>(ctx, dim3(nblk_), dim3(256), 0, (const double*)A, (long long)lda, (const double*)D, (long long)m, (long long)m, (long long)n, nre, (double*)part)));
         std::vector<double> hp((size_t)nblk_ * 2);
-        QIL_HIP(hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
-        QIL_HIP(qil_stream_sync(ctx));
+        QIL_TRY(qil_read_back(ctx, hp.data(), part, hp.size() * sizeof(double)));
         double rho = 0, tot = 0;
         for (unsigned b = 0; b < nblk_; ++b) {
             rho += hp[2 * b];
@@ -746,8 +745,7 @@ int signal_mps_impl(qil_context* ctx, const void* x, int64_t len, int dtype, con
     QIL_TRY(qil_ctx_alloc(ctx, kPartBlocks * sizeof(double), &part));
     QIL_TRY((qil_klaunch<sumsq_partial_k>(ctx, dim3(kPartBlocks), dim3(256), 0, (const double*)X, (long long)(N * ncomp), (double*)part)));
     std::vector<double> ph(kPartBlocks);
-    QIL_HIP(hipMemcpyAsync(ph.data(), part, kPartBlocks * sizeof(double), hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(qil_stream_sync(ctx));   // also completes the upload of caller memory `x`
+    QIL_TRY(qil_read_back(ctx, ph.data(), part, kPartBlocks * sizeof(double)));   // also completes the upload of caller memory `x`
     qil_ctx_free(ctx, part);
     double ss = 0;
     for (double v : ph) ss += v;                  // fixed order: deterministic
@@ -1309,8 +1307,7 @@ extern "C" int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t
     std::vector<double> Sv;
     QIL_TRY(svd_trunc_dev(ctx, dtype, m, n, dA, m, cutoff, cutoff >= 0, maxdim, mindim, 0, &r, &dU, &dVh, &Sv));
     QIL_HIP(hipMemcpyAsync(U, dU, (size_t)(m * r) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(hipMemcpyAsync(Vh, dVh, (size_t)(r * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(qil_stream_sync(ctx));
+    QIL_TRY(qil_read_back(ctx, Vh, dVh, (size_t)(r * n) * e));
     for (int64_t i = 0; i < r; ++i) S[i] = Sv[(size_t)i];
     *rank = r;
     qil_ctx_free(ctx, dA);
@@ -1354,8 +1351,7 @@ extern "C" int qil_rsvd(qil_context* ctx, const void* A, int64_t m, int64_t n, i
     QIL_TRY(qil_dev_transpose(ctx, dtype, 0, r, m, L, r, dU, m));
     QIL_TRY(qil_dev_transpose(ctx, dtype, 0, n, r, R, n, dVh, r));
     QIL_HIP(hipMemcpyAsync(U, dU, (size_t)(m * r) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(hipMemcpyAsync(Vh, dVh, (size_t)(r * n) * e, hipMemcpyDeviceToHost, qil_stream(ctx)));
-    QIL_HIP(qil_stream_sync(ctx));
+    QIL_TRY(qil_read_back(ctx, Vh, dVh, (size_t)(r * n) * e));
     for (int64_t i = 0; i < r; ++i) S[i] = Sv[(size_t)i];
     *rank = r;
     qil_ctx_free(ctx, L);

@@ -412,6 +412,19 @@ def test_rsvd_low_rank_fixture(qil):                              # test_rsvd.jl
         qil.rsvd(np.zeros((0, 4)))
 
 
+def test_rsvd_operand_beyond_the_kernel_copy_limit(qil):
+    # a 4 x 2^22 f64 operand (134 MB) whose sketch is as wide as its short side: the exact-SVD branch copies the operand, and
+    # copies above 64 MB go through the copy engine instead of the combinable copy kernel (qil_dev_copy2d's bulk path)
+    rng = np.random.default_rng(3)
+    V0 = rng.standard_normal((3, 1 << 22))
+    A = np.vstack([V0[0] * 3.0, V0[1], V0[0] - V0[2] * 0.5, V0[2] * 1e-3])
+    U, S, Vh = qil.rsvd(A, k=2, p=2, q=0)
+    sref = np.linalg.svd(A @ A.T, compute_uv=False) ** 0.5
+    assert len(S) == 2 and np.abs(S - sref[:2]).max() < 1e-9 * sref[0]                 # the rank the caller asked for (rsvd.jl:72)
+    assert np.abs(U.T @ U - np.eye(2)).max() < 1e-10
+    assert np.abs(np.linalg.norm(A.T @ U, axis=0) - S).max() < 1e-9 * sref[0]          # A^T u_j = s_j v_j
+
+
 @pytest.mark.parametrize("shape", [(40, 12), (12, 40), (33, 33), (300, 150), (200, 200), (130, 400), (2000, 24), (700, 260)])
 @pytest.mark.parametrize("dt", [np.float64, np.complex128])
 def test_svd_trunc_vs_lapack(qil, shape, dt):
