@@ -4,6 +4,10 @@
 #include "qil_internal.h"
 #include "qil_launch.h"
 
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <memory>
 #include <chrono>
@@ -163,6 +167,19 @@ int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out) {
         return qil_fail(QIL_ENOMEM, "injected allocation failure (qil_context_fail_alloc_after)");
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~(size_t)255;
+    struct alloc_timer {                                         // QIL_BATCH_DEBUG accounting
+        qil_context* c;
+        std::chrono::steady_clock::time_point t0;
+        explicit alloc_timer(qil_context* cc) : c(cc) {
+            if (c->dbg_times) t0 = std::chrono::steady_clock::now();
+        }
+        ~alloc_timer() {
+            if (c->dbg_times) {
+                c->dbg_alloc_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                ++c->dbg_alloc_n;
+            }
+        }
+    } timer(ctx);
     auto it = ctx->free_blocks.find(bytes);
     if (it != ctx->free_blocks.end()) {
         *out = it->second;
@@ -181,6 +198,7 @@ int qil_ctx_alloc(qil_context* ctx, size_t bytes, void** out) {
                }()) {
         // taken from the blocks the home context lends for the duration of a batch
     } else {
+        ++ctx->dbg_alloc_miss;
         hipError_t e = hipMalloc(out, bytes);
         if (e == hipErrorOutOfMemory && !ctx->free_blocks.empty()) {
             // give cached blocks back and retry once
@@ -467,6 +485,13 @@ struct qil_chainq {
     std::atomic<unsigned> seq{0};                  // launches it has queued since the key last changed
     std::atomic<int> live{1};
     std::atomic<int> status{0};                    // first failed launch of this chain
+    // a chain thread that waits for a read-back SLEEPS here (futex) and the group's launcher, which polls anyway, watches the
+    // ticket word for it: the GPU boxes give a process a CPU quota (16 CPUs), and 32 chain threads spinning on their tickets
+    // exhaust it -- every thread is then throttled for the rest of the scheduler period (measured: three 45-55 ms stalls of
+    // all four queues per 32-chain batch)
+    std::atomic<uint32_t> parked{0};
+    const unsigned long long* wait_word = nullptr;
+    unsigned long long wait_ticket = 0;
 };
 struct qil_lockstep {
     int nslots = 0;
@@ -498,6 +523,38 @@ void qil_progress_phase(qil_context* ctx, int phase) {
     }
 }
 
+static inline void futex_wait_for(std::atomic<uint32_t>* a, uint32_t expected, long timeout_ns) {
+    timespec ts{0, timeout_ns};
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(a), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
+}
+static inline void futex_wake_one(std::atomic<uint32_t>* a) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(a), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+}
+// chain side: sleep until *word >= ticket (the launcher wakes the thread; the timeout only bounds a lost wake-up)
+void qil_lockstep_park(qil_context* ctx, const unsigned long long* word, unsigned long long ticket) {
+    qil_chainq& q = ctx->lockstep->q[ctx->ls_slot];
+    while (__atomic_load_n(word, __ATOMIC_ACQUIRE) < ticket) {
+        q.wait_word = word;
+        q.wait_ticket = ticket;
+        q.parked.store(1, std::memory_order_release);
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) >= ticket) {
+            q.parked.store(0, std::memory_order_relaxed);
+            break;
+        }
+        futex_wait_for(&q.parked, 1, 20 * 1000 * 1000);
+        q.parked.store(0, std::memory_order_relaxed);
+    }
+}
+// launcher side: wake the chains whose tickets have arrived
+static inline void lockstep_wake_arrived(qil_lockstep* ls) {
+    for (int s = 0; s < ls->nslots; ++s) {
+        qil_chainq& q = ls->q[s];
+        if (q.parked.load(std::memory_order_acquire) == 1 && __atomic_load_n(q.wait_word, __ATOMIC_ACQUIRE) >= q.wait_ticket) {
+            uint32_t one = 1;
+            if (q.parked.compare_exchange_strong(one, 2, std::memory_order_acq_rel)) futex_wake_one(&q.parked);
+        }
+    }
+}
 static inline void spin_pause(int& spins) {
     if (++spins < (1 << 14))
         __builtin_ia32_pause();
@@ -509,7 +566,11 @@ qil_launch_req* qil_lockstep_begin(qil_lockstep* ls, qil_context* ctx) {
     qil_chainq& q = ls->q[ctx->ls_slot];
     const unsigned t = q.tail.load(std::memory_order_relaxed);
     int spins = 0;
-    while (t - q.head.load(std::memory_order_acquire) >= QIL_RING) spin_pause(spins);   // ring full
+    if (t - q.head.load(std::memory_order_acquire) >= QIL_RING) {                       // ring full
+        const auto t0 = std::chrono::steady_clock::now();
+        while (t - q.head.load(std::memory_order_acquire) >= QIL_RING) spin_pause(spins);
+        if (ctx->dbg_times) ctx->dbg_ring_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
     qil_launch_req* r = &q.ring[t % QIL_RING];
     r->progress = ctx->progress_key;
     r->seq = q.seq.load(std::memory_order_relaxed);
@@ -561,6 +622,7 @@ static void lockstep_run(qil_lockstep* ls, bool timing) {
     bool waiting = false;
     std::chrono::steady_clock::time_point wait_since;
     for (;;) {
+        lockstep_wake_arrived(ls);
         // order = (progress key, position inside the key's segment): chains running the same program queue the same kernel
         // at the same position, so serving the smallest position first re-aligns chains that are one step apart
         uint64_t headkey = ~0ull, idlekey = ~0ull;
@@ -740,15 +802,21 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     auto drive = [&](int k) {
         qil_context* w = slot_ctx(k);
         const bool in_step = lockstep && w->lockstep;            // (a slot whose thread could not be started runs alone afterwards)
+        w->dbg_times = batch_debug;
         int s0 = QIL_OK;
         if ((k || lockstep) && (hipSetDevice(w->device) != hipSuccess || (!lockstep && hipStreamWaitEvent(w->stream, ready, 0) != hipSuccess))) s0 = QIL_EHIP;
         for (int64_t j = k; j < nb; j += nw) {
             const auto tj0 = std::chrono::steady_clock::now();
             const int s = s0 != QIL_OK ? s0 : fn(j, w);
-            if (batch_debug)
-                fprintf(stderr, "[batch] slot %d item %lld: start %.2f ms, took %.2f ms\n", k, (long long)j,
+            if (batch_debug) {
+                fprintf(stderr, "[batch] slot %d item %lld: start %.2f ms, took %.2f ms; %lld read-backs waited %.2f ms, ring full %.2f ms, "
+                        "%lld allocations (%lld beyond the caches) %.2f ms\n", k, (long long)j,
                         std::chrono::duration<double, std::milli>(tj0 - t_batch).count(),
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count());
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count(), w->dbg_rb_n,
+                        w->dbg_rb_us / 1e3, w->dbg_ring_us / 1e3, w->dbg_alloc_n, w->dbg_alloc_miss, w->dbg_alloc_us / 1e3);
+                w->dbg_rb_n = w->dbg_alloc_n = w->dbg_alloc_miss = 0;
+                w->dbg_rb_us = w->dbg_ring_us = w->dbg_alloc_us = 0;
+            }
             if (s != QIL_OK) {
                 status[(size_t)j] = s;
                 message[(size_t)j] = s0 != QIL_OK ? "worker stream setup failed" : qil_last_error();
@@ -820,13 +888,9 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     home->bytes_cached += home->lend_cached;
     home->lend_blocks.clear();
     home->lend_cached = 0;
-    for (int k = 1; k < nw; ++k) {
-        qil_context* w = slot_ctx(k);
-        for (auto& kv : w->free_blocks) home->free_blocks.emplace(kv.first, kv.second);
-        home->bytes_cached += w->bytes_cached;
-        w->free_blocks.clear();
-        w->bytes_cached = 0;
-    }
+    // (the workers KEEP their caches between batches: a slot runs the same chain shapes every time, and a worker that starts
+    // with an empty cache takes every block from the lender under its mutex -- 32 chain threads: 1 600 allocations of 32 us
+    // each per chain, on the critical path of every lock-step step; qil_context_mem_info / qil_context_trim cover the workers)
     (void)hipEventDestroy(ready);
     for (int64_t j = 0; j < nb; ++j)
         if (status[(size_t)j] != QIL_OK)

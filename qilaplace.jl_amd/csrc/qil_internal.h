@@ -77,6 +77,9 @@ struct qil_context {
     static constexpr size_t kRbSlotBytes = 8192;
     void* rb_host = nullptr;
     uint64_t rb_ticket = 0, rb_done = 0;                          // posted / seen complete
+    bool dbg_times = false;       // QIL_BATCH_DEBUG: where a chain's host thread spends its time
+    double dbg_rb_us = 0, dbg_ring_us = 0, dbg_alloc_us = 0;
+    long long dbg_rb_n = 0, dbg_alloc_n = 0, dbg_alloc_miss = 0;
     // small host -> device uploads of a chain (permutations, scale vectors) without a copy command or an event: filled in a
     // pinned slot, moved by a (combinable) copy kernel; a slot is reused once a read-back posted after its consumers has
     // completed (qil_stage_*)
@@ -111,7 +114,8 @@ struct qil_context {
     // thread) and on worker contexts (own stream and pool, one host thread each), one batch at a time.  For the duration of
     // a batch the home context's cached blocks are LENT: every participant misses in its own cache first, then takes from
     // `lend_blocks` (all work enqueued on them is ordered before the batch by an event), then allocates; at the end the
-    // remaining lent blocks and the workers' caches return to the home cache, so steady-state batches allocate nothing.
+    // remaining lent blocks return to the home cache and the workers keep theirs, so steady-state batches allocate nothing and
+    // take (almost) nothing from the lender.
     std::vector<qil_context*> workers;
     std::mutex batch_mutex;
     qil_context* parent = nullptr;                   // worker -> home
@@ -147,6 +151,7 @@ int qil_ctx_flag_host(qil_context* ctx, size_t bytes, void** out);
 // `bytes` (a multiple of 4, 4-byte aligned source) of device memory to the host, ordered after everything this context has
 // launched: qil_read_back = post + wait; posted read-backs complete in order, at most kRbSlots - 1 may be outstanding.
 // Larger blocks than a slot take the copy-command + stream-synchronisation route.
+void qil_lockstep_park(qil_context* ctx, const unsigned long long* word, unsigned long long ticket);   // (qil_context.hip)
 int qil_read_back_post(qil_context* ctx, const void* dev_src, size_t bytes, uint64_t* ticket);
 int qil_read_back_wait(qil_context* ctx, uint64_t ticket, void* host_dst, size_t bytes);
 int qil_read_back(qil_context* ctx, void* host_dst, const void* dev_src, size_t bytes);

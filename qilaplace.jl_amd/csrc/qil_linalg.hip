@@ -4126,6 +4126,7 @@ int qil_read_back_wait(qil_context* ctx, uint64_t ticket, void* host_dst, size_t
     const unsigned long long* word = reinterpret_cast<const unsigned long long*>(base + qil_context::kRbSlots * qil_context::kRbSlotBytes);
     const auto t0 = std::chrono::steady_clock::now();
     long long spins = 0;
+    if (ctx->lockstep) qil_lockstep_park(ctx, word, ticket);      // (sleeps; the group's launcher watches the word)
     while (__atomic_load_n(word, __ATOMIC_ACQUIRE) < ticket) {
         __builtin_ia32_pause();
         if ((++spins & 0xfffff) == 0) {                          // a launch that never ran must not hang the caller
@@ -4139,6 +4140,10 @@ int qil_read_back_wait(qil_context* ctx, uint64_t ticket, void* host_dst, size_t
     }
     memcpy(host_dst, base + (ticket % qil_context::kRbSlots) * qil_context::kRbSlotBytes, bytes);
     ctx->rb_done = std::max(ctx->rb_done, (uint64_t)ticket);
+    if (ctx->dbg_times) {
+        ctx->dbg_rb_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        ++ctx->dbg_rb_n;
+    }
     return QIL_OK;
 }
 int qil_read_back(qil_context* ctx, void* host_dst, const void* dev_src, size_t bytes) {

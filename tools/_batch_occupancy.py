@@ -11,12 +11,12 @@ import os, sys, csv, glob, json
 import numpy as np
 
 
-def run(nb, chi):
+def run(nb, chi, same=False):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import qilaplace_jl_amd as qil
     ctx = qil.default_context()
     def sat(L, chi, base=2): return [int(min(base ** (i + 1), base ** (L - 1 - i), chi)) for i in range(L - 1)]
-    def make(i): return qil.SignalMPS.alloc(sat(24, chi), dtype=np.float64).fill_random(5 + i)
+    def make(i): return qil.SignalMPS.alloc(sat(24, chi), dtype=np.float64).fill_random(5 if same else 5 + i)
     # one chain alone first (warm pool, code objects).  NOTE: under rocprofv3 this multi-threaded workload dies with a SIGSEGV
     # inside the tracer's interception layer in roughly one run of three -- with this library and with the one from before
     # the batched kernels alike (A/B, 6 runs each), never without the tracer (8 of 8 untraced processes) -- re-run it.
@@ -81,6 +81,7 @@ def analyse(d):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run(int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]) if len(sys.argv) > 3 else 256)
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]) if len(sys.argv) > 3 else 256,
+            len(sys.argv) > 4 and sys.argv[4] == "same")
     else:
         analyse(sys.argv[2])

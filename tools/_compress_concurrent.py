@@ -8,7 +8,8 @@ nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 chi = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 ctx = qil.default_context()
 def sat(L, chi, base=2): return [int(min(base ** (i + 1), base ** (L - 1 - i), chi)) for i in range(L - 1)]
-def make(i, c=None): return qil.SignalMPS.alloc(sat(24, chi), dtype=np.float64, ctx=c).fill_random(5 + i)
+same = len(sys.argv) > 3 and sys.argv[3] == "same"          # identical chains: the lock-step groups never fall out of step
+def make(i, c=None): return qil.SignalMPS.alloc(sat(24, chi), dtype=np.float64, ctx=c).fill_random(5 if same else 5 + i)
 for rep in range(3):
     psi = make(0); ctx.synchronize(); t0 = time.perf_counter(); qil.compress(psi, maxdim=chi // 2, tol=1e-10); ctx.synchronize(); t1 = time.perf_counter() - t0
 for rep in range(3):
