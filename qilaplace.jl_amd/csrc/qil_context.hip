@@ -118,7 +118,6 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
         hipEventDestroy(pr.second);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    if (ctx->flag_host) hipHostFree(ctx->flag_host);
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     if (ctx->st_host) hipHostFree(ctx->st_host);
     if (ctx->st_dev) hipFree(ctx->st_dev);
@@ -370,14 +369,6 @@ int qil_ctx_event(qil_context* ctx, hipEvent_t* e) { return get_event(ctx, e); }
 void qil_ctx_event_release(qil_context* ctx, hipEvent_t e) {
     if (e) ctx->event_pool.push_back(e);
 }
-// a small pinned block of the context's own for flag read-backs that the host polls while the stream runs on
-int qil_ctx_flag_host(qil_context* ctx, size_t bytes, void** out) {
-    if (bytes > 4096) return qil_fail(QIL_EINVAL_ARG, "flag block too large");
-    if (!ctx->flag_host) QIL_HIP(hipHostMalloc(&ctx->flag_host, 4096, hipHostMallocDefault));
-    *out = ctx->flag_host;
-    return QIL_OK;
-}
-
 int qil_ctx_prof_begin(qil_context* ctx) {
     if (!ctx->profile) return QIL_OK;
     hipEvent_t a, b;

@@ -70,7 +70,6 @@ struct qil_context {
     bool want_rinv = false;
     void* rinv = nullptr;
     const void* rinv_for = nullptr;
-    void* flag_host = nullptr;    // 4 KB pinned: convergence flags the host reads while the stream runs on (qil_ctx_flag_host)
     // small device -> host read-backs without a copy command or a stream synchronisation (qil_read_back): kRbSlots slots of
     // kRbSlotBytes in pinned, device-visible memory + a ticket word a kernel writes behind the data; the host polls the word
     static constexpr int kRbSlots = 4;
@@ -147,7 +146,6 @@ int qil_ctx_desc_acquire(qil_context* ctx, size_t bytes, void** host, void** dev
 int qil_ctx_desc_commit(qil_context* ctx, int slot);
 int qil_ctx_event(qil_context* ctx, hipEvent_t* e);            // from the context's event pool
 void qil_ctx_event_release(qil_context* ctx, hipEvent_t e);
-int qil_ctx_flag_host(qil_context* ctx, size_t bytes, void** out);
 // `bytes` (a multiple of 4, 4-byte aligned source) of device memory to the host, ordered after everything this context has
 // launched: qil_read_back = post + wait; posted read-backs complete in order, at most kRbSlots - 1 may be outstanding.
 // Larger blocks than a slot take the copy-command + stream-synchronisation route.

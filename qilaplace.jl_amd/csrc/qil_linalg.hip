@@ -1927,20 +1927,6 @@ struct trtri_diag_k {
     }
 };
 
-template <class T>
-__device__ __forceinline__ void negate_block_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ A, long long lda, int m, int n) {
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < (long long)m * n; t += (long long)gridDim.x * blockDim.x)
-        A[(t % m) + lda * (t / m)] = neg_t(A[(t % m) + lda * (t / m)]);
-}
-template <class T>
-struct negate_block_k {
-    static constexpr int NT = 1024, MINW = 1;
-    template <class... QA>
-    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
-        negate_block_body<T>(b, g, a...);
-    }
-};
-
 // The off-diagonal blocks of Xinv = R^-1 (k x k, ld k) from its inverted diagonal blocks of width `blk` (already in place):
 // neighbouring blocks are merged level by level, [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1]  (MFMA GEMMs)
 template <class T>
@@ -2010,147 +1996,11 @@ int trtri_upper(qil_context* ctx, const T* R, long long ldr, int k, T* Xinv) {
 // and once more on Q (CholeskyQR2: orthonormal to rounding while kappa(A)^2 eps << 1).  The gauge sweeps of compress! /
 // canonicalize! factor sites whose conditioning the truncation certificate bounds anyway (it declines beyond kappa ~ 5e5),
 // and a blocked Householder QR of 512 x 256 is ~80 small launches with eight 50-70 us one-workgroup panels in them.
-// chol_inv_block: ONE workgroup of 32 x 32 threads, the diagonal block (nb <= NBK = 32 TS) in REGISTERS: thread (tr, tc) keeps
-// the TS x TS tile (tr, tc) -- of the Schur complement S if tc >= tr (upper triangle), of the elimination matrix E = L~^-1
-// (G = L~ D L~^H, unit lower triangular) if tc <= tr; the diagonal threads keep both.  Step j: the owners of row j publish
-// it (S(j, j:) and E(j, :j]) through a double-buffered LDS row, one barrier, then every thread below row j updates its tile
-// with the multipliers m_i = conj(S(j, i)) / d_j: S(i, k) -= m_i S(j, k), E(i, c) -= m_i E(j, c) -- 2 TS^2 FMAs per thread and
-// step, no read-modify-write traffic (an LDS-resident right-looking factorisation moves n^3 / 3 x 24 B through the LDS:
-// 180 us at n = 128 against ~25 here).  Then R = D^-1/2 S (its rows are final when they are published) and
-// R^-1 = E^H D^-1/2.  A pivot that is not above piv_rel times its original diagonal entry raises *flag (the caller then takes
-// the Householder route; everything written is discarded).
-template <class T, int TS, int TG>
-__device__ __forceinline__ void chol_inv_block_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ G, long long ldg, int nb, T* __restrict__ Rout,
-                                                       long long ldr, T* __restrict__ Xout, long long ldx, double piv_rel,
-                                                       int* __restrict__ flag) {
-    constexpr int NBK = TG * TS;
-    __shared__ __attribute__((aligned(16))) T srow[2][NBK];
-    __shared__ __attribute__((aligned(16))) T erow[2][NBK];
-    __shared__ double dg[NBK], d0[NBK];
-    __shared__ int s_bad;
-    const int tid = threadIdx.x, tc = tid % TG, tr = tid / TG;
-    T w[TS][TS], e2[TS][TS];          // w: S tile (tc >= tr) or E tile (tc < tr); e2: E tile of the diagonal threads
-    auto one = []() {
-        T v{};
-        reinterpret_cast<double*>(&v)[0] = 1.0;
-        return v;
-    };
-#pragma unroll
-    for (int a = 0; a < TS; ++a)
-#pragma unroll
-        for (int b = 0; b < TS; ++b) {
-            const int i = TS * tr + a, k = TS * tc + b;
-            T v{};
-            if (tc >= tr) {                                    // S: the block itself (rows / columns beyond nb: identity)
-                if (i < nb && k < nb)
-                    v = i <= k ? G[i + ldg * k] : conj_t(G[k + ldg * i]);
-                else if (i == k)
-                    v = one();
-            } else if (i == k) {
-                v = one();                                     // (never: tc < tr has no diagonal)
-            }
-            w[a][b] = v;
-            e2[a][b] = (tc == tr && a == b) ? one() : T{};
-        }
-    if (tid == 0) s_bad = 0;
-    if (tc == tr)
-#pragma unroll
-        for (int a = 0; a < TS; ++a) d0[TS * tr + a] = reinterpret_cast<const double*>(&w[a][a])[0];
-    __syncthreads();
-    const int ntile = (nb + TS - 1) / TS;
-    for (int jt = 0; jt < ntile; ++jt) {
-#pragma unroll
-        for (int jj = 0; jj < TS; ++jj) {
-            const int j = TS * jt + jj, par = j & 1;
-            if (tr == jt) {                                    // publish row j
-                if (tc >= tr)
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) srow[par][TS * tc + b] = w[jj][b];
-                if (tc < tr)
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) erow[par][TS * tc + b] = w[jj][b];
-                if (tc == tr)
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) erow[par][TS * tc + b] = e2[jj][b];
-            }
-            __syncthreads();
-            if (tr >= jt) {
-                const double d = reinterpret_cast<const double*>(&srow[par][j])[0];
-                const bool dead = !(d > piv_rel * d0[j]);
-                if (tc == jt && tr == jt) {
-                    dg[j] = dead ? 1.0 : d;
-                    if (dead) s_bad = 1;
-                }
-                const double inv = dead ? 0.0 : rcp_refined(d);
-                T mlt[TS];
-#pragma unroll
-                for (int a = 0; a < TS; ++a) {
-                    const int i = TS * tr + a;
-                    mlt[a] = i > j ? scale_t(conj_t(srow[par][i]), inv) : T{};
-                }
-                if (tc >= tr) {
-                    T v[TS];
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) v[b] = srow[par][TS * tc + b];
-#pragma unroll
-                    for (int a = 0; a < TS; ++a)
-#pragma unroll
-                        for (int b = 0; b < TS; ++b) w[a][b] = sub_t(w[a][b], fma_t(mlt[a], v[b], T{}));
-                }
-                if (tc <= jt && tc <= tr) {
-                    T v[TS];
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) v[b] = erow[par][TS * tc + b];
-                    if (tc < tr) {
-#pragma unroll
-                        for (int a = 0; a < TS; ++a)
-#pragma unroll
-                            for (int b = 0; b < TS; ++b) w[a][b] = sub_t(w[a][b], fma_t(mlt[a], v[b], T{}));
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < TS; ++a)
-#pragma unroll
-                            for (int b = 0; b < TS; ++b) e2[a][b] = sub_t(e2[a][b], fma_t(mlt[a], v[b], T{}));
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0 && s_bad) atomicOr(flag, 1);
-    // R(i, k) = S(i, k) / sqrt(d_i) (k >= i);  X(c, i) = conj(E(i, c)) / sqrt(d_i) (c <= i)
-#pragma unroll
-    for (int a = 0; a < TS; ++a)
-#pragma unroll
-        for (int b = 0; b < TS; ++b) {
-            const int i = TS * tr + a, k = TS * tc + b;
-            if (i >= nb || k >= nb) continue;
-            const double rs = rsqrt(dg[i]);
-            if (tc >= tr && i <= k) {
-                T v = scale_t(w[a][b], rs);
-                if (i == k) {
-                    v = T{};
-                    reinterpret_cast<double*>(&v)[0] = sqrt(dg[i]);
-                }
-                Rout[i + ldr * k] = v;
-            }
-            if (tc < tr) Xout[k + ldx * i] = scale_t(conj_t(w[a][b]), rs);
-            if (tc == tr && k <= i) Xout[k + ldx * i] = scale_t(conj_t(e2[a][b]), rs);
-        }
-}
-template <class T, int TS, int TG>
-struct chol_inv_block_k {
-    static constexpr int NT = TG * TG, MINW = 1;
-    template <class... QA>
-    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
-        chol_inv_block_body<T, TS, TG>(b, g, a...);
-    }
-};
-
-// chol_inv_block16: the same 64-column diagonal block (R and R^-1 of a Hermitian positive definite block) with the column
-// chain cut to 16 columns at a time.  The register-tiled elimination above pays one workgroup barrier and an LDS round trip
-// per COLUMN (64 x ~1300 cycles = 35 us per block, the largest single item of a CholeskyQR2 gauge step); here the block
-// lives in LDS as a full Hermitian 64 x 64 array and is factored by 16-column sub-blocks:
+// chol_inv_block16: R and R^-1 of a Hermitian positive definite diagonal block of up to 64 columns in ONE workgroup, with the
+// column chain cut to 16 columns at a time.  (The first version -- a register-tiled elimination of the whole block on 32 x 32
+// threads, one workgroup barrier and an LDS round trip per COLUMN: 64 x ~1300 cycles = 35 us per block, the largest single item
+// of a CholeskyQR2 gauge step -- was removed; this one takes 19 us, tools/micro/chol_block_cost.hip.)  The block lives in LDS
+// as a full Hermitian 64 x 64 array and is factored by 16-column sub-blocks:
 //   D(b)  ONE wave eliminates the 16 x 16 diagonal sub-block of [S | I] in registers (lane (i, g) = four columns of row i):
 //         a step is one reciprocal, the multipliers and the pivot row passed lane to lane (chol16_step) and 8 FMAs -- no
 //         barrier, no LDS; R_bb = D^-1/2 U and X_bb = R_bb^-1 = E^H D^-1/2 go back to LDS;
@@ -2446,11 +2296,11 @@ struct chol_inv_block16_k {
 };
 
 // G (n x n, ld n, Hermitian positive definite; DESTROYED) = R^H R;  Rm (upper triangular, ld n) and Xm = R^-1 (ld n), both
-// zero below the diagonal; *flag (device) is raised on a bad pivot.  Diagonal blocks of 32 TS columns in one workgroup each,
-// the rest by MFMA GEMMs.
-template <class T, int TS, int TG>
-int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag, bool zeroed) {
-    constexpr int NBK = TG * TS;
+// zero below the diagonal (`zeroed`: the caller has cleared them); *flag (device) is raised on a bad pivot.  Diagonal blocks
+// of 64 columns in one workgroup each (chol_inv_block16), panels, trailing updates and the merges of R^-1 by MFMA GEMMs.
+template <class T>
+int chol_inv(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag, bool zeroed = false) {
+    constexpr int NBK = 64;
     if (!zeroed) {
         QIL_TRY(qil_dev_zero(ctx, Rm, (size_t)n * n * sizeof(T)));
         QIL_TRY(qil_dev_zero(ctx, Xm, (size_t)n * n * sizeof(T)));
@@ -2458,12 +2308,7 @@ int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag, bool zer
     const int opH = sizeof(T) == 16 ? 2 : 1;
     for (int j0 = 0; j0 < n; j0 += NBK) {
         const int nbj = std::min(NBK, n - j0), rest = n - j0 - nbj;
-        static const bool sub16 = !(getenv("QIL_CHOL16") && atoi(getenv("QIL_CHOL16")) == 0);
-        if (sub16 && NBK == 64)
-            QIL_TRY((qil_klaunch<chol_inv_block16_k<T>>(ctx, dim3(1), dim3(256), chol16_lds<T>(), (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
-        else
-            QIL_TRY((qil_klaunch<chol_inv_block_k<T, TS, TG>>(ctx, dim3(1), dim3(TG * TG), 0, (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
-        QIL_HIP(hipGetLastError());
+        QIL_TRY((qil_klaunch<chol_inv_block16_k<T>>(ctx, dim3(1), dim3(256), chol16_lds<T>(), (const T*)(G + j0 + (long long)n * j0), (long long)n, nbj, Rm + j0 + (long long)n * j0, (long long)n, Xm + j0 + (long long)n * j0, (long long)n, 1e-11, flag)));
         if (rest > 0) {
             T* Rjr = Rm + j0 + (long long)n * (j0 + nbj);
             // R(j, rest) = R_jj^-H G(j, rest);   G(rest, rest) -= R(j, rest)^H R(j, rest)
@@ -2474,13 +2319,6 @@ int chol_inv_ts(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag, bool zer
         }
     }
     return trtri_merge<T>(ctx, Rm, n, n, Xm, NBK);
-}
-// 64-column diagonal blocks (TS = 2) measured best for both dtypes: compress! on 24 sites, chi 512 -> 256: f64 161.6 ms (TS 4:
-// 166.8, TS 1: 179.1, Householder panels: 197.8), c64 212.6 ms (214.0 / 229.2 / 341.6); chi 256 -> 128: 68.2 / 69.5 / 73.2 / 70.7
-template <class T>
-int chol_inv(qil_context* ctx, T* G, int n, T* Rm, T* Xm, int* flag, bool zeroed = false) {
-    // (4 x 4 tiles on 16 x 16 threads, same 64 columns: chi 256 69.8 against 66.8 ms; 2 x 2 tiles on 16 x 16 threads, 32 columns: 74.1)
-    return chol_inv_ts<T, 2, 32>(ctx, G, n, Rm, Xm, flag, zeroed);
 }
 
 // The second pass of CholeskyQR2 factors G2 = Q1^H Q1 = I + E with |E| ~ kappa(A)^2 eps.  For |E| this small the factor is
@@ -2546,11 +2384,8 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, m, n, n, A, lda, X1, n, Q1, m));
     QIL_TRY(gemm_dispatch<T>(ctx, opH, 0, n, n, m, Q1, m, Q1, m, G, n));
     // second pass: G = I + E; first-order factor while n max |e| <= 3e-8 (|U|^2 below rounding), else the real thing
-    static const bool near_id = !(getenv("QIL_CHOL_NEAR") && atoi(getenv("QIL_CHOL_NEAR")) == 0);
-    if (near_id)
-        QIL_TRY((qil_klaunch<chol_near_identity_k<T>>(ctx, dim3((unsigned)std::min<long long>((n * n + 255) / 256, 1024)), dim3(256), 0, (const T*)G, (int)n, R2, X2, 3e-8 / (double)n, (int*)fl)));
-    else
-        QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
+    // (measured, compress! chi 256 -> 128: 61.8 ms with a second full factorisation, 55.9 ms with this)
+    QIL_TRY((qil_klaunch<chol_near_identity_k<T>>(ctx, dim3((unsigned)std::min<long long>((n * n + 255) / 256, 1024)), dim3(256), 0, (const T*)G, (int)n, R2, X2, 3e-8 / (double)n, (int*)fl)));
     int bad = 0;
     QIL_TRY(qil_read_back(ctx, &bad, fl, sizeof(int)));
     if (!(bad & 1) && (bad & 2)) {

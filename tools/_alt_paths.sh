@@ -4,6 +4,7 @@ run() { echo "== $*"; env "$@" timeout 1200 python3 -m pytest tests -m gpu -q -x
 run QIL_SVD_GRAM=0                       # vector-ALU block rounds instead of the Gram-matrix rounds on the matrix cores
 run QIL_SVD_GRAM=2                       # Gram rounds for complex operands too
 run QIL_QR_CHOL=0                        # Householder / CGS2 panels only
+run QIL_READBACK=0                       # read-backs as copy commands + stream synchronisation instead of the polled tickets
 run QIL_SVD_CERT=0                       # no truncation certificate: every gauge step is an SVD
 run QIL_SVD_LOWRANK=0                    # no certified low-rank route
 run QIL_BATCH_LOCKSTEP=0                 # batches: one stream per chain
