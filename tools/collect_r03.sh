@@ -20,10 +20,16 @@ timeout 900 python3 bench.py --workload dt_sweep_n24_s64 > $O/r03_bench_sweep.js
 QIL_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 50 --no-cpu-baseline --no-truncate > $O/r03_bench_gpus2_gloo_apply.json 2> $O/gloo_apply.err
 QIL_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 10 --workload dt_sweep_n24_s64 --no-cpu-baseline > $O/r03_bench_gpus2_gloo_sweep.json 2> $O/gloo_sweep.err
 timeout 300 python3 tools/_compress_time.py 2>/dev/null > $O/r03_compress_times.txt
-for nb in 8 16 32; do timeout 300 python3 tools/_compress_concurrent.py $nb 256 2>/dev/null | tail -1 >> $O/r03_compress_times.txt; done
+for nb in 8 16 32 64; do timeout 300 python3 tools/_compress_concurrent.py $nb 256 2>/dev/null | tail -1 >> $O/r03_compress_times.txt; done
+timeout 300 python3 tools/_compress_concurrent.py 32 256 same 2>/dev/null | tail -1 | sed 's/^/32 IDENTICAL chains (no divergence between the chains of a group): /' >> $O/r03_compress_times.txt
 QIL_BATCH_LOCKSTEP=0 timeout 300 python3 tools/_compress_concurrent.py 8 256 2>/dev/null | tail -1 | sed 's/^/QIL_BATCH_LOCKSTEP=0: /' >> $O/r03_compress_times.txt
+QIL_READBACK=0 timeout 300 python3 tools/_compress_concurrent.py 8 256 2>/dev/null | tail -1 | sed 's/^/QIL_READBACK=0: /' >> $O/r03_compress_times.txt
 timeout 200 python3 tools/_apply_compress_batch_time.py 2>/dev/null | tail -1 >> $O/r03_compress_times.txt
+timeout 200 python3 tools/_exact_compress_time.py 3 2>/dev/null | tail -1 >> $O/r03_compress_times.txt
+cat /sys/fs/cgroup/cpu.max 2>/dev/null | sed 's/^/cgroup cpu.max of this box (quota period, us): /' >> $O/r03_compress_times.txt
 ./tools/micro/gram_round_cost.bin > $O/r03_gram_round_cost.txt 2>&1
+timeout 300 bash tools/r03_timeline.sh 256 f64 > /dev/null 2>&1; cp $O/timeline_256_f64.txt $O/r03_timeline_256_f64.txt
+timeout 300 bash tools/r03_batch_trace.sh 32 256 > $O/r03_batch_trace_32.txt 2>&1
 # (the tracer crashes on this multi-threaded workload about one run in three, whatever the library: retry)
 : > $O/r03_batch_occupancy.jsonl
 ( cd /tmp && export TMPDIR=/tmp
