@@ -398,7 +398,13 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
             const bool fills = (double)m * (double)n >= 0.85 * 16384.0 * (double)t128;   // little padding in edge tiles
             if (t128 * batch.count >= 512 && fills) QIL_GEMM_GO(128, 128, 64, 64, true);
         }
-        if (m >= 256) QIL_GEMM_GO(128, 64, 64, 32, true);
+        // 128 x 64 tiles only when they still give every CU a workgroup: a product that fills a fraction of the chip is bound by
+        // the time of ONE tile on its CU, and a 64 x 64 tile takes half of it
+        {
+            constexpr long long min_tiles = 128;   // (measured, compress! chi 256 / 512: always 51.9 / 131.1 ms; from 64, 256 or 1024 tiles on: 49.4-50.4 / 123.1 ms)
+            const long long t = ((m + 127) / 128) * ((n + 63) / 64) * batch.count;
+            if (m >= 256 && t >= min_tiles) QIL_GEMM_GO(128, 64, 64, 32, true);
+        }
         QIL_GEMM_GO(64, 64, 32, 32, true);
     }
 #undef QIL_GEMM_GO
