@@ -384,6 +384,12 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
     constexpr bool CX = sizeof(T) == 16;
 #define QIL_GEMM_GO(BM, BN, WM, WN, PIPE) \
     return gemm_launch<T, BM, BN, WM, WN, PIPE>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch)
+    // few output tiles (the 256 x 256 products of the gauge steps: 16 tiles of 64 x 64): a product that leaves most of the chip
+    // idle is bound by the K loop of ONE tile on its CU (32 MFMAs per wave and 32-deep K step at 64 x 64, 8 at 32 x 32)
+    // (measured, up to 0 / 16 / 32 / 64 tiles of 64 x 64 as 32 x 32 tiles: compress! chi 256 f64 49.5 / 46.2 / 45.6 / 46.1 ms, c64 66.2 /
+    // 61.5 / 59.6 / 61.0, chi 512 f64 122.3 / 118.0 / 115.7 / 114.5, c64 165.9 / 151.8 / 148.1 / 142.6, fused apply-and-truncate 147 / 131 / 128 / 129)
+    constexpr long long small_tiles = 64;
+    if (((m + 63) / 64) * ((n + 63) / 64) * batch.count <= small_tiles && m >= 32 && n >= 32) QIL_GEMM_GO(32, 32, 16, 16, true);
     if constexpr (CX) {
         QIL_GEMM_GO(64, 64, 32, 32, true);      // pipelined: equal on big squares, 56 vs 45 TFLOP/s on 64 x 16384 x 8192
     } else {
