@@ -60,7 +60,7 @@ __device__ __forceinline__ c64 maybe_conj(c64 v, int cj) { return cj ? c64{v.re,
 
 // ARC / BKC: op(A)'s row index / op(B)'s k index is the contiguous one in memory (compile time, so that the staging
 // pattern -- which element of the tile a thread loads and where it lands in LDS -- folds into constants).
-template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC>
+template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC, int GKT = GK>
 __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3 gridDim, long long m, long long n, long long k_total,
                                                  const T* __restrict__ A, long long a_rs, long long a_ks, int conjA,
                                                  const T* __restrict__ B, long long b_ks, long long b_cs, int conjB,
@@ -76,11 +76,11 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                                               // staging writes and the fragment reads
     constexpr int NBUF = PIPE ? 2 : 1;
     constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr int EA = BM * GK / 256, EB = BN * GK / 256;
+    constexpr int EA = BM * GKT / 256, EB = BN * GKT / 256;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
-    double* As = reinterpret_cast<double*>(gemm_smem);            // [NBUF][NP][GK][LA]
-    double* Bs = As + NBUF * NP * GK * LA;                         // [NBUF][NP][GK][LB]
+    double* As = reinterpret_cast<double*>(gemm_smem);            // [NBUF][NP][GKT][LA]
+    double* Bs = As + NBUF * NP * GKT * LA;                         // [NBUF][NP][GKT][LB]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = (wave % (BM / WM)) * WM, wc = (wave / (BM / WM)) * WN;
@@ -140,8 +140,8 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
         const int idx = tid + 256 * e;
-        const int i = a_rows_contig ? idx % BM : idx / GK;
-        const int kk = a_rows_contig ? idx / BM : idx % GK;
+        const int i = a_rows_contig ? idx % BM : idx / GKT;
+        const int kk = a_rows_contig ? idx / BM : idx % GKT;
         const long long gr = row0 + i;
         ka[e] = kk;
         sa[e] = kk * LA + i;
@@ -150,14 +150,14 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
         const int idx = tid + 256 * e;
-        const int kk = b_k_contig ? idx % GK : idx / BN;
-        const int j = b_k_contig ? idx / GK : idx % BN;
+        const int kk = b_k_contig ? idx % GKT : idx / BN;
+        const int j = b_k_contig ? idx / GKT : idx % BN;
         const long long gc = col0 + j;
         kb[e] = kk;
         sb[e] = kk * LB + j;
         pb[e] = B + (kbeg + kk) * b_ks + min(gc, n - 1) * b_cs;
     }
-    const long long a_step = (long long)GK * a_ks, b_step = (long long)GK * b_ks;
+    const long long a_step = (long long)GKT * a_ks, b_step = (long long)GKT * b_ks;
     // Edges.  Rows / columns beyond the matrix are CLAMPED to the last valid one when the pointers are set up: such
     // lanes load real data that only ever reaches C entries the epilogue does not store, so the M / N edges need no
     // predicate at all.  Only the K edge matters (a partial last tile would add garbage to valid entries): full
@@ -165,7 +165,7 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
     // address per lane and zeroes the k-invalid elements when the tile is staged.  Nothing touches a loaded value
     // before store_tile, so the loads stay in flight across the MFMAs of the current tile.
     auto load_tile = [&](long long k0) {
-        if (k0 + GK <= kend) {
+        if (k0 + GKT <= kend) {
 #pragma unroll
             for (int e = 0; e < EA; ++e) {
                 ra[e] = *pa[e];
@@ -184,46 +184,46 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
         }
     };
     auto store_tile = [&](int buf, long long k0) {     // k0 = first k of the tile held in ra / rb
-        double* a0 = As + (buf * NP) * GK * LA;
-        double* b0 = Bs + (buf * NP) * GK * LB;
-        if (k0 + GK <= kend) {
+        double* a0 = As + (buf * NP) * GKT * LA;
+        double* b0 = Bs + (buf * NP) * GKT * LB;
+        if (k0 + GKT <= kend) {
 #pragma unroll
-            for (int e = 0; e < EA; ++e) put_plane(a0, a0 + GK * LA, sa[e], maybe_conj(ra[e], conjA));
+            for (int e = 0; e < EA; ++e) put_plane(a0, a0 + GKT * LA, sa[e], maybe_conj(ra[e], conjA));
 #pragma unroll
-            for (int e = 0; e < EB; ++e) put_plane(b0, b0 + GK * LB, sb[e], maybe_conj(rb[e], conjB));
+            for (int e = 0; e < EB; ++e) put_plane(b0, b0 + GKT * LB, sb[e], maybe_conj(rb[e], conjB));
         } else {
 #pragma unroll
             for (int e = 0; e < EA; ++e)
-                put_plane(a0, a0 + GK * LA, sa[e], (k0 + ka[e] < kend) ? maybe_conj(ra[e], conjA) : T{});
+                put_plane(a0, a0 + GKT * LA, sa[e], (k0 + ka[e] < kend) ? maybe_conj(ra[e], conjA) : T{});
 #pragma unroll
             for (int e = 0; e < EB; ++e)
-                put_plane(b0, b0 + GK * LB, sb[e], (k0 + kb[e] < kend) ? maybe_conj(rb[e], conjB) : T{});
+                put_plane(b0, b0 + GKT * LB, sb[e], (k0 + kb[e] < kend) ? maybe_conj(rb[e], conjB) : T{});
         }
     };
     int buf = 0;
     if (PIPE && kbeg < kend) load_tile(kbeg);
-    for (long long k0 = kbeg; k0 < kend; k0 += GK) {
+    for (long long k0 = kbeg; k0 < kend; k0 += GKT) {
         if (!PIPE) {
             if (k0 > kbeg) __syncthreads();         // everyone is done reading the single buffer
             load_tile(k0);
         }
         store_tile(buf, k0);
         __syncthreads();
-        if (PIPE && k0 + GK < kend) load_tile(k0 + GK);     // in flight during the MFMAs below
-        const double* a0 = As + (buf * NP) * GK * LA;
-        const double* b0 = Bs + (buf * NP) * GK * LB;
+        if (PIPE && k0 + GKT < kend) load_tile(k0 + GKT);     // in flight during the MFMAs below
+        const double* a0 = As + (buf * NP) * GKT * LA;
+        const double* b0 = Bs + (buf * NP) * GKT * LB;
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 4) {
+        for (int kk = 0; kk < GKT; kk += 4) {
             double are[TM], aim[TM], bre[TN], bim[TN];
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 are[t] = a0[(kk + l4) * LA + wr + 16 * t + l15];
-                if (CX) aim[t] = a0[GK * LA + (kk + l4) * LA + wr + 16 * t + l15];
+                if (CX) aim[t] = a0[GKT * LA + (kk + l4) * LA + wr + 16 * t + l15];
             }
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
                 bre[t] = b0[(kk + l4) * LB + wc + 16 * t + l15];
-                if (CX) bim[t] = b0[GK * LB + (kk + l4) * LB + wc + 16 * t + l15];
+                if (CX) bim[t] = b0[GKT * LB + (kk + l4) * LB + wc + 16 * t + l15];
             }
 #pragma unroll
             for (int ti = 0; ti < TM; ++ti)
@@ -267,12 +267,12 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                 }
             }
 }
-template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC>
+template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC, int GKT = GK>
 struct gemm_mfma_k {
     static constexpr int NT = 256, MINW = (BM * BN <= 128 * 128 ? 2 : 1);
     template <class... QA>
     static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
-        gemm_mfma_body<T, BM, BN, WM, WN, PIPE, ARC, BKC>(b, g, a...);
+        gemm_mfma_body<T, BM, BN, WM, WN, PIPE, ARC, BKC, GKT>(b, g, a...);
     }
 };
 
@@ -307,12 +307,12 @@ struct gemm_batch {
     int subtract = 0;                   // 1: C <- C - op(A) op(B)  (the projection step of the blocked QR, no temporary)
 };
 
-template <class T, int BM, int BN, int WM, int WN, bool PIPE>
+template <class T, int BM, int BN, int WM, int WN, bool PIPE, int GKT = GK>
 int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T* A, long long a_rs,
                 long long a_ks, int conjA, const T* B, long long b_ks, long long b_cs, int conjB, T* C,
                 long long ldc, const gemm_batch& bt) {
     constexpr int NP = sizeof(T) == 16 ? 2 : 1;
-    constexpr size_t lds = (size_t)(PIPE ? 2 : 1) * NP * GK * ((BM + GPAD) + (BN + GPAD)) * sizeof(double);
+    constexpr size_t lds = (size_t)(PIPE ? 2 : 1) * NP * GKT * ((BM + GPAD) + (BN + GPAD)) * sizeof(double);
     const bool arc = a_rs == 1, bkc = b_ks == 1;
     const long long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
     const long long tiles = tiles_m * tiles_n;
@@ -340,7 +340,7 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     long long ldo = ldc;
     void* wsp = nullptr;
     if (splits > 1) {
-        kchunk = (((k + splits - 1) / splits) + GK - 1) / GK * GK;
+        kchunk = (((k + splits - 1) / splits) + GKT - 1) / GKT * GKT;
         splits = (int)((k + kchunk - 1) / kchunk);
         cstride = m * n * bt.count;
         c_bs = m * n;
@@ -352,7 +352,7 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     static const bool xcd_order = true;
     const int col_fastest = (tiles_n <= 8 ? 1 : 0) | (xcd_order ? 0 : 2);
 #define QIL_GEMM_K(ARCv, BKCv)                                                                                               \
-    QIL_TRY((qil_klaunch<gemm_mfma_k<T, BM, BN, WM, WN, PIPE, ARCv, BKCv>>(                                                      \
+    QIL_TRY((qil_klaunch<gemm_mfma_k<T, BM, BN, WM, WN, PIPE, ARCv, BKCv, GKT>>(                                                      \
         ctx, dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits), dim3(256), lds, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, \
         b_cs, conjB, Cout, ldo, kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,        \
         bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride, splits > 1 ? 0 : bt.subtract)))
@@ -389,7 +389,9 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
     // (measured, up to 0 / 16 / 32 / 64 tiles of 64 x 64 as 32 x 32 tiles: compress! chi 256 f64 49.5 / 46.2 / 45.6 / 46.1 ms, c64 66.2 /
     // 61.5 / 59.6 / 61.0, chi 512 f64 122.3 / 118.0 / 115.7 / 114.5, c64 165.9 / 151.8 / 148.1 / 142.6, fused apply-and-truncate 147 / 131 / 128 / 129)
     constexpr long long small_tiles = 64;
-    if (((m + 63) / 64) * ((n + 63) / 64) * batch.count <= small_tiles && m >= 32 && n >= 32) QIL_GEMM_GO(32, 32, 16, 16, true);
+    // (K step of the small tiles 16 / 32 / 64: compress! chi 256 46.5 / 45.3 / 45.2 ms, chi 512 115.1 / 111.7 / 112.1, exact route 300 / 293 / 294)
+    if (((m + 63) / 64) * ((n + 63) / 64) * batch.count <= small_tiles && m >= 32 && n >= 32)
+        return gemm_launch<T, 32, 32, 16, 16, true, 32>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch);
     if constexpr (CX) {
         QIL_GEMM_GO(64, 64, 32, 32, true);      // pipelined: equal on big squares, 56 vs 45 TFLOP/s on 64 x 16384 x 8192
     } else {
