@@ -2853,22 +2853,32 @@ __device__ __forceinline__ void gram_block_round_body(const gram_round_args<T>& 
         const int nks = mpad / 4;
         d4 rr2 = {0, 0, 0, 0}, ii2 = {0, 0, 0, 0}, ri2 = {0, 0, 0, 0};   // second accumulator set: no dependent MFMA chain
         int ks = ks0;
-        for (; ks + KSP < nks; ks += 2 * KSP) {
-            const T av = xa[4 * ks], bv = xb[4 * ks];
-            const T av2 = xa[4 * (ks + KSP)], bv2 = xb[4 * (ks + KSP)];
-            if constexpr (CX) {
-                // G = (ar - i ai)^T (br + i bi):  re = ar br + ai bi,  im = ar bi - ai br
-                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.re, rr, 0, 0, 0);
-                rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2.re, bv2.re, rr2, 0, 0, 0);
-                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.im, rr, 0, 0, 0);
-                rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2.im, bv2.im, rr2, 0, 0, 0);
-                ri = __builtin_amdgcn_mfma_f64_16x16x4f64(av.re, bv.im, ri, 0, 0, 0);
-                ri2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2.re, bv2.im, ri2, 0, 0, 0);
-                ii = __builtin_amdgcn_mfma_f64_16x16x4f64(av.im, bv.re, ii, 0, 0, 0);
-                ii2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2.im, bv2.re, ii2, 0, 0, 0);
-            } else {
-                rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, rr, 0, 0, 0);
-                rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av2, bv2, rr2, 0, 0, 0);
+        // eight K steps per trip: all sixteen fragment reads are issued before the first MFMA (one LDS latency per trip
+        // instead of one per step: 6 800 -> see tools/micro/gram_round_cost.hip), two accumulator sets alternate
+        constexpr int UNR = 8;
+        for (; ks + (UNR - 1) * KSP < nks; ks += UNR * KSP) {
+            T av[UNR], bv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                av[u] = xa[4 * (ks + u * KSP)];
+                bv[u] = xb[4 * (ks + u * KSP)];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u += 2) {
+                if constexpr (CX) {
+                    // G = (ar - i ai)^T (br + i bi):  re = ar br + ai bi,  im = ar bi - ai br
+                    rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].re, bv[u].re, rr, 0, 0, 0);
+                    rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1].re, bv[u + 1].re, rr2, 0, 0, 0);
+                    rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].im, bv[u].im, rr, 0, 0, 0);
+                    rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1].im, bv[u + 1].im, rr2, 0, 0, 0);
+                    ri = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].re, bv[u].im, ri, 0, 0, 0);
+                    ri2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1].re, bv[u + 1].im, ri2, 0, 0, 0);
+                    ii = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].im, bv[u].re, ii, 0, 0, 0);
+                    ii2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1].im, bv[u + 1].re, ii2, 0, 0, 0);
+                } else {
+                    rr = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], rr, 0, 0, 0);
+                    rr2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bv[u + 1], rr2, 0, 0, 0);
+                }
             }
         }
         for (; ks < nks; ks += KSP) {
