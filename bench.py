@@ -287,7 +287,7 @@ def truncate_block(qil, ctx, reps=3, cpu=True):
         ctx.synchronize()
         t_eight = time.perf_counter() - t0
         del eight
-        for nbig in (16, 32):
+        for nbig in (16, 32, 64):
             many = chains(nbig)
             ctx.synchronize()
             t0 = time.perf_counter()
@@ -357,7 +357,8 @@ def truncate_block(qil, ctx, reps=3, cpu=True):
         "batch_of_8_over_single": t_eight / t_one,
         "compress_batch_of_16_ms": t_many[16] * 1e3, "batch_of_16_over_single": t_many[16] / t_one,
         "compress_batch_of_32_ms": t_many[32] * 1e3, "batch_of_32_over_single": t_many[32] / t_one,
-        "chains_per_s_batch_of_32": 32 / t_many[32], "chains_per_s_single": 1 / t_one,
+        "compress_batch_of_64_ms": t_many[64] * 1e3, "batch_of_64_over_single": t_many[64] / t_one,
+        "chains_per_s_batch_of_32": 32 / t_many[32], "chains_per_s_batch_of_64": 64 / t_many[64], "chains_per_s_single": 1 / t_one,
         "cpu_baseline": cpu_res,
         "roofline": truncate_roofline(t_exact, t_one, f_exact, f_fused, t_fused),
     }

@@ -33,7 +33,7 @@ timeout 300 bash tools/r03_batch_trace.sh 32 256 > $O/r03_batch_trace_32.txt 2>&
 # (the tracer crashes on this multi-threaded workload about one run in three, whatever the library: retry)
 : > $O/r03_batch_occupancy.jsonl
 ( cd /tmp && export TMPDIR=/tmp
-  for nb in 8 32; do
+  for nb in 8 32 64; do
   for try in 1 2 3 4; do
     rm -rf $O/p2
     timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/p2 -- python3 $R/tools/_batch_occupancy.py run $nb 256 > $O/p2.log 2>&1
