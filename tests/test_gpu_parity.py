@@ -1123,6 +1123,24 @@ def test_qr_full_rank_matches_lapack_up_to_phase(qil):
         assert np.abs(Q - Qn * sg).max() < 1e-10 and np.abs(R - Rn * sg[:, None]).max() < 1e-9
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("decades", [0.5, 3.0, 4.5, 7.0])
+def test_qr_cholesky_route_across_conditioning(qil, cplx, decades):
+    """CholeskyQR2 (qr_impl, 64..1024 columns) over operands whose conditioning walks through its three regimes: the first-order
+    second pass (kappa^2 eps n below 3e-8), the full second factorisation (above), and the refusal on a pivot below 1e-11 of its
+    diagonal entry (Householder panels take over).  Whatever route: Q orthonormal to rounding, Q R = A, R upper triangular with
+    a positive diagonal."""
+    rng = np.random.default_rng(int(10 * decades) + cplx)
+    m, n = 512, 128
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)) + (1j * rng.standard_normal((m, n)) if cplx else 0))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0))
+    A = (U * np.logspace(0, -decades, n)) @ V.conj().T
+    Q, R = qil.qr_positive(A)
+    assert np.abs(Q.conj().T @ Q - np.eye(n)).max() < 5e-13
+    assert np.abs(Q @ R - A).max() < 1e-13
+    assert np.abs(np.tril(R, -1)).max() == 0 and np.all(np.diag(R).real > 0) and np.abs(np.diag(R).imag).max() < 1e-15
+
+
 def test_rsvd_wide_sketch_on_low_rank_signal(qil):
     """README quick start: a rank-2 structured signal with the default sketch (l = 30 of 32 columns)."""
     n = 10
