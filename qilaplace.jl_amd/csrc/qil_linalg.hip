@@ -3141,6 +3141,177 @@ int launch_gram_round(qil_context* ctx, T* X, long long ldx, int k, int nblk, in
 // singular value, S on the host, SVh (k x q) = diag(S) V^H.  Serves 97 <= k < 640 (and smaller k whose general path would not be LDS-resident) with the columns in LDS;
 // *handled = 0 (nothing touched beyond B's contents being intact) sends the caller to the general svd_impl.
 template <class T>
+int svd_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* U, long long ldu, double* S_host, T* Vh,
+             long long ldvh, double negl_rel);
+
+// svd_left_mid's route for rank-deficient triangular factors (see there): R (k x k, ld k) = thin-QR factor of the tall operand,
+// Q (p x k, ldq) its basis, Xw (k x k workspace).  *done = 0: too few negligible rows, nothing written.
+template <class T>
+int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb, T* Uiso, long long ldu, double* S_host,
+                 T* SVh, long long ldsvh, double negl_rel, int* handled, double cert_cutoff);
+template <class T>
+int svd_left_deflated(qil_context* ctx, long long p, long long k, const T* Q, long long ldq, const T* R, T* Xw, T* Uiso,
+                      long long ldu, double* S_host, T* SVh, long long ldsvh, double negl_rel, bool dbg, int* done) {
+    *done = 0;
+    const int dtype = sizeof(T) == 16 ? QIL_C64 : QIL_F64;
+    const unsigned gk = (unsigned)std::min<long long>((k * k + 255) / 256, 65536);
+    // the rows of R as the columns of Xw = R^H, their squared norms to the host
+    void* nrm = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * sizeof(double), &nrm));
+    QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3(gk), dim3(256), 0, R, k, k, k, Xw, k)));
+    QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)k), dim3(256), 0, (const T*)Xw, k, k, (double*)nrm)));
+    std::vector<double> rn((size_t)k);
+    const int rst = qil_read_back(ctx, rn.data(), nrm, (size_t)k * sizeof(double));
+    qil_ctx_free(ctx, nrm);
+    QIL_TRY(rst);
+    double total = 0.0;
+    for (double& v : rn) {
+        v *= v;                                                  // (col_norms_k returns norms)
+        total += v;
+    }
+    std::vector<int> order((size_t)k);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rn[(size_t)a] < rn[(size_t)b]; });
+    std::vector<char> drop((size_t)k, 0);
+    double acc = 0.0;
+    long long ndrop = 0;
+    for (int j : order) {
+        if (!(acc + rn[(size_t)j] <= ctx->svd_deflate * total)) break;
+        acc += rn[(size_t)j];
+        drop[(size_t)j] = 1;
+        ++ndrop;
+    }
+    const long long r = k - ndrop;
+    if (dbg) fprintf(stderr, "[svd-left] deflation: %lld of %lld rows of R carry all but %.1e of the weight\n", r, k, total > 0 ? acc / total : 0.0);
+    // (measured on the exact compress! of the bond-1008 zT product, deflating when at most 0.6 / 0.75 / 0.9 / 0.97 / 0.995 of the
+    // rows stay: 279 / 291 / 268 / 252 / 252 ms, 295 without: even 10 % negligible rows are worth it -- what goes is the
+    // degenerate cluster the sweeps crawl on)
+    if (r < 1 || (double)r > 0.97 * (double)k) return QIL_OK;
+    std::vector<int> keep;
+    keep.reserve((size_t)r);
+    for (long long j = 0; j < k; ++j)
+        if (!drop[(size_t)j]) keep.push_back((int)j);            // in the original order
+    void *hp = nullptr, *dp = nullptr, *bk = nullptr, *uk = nullptr, *svk = nullptr, *qk = nullptr;
+    auto release = [&]() {
+        for (void* b : {bk, uk, svk, qk})
+            if (b) qil_ctx_free(ctx, b);
+    };
+    int slot = -1;
+    QIL_TRY(qil_stage_acquire(ctx, (size_t)r * sizeof(int), &hp, &dp, &slot));
+    memcpy(hp, keep.data(), (size_t)r * sizeof(int));
+    QIL_TRY(qil_stage_push(ctx, slot, (size_t)r * sizeof(int)));
+    const int* keepd = static_cast<const int*>(dp);
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * k) * sizeof(T), &bk));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * r) * sizeof(T), &uk));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * k) * sizeof(T), &svk));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(p * r) * sizeof(T), &qk));
+    T *Bk = static_cast<T*>(bk), *Uk = static_cast<T*>(uk), *SVk = static_cast<T*>(svk), *Qk = static_cast<T*>(qk);
+    // Bk = R[K, :] (r x k) = (Xw[:, K])^H;  Qk = Q[:, K]
+    QIL_TRY((qil_klaunch<gather_cols_k<T>>(ctx, dim3(gk), dim3(256), 0, (const T*)Xw, k, k, keepd, (const double*)nullptr, Bk, r, (int)r, 1)));
+    QIL_TRY((qil_klaunch<gather_cols_k<T>>(ctx, dim3((unsigned)std::min<long long>((p * r + 255) / 256, 65536)), dim3(256), 0, Q, ldq, p, keepd, (const double*)nullptr, Qk, p, (int)r, 0)));
+    qil_stage_commit(ctx, slot);
+    // one-factor SVD of the wide block: Bk = Uk diag(S) V^H, SVk = diag(S) V^H
+    int h2 = 0;
+    int st = svd_left_mid<T>(ctx, r, k, Bk, r, Uk, r, S_host, SVk, r, negl_rel, &h2, 0.0);
+    if (st == QIL_OK && !h2) {                                   // outside the one-factor routine's range: the general SVD
+        st = svd_impl<T>(ctx, r, k, Bk, r, Uk, r, S_host, SVk, r, negl_rel);
+        if (st == QIL_OK) st = qil_dev_scale(ctx, dtype, 0, r, k, SVk, r, S_host);
+    }
+    if (st != QIL_OK) {
+        release();
+        return st;
+    }
+    for (long long j = r; j < k; ++j) S_host[j] = 0.0;
+    // Uiso = [Q[:, K] Uk, 0],  S V^H = [SVk; 0]
+    st = gemm_dispatch<T>(ctx, 0, 0, p, r, r, Qk, p, Uk, r, Uiso, ldu);
+    if (st == QIL_OK) st = qil_dev_zero2d(ctx, Uiso + ldu * r, (size_t)ldu * sizeof(T), (size_t)p * sizeof(T), (size_t)(k - r));
+    if (st == QIL_OK) st = qil_dev_zero2d(ctx, SVh, (size_t)ldsvh * sizeof(T), (size_t)k * sizeof(T), (size_t)k);
+    if (st == QIL_OK) st = qil_dev_copy2d(ctx, SVh, (size_t)ldsvh * sizeof(T), SVk, (size_t)r * sizeof(T), (size_t)r * sizeof(T), (size_t)k);
+    release();
+    QIL_TRY(st);
+    *done = 1;
+    return QIL_OK;
+}
+
+// The same for a WIDE operand B (k x q, k < q), B^H = Q R: B = X Q^H with X = R^H (k x k), whose COLUMNS are the rows of R.
+// Negligible columns of X are dropped (exactly their weight), X[:, K] = U' S' V'^H (tall, k x r) gives U = U' and
+// S V^H = (S' V'^H) Q[:, K]^H.  Q (q x k, ldq); X is left intact.  *done = 0: nothing written.
+template <class T>
+int svd_left_deflated_wide(qil_context* ctx, long long k, long long q, const T* Q, long long ldq, const T* X, T* Uiso, long long ldu,
+                           double* S_host, T* SVh, long long ldsvh, double negl_rel, bool dbg, int* done) {
+    *done = 0;
+    const int dtype = sizeof(T) == 16 ? QIL_C64 : QIL_F64;
+    void* nrm = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)k * sizeof(double), &nrm));
+    QIL_TRY((qil_klaunch<col_norms_k<T>>(ctx, dim3((unsigned)k), dim3(256), 0, X, k, k, (double*)nrm)));
+    std::vector<double> rn((size_t)k);
+    const int rst = qil_read_back(ctx, rn.data(), nrm, (size_t)k * sizeof(double));
+    qil_ctx_free(ctx, nrm);
+    QIL_TRY(rst);
+    double total = 0.0;
+    for (double& v : rn) {
+        v *= v;
+        total += v;
+    }
+    std::vector<int> order((size_t)k);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rn[(size_t)a] < rn[(size_t)b]; });
+    std::vector<char> drop((size_t)k, 0);
+    double acc = 0.0;
+    long long ndrop = 0;
+    for (int j : order) {
+        if (!(acc + rn[(size_t)j] <= ctx->svd_deflate * total)) break;
+        acc += rn[(size_t)j];
+        drop[(size_t)j] = 1;
+        ++ndrop;
+    }
+    const long long r = k - ndrop;
+    if (dbg) fprintf(stderr, "[svd-left] deflation (wide): %lld of %lld rows of R carry all but %.1e of the weight\n", r, k, total > 0 ? acc / total : 0.0);
+    if (r < 1 || (double)r > 0.97 * (double)k) return QIL_OK;
+    std::vector<int> keep;
+    keep.reserve((size_t)r);
+    for (long long j = 0; j < k; ++j)
+        if (!drop[(size_t)j]) keep.push_back((int)j);
+    void *hp = nullptr, *dp = nullptr, *xk = nullptr, *uk = nullptr, *svk = nullptr, *qk = nullptr;
+    auto release = [&]() {
+        for (void* b : {xk, uk, svk, qk})
+            if (b) qil_ctx_free(ctx, b);
+    };
+    int slot = -1;
+    QIL_TRY(qil_stage_acquire(ctx, (size_t)r * sizeof(int), &hp, &dp, &slot));
+    memcpy(hp, keep.data(), (size_t)r * sizeof(int));
+    QIL_TRY(qil_stage_push(ctx, slot, (size_t)r * sizeof(int)));
+    const int* keepd = static_cast<const int*>(dp);
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * r) * sizeof(T), &xk));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(k * r) * sizeof(T), &uk));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(r * r) * sizeof(T), &svk));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(q * r) * sizeof(T), &qk));
+    T *Xk = static_cast<T*>(xk), *Uk = static_cast<T*>(uk), *SVk = static_cast<T*>(svk), *Qk = static_cast<T*>(qk);
+    QIL_TRY((qil_klaunch<gather_cols_k<T>>(ctx, dim3((unsigned)std::min<long long>((k * r + 255) / 256, 65536)), dim3(256), 0, X, k, k, keepd, (const double*)nullptr, Xk, k, (int)r, 0)));
+    QIL_TRY((qil_klaunch<gather_cols_k<T>>(ctx, dim3((unsigned)std::min<long long>((q * r + 255) / 256, 65536)), dim3(256), 0, Q, ldq, q, keepd, (const double*)nullptr, Qk, q, (int)r, 0)));
+    qil_stage_commit(ctx, slot);
+    int h2 = 0;
+    int st = svd_left_mid<T>(ctx, k, r, Xk, k, Uk, k, S_host, SVk, r, negl_rel, &h2, 0.0);
+    if (st == QIL_OK && !h2) {
+        st = svd_impl<T>(ctx, k, r, Xk, k, Uk, k, S_host, SVk, r, negl_rel);
+        if (st == QIL_OK) st = qil_dev_scale(ctx, dtype, 0, r, r, SVk, r, S_host);
+    }
+    if (st != QIL_OK) {
+        release();
+        return st;
+    }
+    for (long long j = r; j < k; ++j) S_host[j] = 0.0;
+    st = qil_dev_zero2d(ctx, Uiso, (size_t)ldu * sizeof(T), (size_t)k * sizeof(T), (size_t)k);
+    if (st == QIL_OK) st = qil_dev_copy2d(ctx, Uiso, (size_t)ldu * sizeof(T), Uk, (size_t)k * sizeof(T), (size_t)k * sizeof(T), (size_t)r);
+    if (st == QIL_OK) st = qil_dev_zero2d(ctx, SVh, (size_t)ldsvh * sizeof(T), (size_t)k * sizeof(T), (size_t)q);
+    if (st == QIL_OK) st = gemm_dispatch<T>(ctx, 0, 2, r, q, r, SVk, r, Qk, q, SVh, ldsvh);
+    release();
+    QIL_TRY(st);
+    *done = 1;
+    return QIL_OK;
+}
+
+template <class T>
 int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb, T* Uiso, long long ldu, double* S_host,
                  T* SVh, long long ldsvh, double negl_rel, int* handled, double cert_cutoff) {
     *handled = 0;
@@ -3252,6 +3423,24 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             static const double grade_max = 1e24;
             qr2 = std::isfinite(fro2) && fro2 > grade * (double)k * dmin && fro2 < grade_max * (double)k * dmin;
             if (dbg) fprintf(stderr, "[svd-left] %lld x %lld: mean / min |r_ii|^2 = %.3g -> %s\n", p, q, fro2 / ((double)k * std::max(dmin, 1e-300)), qr2 ? "second QR" : "rotate R");
+            // A numerically RANK-DEFICIENT factor that is about to be truncated by a cutoff (product bonds before their
+            // truncation): rotating the k columns of R crawls (14-18 sweeps at 128 columns: the null space is a k - r fold
+            // degenerate cluster), and most of the work is spent on directions the cutoff discards.  The rows of R say which:
+            // dropping the rows with the smallest norms changes A by EXACTLY their weight (A = Q R), so rows are dropped while
+            // their weight stays below ctx->svd_deflate (1e-3 of the caller's cutoff) of the total, and the one-factor SVD of
+            // the remaining r x k block -- a wide, full-rank operand: QR of its r columns, r x r rotations -- gives the same
+            // factors: U = Q[:, K] U_K, S V^H = S_K V_K^H.
+            const bool deficient = std::isfinite(fro2) && fro2 >= grade_max * (double)k * dmin;
+            if (deficient && ctx->svd_deflate > 0.0) {                // (such a factor never passes the certificate: min |r_ii| settles it)
+                int done = 0;
+                QIL_TRY((svd_left_deflated<T>(ctx, p, k, Qm, ldq, R, X, Uiso, ldu, S_host, SVh, ldsvh, negl_rel, dbg, &done)));
+                if (done) {
+                    lap("deflated route");
+                    release();
+                    *handled = 1;
+                    return QIL_OK;
+                }
+            }
         }
         if (qr2) {
             // R^H = Q1 R1; the columns of X = R1^H are rotated (R = X Q1^H has the same left singular vectors)
@@ -3277,6 +3466,16 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             return QIL_OK;
         }
         QIL_TRY((qil_klaunch<conj_transpose_k<T>>(ctx, dim3(gk), dim3(256), 0, (const T*)R, k, k, k, X, k)));
+        if (ctx->svd_deflate > 0.0 && k >= 64) {                 // rank-deficient products: the negligible rows of R leave the problem
+            int done = 0;
+            QIL_TRY((svd_left_deflated_wide<T>(ctx, k, q, static_cast<const T*>(bh), q, X, Uiso, ldu, S_host, SVh, ldsvh, negl_rel, dbg, &done)));
+            if (done) {
+                lap("deflated route (wide)");
+                release();
+                *handled = 1;
+                return QIL_OK;
+            }
+        }
     }
     lap("QR");
     qil_progress_phase(ctx, 3);

@@ -230,6 +230,11 @@ int svd_trunc_dev(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, in
     // Gauge sweeps keep ONE factor as the site (isometric) and multiply the other into the neighbour: the mid-size path
     // that accumulates no rotation matrix (qil_dev_svd_left) serves them; everything else takes the general SVD.
     int handled = 0;
+    struct deflate_scope {                                       // the one-factor SVD may drop 1e-3 of what the cutoff allows
+        qil_context* c;
+        ~deflate_scope() { c->svd_deflate = 0.0; }
+    } dscope{ctx};
+    ctx->svd_deflate = (use_cutoff && cutoff > 0.0) ? 1e-3 * cutoff : 0.0;
     if (absorb == 2) {            // U isometric, S Vh absorbed
         QIL_TRY(qil_dev_svd_left(ctx, dtype, m, n, A, lda, U, m, S.data(), Vh, r0, negl_rel, &handled, cert_cutoff));
     } else if (absorb == 1) {     // Vh isometric, U S absorbed: the same problem on A^H

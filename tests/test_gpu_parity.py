@@ -1824,6 +1824,40 @@ def test_compress_wide_bonds_against_oracle(qil, L, chi, maxdim, dtype):
     assert np.abs(got - want).max() < 1e-7 * scale
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("chi,rank", [(160, 60), (130, 110), (260, 40)])
+def test_compress_rank_deficient_bonds_take_the_deflated_svd(qil, chi, rank, dtype):
+    """Chains whose bonds are numerically rank-deficient (every product bond before its truncation): the one-factor SVD drops
+    the negligible rows of its triangular factor and rotates only the rest (svd_left_deflated / _wide: tall and wide sites,
+    both sweep directions).  Same bonds, amplitude and truncated state as the oracle's compress! (mps.jl:913-973), which
+    takes the full SVD of every site."""
+    L = 14
+    rng = np.random.default_rng(chi + rank)
+    prof = saturated_profile(L, chi)
+    a = random_mps_data(prof, rng, dtype=dtype)
+    # every interior bond of width >= 64 goes through a bottleneck of `rank` states: a[i] <- a[i] P, P of rank `rank`
+    for i in range(len(a) - 1):
+        d = a[i].shape[2]
+        if d < 64:
+            continue
+        r = min(rank, d)
+        P = rng.standard_normal((d, r)) @ rng.standard_normal((r, d)) / np.sqrt(d * r)
+        a[i] = np.einsum("asb,bc->asc", a[i], P.astype(a[i].dtype))
+    psi = qil.SignalMPS(a, amplitude=1.0)
+    ref = O.SignalMPS([t.copy() for t in a], amplitude=1.0)
+    bits = rng.integers(0, 2, size=(256, L))
+    qil.compress(psi, tol=1e-10)
+    O.compress(ref, tol=1e-10)
+    assert psi.bond_dims == ref.bond_dims and max(psi.bond_dims) <= rank
+    assert abs(psi.amplitude - ref.amplitude) < 1e-9 * ref.amplitude
+    got, want = qil.coefficient_batch(psi, bits), O.coefficient_batch(ref, bits)
+    assert np.abs(got - want).max() < 1e-7 * np.abs(want).max()
+    # the gauge the sweep leaves behind: every site but the first is right-orthonormal to rounding
+    for t in psi.to_host()[1:]:
+        m = t.reshape(t.shape[0], -1)
+        assert np.abs(m @ m.conj().T - np.eye(m.shape[0])).max() < 1e-11
+
+
 def test_zt_tutorial_pole_scans_reproduce_published_peaks(qil, pins):
     """docs/src/tutorials/zt.md:318-561 end to end (examples/zt_pole_scan.py): n = 20 two-pole signal, RSVD encode, zT
     MPOs at wr = 2 pi and 0.5, and the three |chi(k, l)| scans.  The printed peak indices / locations / pole errors of
