@@ -3427,11 +3427,11 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             // truncation): rotating the k columns of R crawls (14-18 sweeps at 128 columns: the null space is a k - r fold
             // degenerate cluster), and most of the work is spent on directions the cutoff discards.  The rows of R say which:
             // dropping the rows with the smallest norms changes A by EXACTLY their weight (A = Q R), so rows are dropped while
-            // their weight stays below ctx->svd_deflate (1e-3 of the caller's cutoff) of the total, and the one-factor SVD of
+            // their weight stays below ctx->svd_deflate (1e-6 of the caller's cutoff) of the total, and the one-factor SVD of
             // the remaining r x k block -- a wide, full-rank operand: QR of its r columns, r x r rotations -- gives the same
             // factors: U = Q[:, K] U_K, S V^H = S_K V_K^H.
             const bool deficient = std::isfinite(fro2) && fro2 >= grade_max * (double)k * dmin;
-            if (deficient && ctx->svd_deflate > 0.0) {                // (such a factor never passes the certificate: min |r_ii| settles it)
+            if (deficient && ctx->svd_deflate > 0.0 && k >= 64) {                // (such a factor never passes the certificate: min |r_ii| settles it)
                 int done = 0;
                 QIL_TRY((svd_left_deflated<T>(ctx, p, k, Qm, ldq, R, X, Uiso, ldu, S_host, SVh, ldsvh, negl_rel, dbg, &done)));
                 if (done) {
