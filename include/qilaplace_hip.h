@@ -87,6 +87,11 @@ int qil_context_fail_alloc_after(qil_context* ctx, int64_t n);
 /* Testing aid: pool bytes in use that no MPS/MPO handle owns.  Zero between calls -- every temporary is back in
  * the pool whether the last call succeeded or failed.                                                        */
 int qil_context_unowned_bytes(qil_context* ctx, int64_t* out);
+/* Host CPUs the batch runners of this process may keep busy: min(cgroup CPU quota, affinity mask) / LOCAL_WORLD_SIZE
+ * (the ranks torch.distributed.run / bench.py place on this node), overridden by QIL_CPU_BUDGET.  The lock-step batch
+ * entry points (qil_*_batch) never run more polling launcher threads than this minus one.  No reference counterpart
+ * (the reference is single-threaded Julia + BLAS threads, benchmarking.md:12).                                      */
+int qil_host_cpu_budget(int* out);
 
 /* HIP-event timing on the context's stream (hipEventRecord / hipEventElapsedTime). */
 int qil_timer_start(qil_context* ctx);
@@ -194,7 +199,17 @@ int qil_norm(const qil_mps* psi, double* out);
 /* canonicalize!(psi, direction; center, cutoff=1e-12, maxdim) src/mps.jl:787-847.
  * center = 0 selects the default (N for :right, 1 for :left); 1-based otherwise.    */
 int qil_canonicalize(qil_mps* psi, int direction, int64_t center, double cutoff, int64_t maxdim);
-/* compress!(psi; maxdim, tol=1e-12, sweeps=1) src/mps.jl:913-999.  In place.        */
+/* compress!(psi; maxdim, tol=1e-12, sweeps=1) src/mps.jl:913-999.  In place.
+ * Accuracy contract: same bond dimensions and amplitude as the reference's rule (cutoff = tol^2 / ((N-1) sweeps),
+ * mps.jl:920; gauge passes at canonicalize!'s cutoff 1e-12), truncated state within 1e-9 of the CPU restatement's on
+ * sampled coefficients (tests: test_compress_*, test_bench_truncate_operands_against_oracle).  One deliberate
+ * deviation from "full SVD of every site": when a site's triangular factor is numerically rank-deficient (every
+ * product bond before its truncation) the one-factor SVD first DROPS the rows of that factor whose summed squared
+ * weight stays below 1e-6 of the caller's cutoff x |A|_F^2 and factors only the rest (svd_left_deflated).  A dropped
+ * weight w costs sqrt(w) in amplitude, i.e. at most 1e-3 of what the cutoff itself is allowed to discard per site:
+ * measured on the bond-1008 zT product (maxdim 64, tol 1e-8) the truncated state differs from the CPU restatement's
+ * by 4e-10 of the scale with the rule and 1e-11 without it, against 1.8e-5 of truncation error of the algorithm
+ * itself.                                                                                                            */
 int qil_compress(qil_mps* psi, int64_t maxdim, double tol, int sweeps);
 
 /* zip_to_compress_mpo over a whole MPO, in place (src/transforms/dt_transformer.jl:167-288; the step the

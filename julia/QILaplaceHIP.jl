@@ -352,7 +352,11 @@ function _factors_to_itensors(U, S, Vh, r, Lis, Ris, bondtag)
     v = Index(r; tags=bondtag)
     Ut = ITensor(reshape(U[:, 1:r], dim.(Lis)..., r), Lis..., u)
     St = diag_itensor(S[1:r], u, v)
-    Vt = ITensor(reshape(permutedims(conj.(Vh[1:r, :])), dim.(Ris)..., r), Ris..., v)   # A = U S V^H, V as in ITensors.svd
+    # ITensors.svd returns the triple with A ≈ U * S * V and NO dag on V (rsvd.jl:103-121 hands that triple on), so the
+    # tensor V[ris, v] holds the entries of V^H: V[ris, v] = Vh[v, ris] -- a transpose, no conjugation (for a complex A a
+    # conj here would break norm(A - U*S*V) ≈ 0; where Julia is available: A = random_itensor(ComplexF64, i, j);
+    # U, S, V = svd_device(A, i); @assert norm(A - U * S * V) < 1e-12 * norm(A))
+    Vt = ITensor(reshape(permutedims(Vh[1:r, :]), dim.(Ris)..., r), Ris..., v)
     return Ut, St, Vt
 end
 function rsvd_device(A::ITensor, Linds...; k::Int=20, p::Int=10, q::Int=0, random_seed::Int=1234,

@@ -12,7 +12,7 @@ Everything numeric runs in lib/libqilhip.so (HIP, gfx950); importing this packag
 loudly if that library has not been built.
 """
 from ._lib import QilError, QilDomainError, LIB_PATH, last_error  # noqa: F401
-from .containers import (Context, default_context, set_default_context, device_count,  # noqa: F401
+from .containers import (Context, default_context, set_default_context, device_count, host_cpu_budget,  # noqa: F401
                          SignalMPS, ZTMPS, SingleSiteMPO, PairedSiteMPO)
 from .ops import (apply, apply_compress, apply_compress_batch, mpo_compress, compress_batch, mpo_compress_batch, mps_block, coefficient, coefficient_batch, apply_coefficient_batch, apply_coefficient_sweep,  # noqa: F401
                   marginal_batch, coefficient_grid, laplace_values,
@@ -26,7 +26,7 @@ from .interchange import save, load  # noqa: F401
 from .sweep import shard_items, sweep, damping_sweep, gather_results  # noqa: F401
 
 __all__ = [
-    "Context", "default_context", "set_default_context", "device_count",
+    "Context", "default_context", "set_default_context", "device_count", "host_cpu_budget",
     "SignalMPS", "ZTMPS", "SingleSiteMPO", "PairedSiteMPO",
     "apply", "apply_compress", "apply_compress_batch", "coefficient", "coefficient_batch", "apply_coefficient_batch", "apply_coefficient_sweep", "marginal_batch", "coefficient_grid", "laplace_values", "mps_to_vector", "norm",
     "canonicalize", "compress", "signal_mps", "signal_ztmps", "signal_mps_batch", "signal_ztmps_batch", "rsvd", "svd_trunc", "gemm",

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "qil_context_mem_info": [_vp, _pi64, _pi64, _pi64, _pi64],
     "qil_context_fail_alloc_after": [_vp, _i64],
     "qil_context_unowned_bytes": [_vp, _pi64],
+    "qil_host_cpu_budget": [_pint],
     "qil_timer_start": [_vp],
     "qil_timer_stop": [_vp, _pdbl],
     "qil_profile_enable": [_vp, _int],

@@ -88,6 +88,13 @@ def device_count() -> int:
     return n.value
 
 
+def host_cpu_budget() -> int:
+    """CPUs the batch runners may keep busy: min(cgroup quota, affinity) / LOCAL_WORLD_SIZE (QIL_CPU_BUDGET overrides)."""
+    n = C.c_int()
+    L.check(L.lib.qil_host_cpu_budget(C.byref(n)))
+    return n.value
+
+
 def _dtype_code(arrs):
     return L.QIL_C64 if any(np.iscomplexobj(a) for a in arrs) else L.QIL_F64
 

@@ -259,7 +259,16 @@ qil_call_scope::qil_call_scope(qil_context* c)
     : ctx(c), serial0(c ? c->alloc_serial : 0), fails0(qil_fail_count()) {
     // per-call heuristics state starts afresh: what one call learns about its operands (qr_impl's Cholesky QR refusals) must not
     // leak into the next one -- an item of a batch then takes exactly the route it takes alone (bit-identical results)
-    if (c) c->cholqr_skip = 0;
+    if (c) {
+        c->cholqr_skip = 0;
+        // ... and so does the R^-1 block CholeskyQR2 parks for a certificate (cholqr2 / certify_no_truncation): it is state of
+        // ONE call.  A pointer that survived the previous call is released if the pool still knows the block as live, and
+        // forgotten either way, so no call can free or certify against a block that has been handed out again since.
+        if (c->rinv && c->live_blocks.count(c->rinv)) qil_ctx_free(c, c->rinv);
+        c->rinv = nullptr;
+        c->rinv_for = nullptr;
+        c->want_rinv = false;
+    }
 }
 
 qil_call_scope::~qil_call_scope() {
@@ -277,6 +286,10 @@ qil_call_scope::~qil_call_scope() {
             ++it;
         }
     }
+    // the parked R^-1 block (if any) has just gone back to the pool with the rest: forget the pointer, do not free it again
+    ctx->rinv = nullptr;
+    ctx->rinv_for = nullptr;
+    ctx->want_rinv = false;
 }
 
 int qil_ctx_pinned(qil_context* ctx, size_t bytes, void** out) {
@@ -521,10 +534,16 @@ static inline void futex_wait_for(std::atomic<uint32_t>* a, uint32_t expected, l
 static inline void futex_wake_one(std::atomic<uint32_t>* a) {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(a), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
 }
-// chain side: sleep until *word >= ticket (the launcher wakes the thread; the timeout only bounds a lost wake-up)
-void qil_lockstep_park(qil_context* ctx, const unsigned long long* word, unsigned long long ticket) {
+// chain side: sleep until *word >= ticket (the launcher wakes the thread; the timeout only bounds a lost wake-up).  Returns
+// QIL_OK when the ticket has arrived, the chain's failed-launch status if a combined launch of this chain failed meanwhile (its
+// read-back kernel may never run), QIL_EHIP after 60 s -- the caller must not wait for ever on a device that has faulted.
+int qil_lockstep_park(qil_context* ctx, const unsigned long long* word, unsigned long long ticket) {
     qil_chainq& q = ctx->lockstep->q[ctx->ls_slot];
+    const auto t0 = std::chrono::steady_clock::now();
     while (__atomic_load_n(word, __ATOMIC_ACQUIRE) < ticket) {
+        const int st = q.status.load(std::memory_order_acquire);
+        if (st != QIL_OK && q.head.load(std::memory_order_acquire) == q.tail.load(std::memory_order_relaxed)) return st;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return QIL_EHIP;
         q.wait_word = word;
         q.wait_ticket = ticket;
         q.parked.store(1, std::memory_order_release);
@@ -535,6 +554,7 @@ void qil_lockstep_park(qil_context* ctx, const unsigned long long* word, unsigne
         futex_wait_for(&q.parked, 1, 20 * 1000 * 1000);
         q.parked.store(0, std::memory_order_relaxed);
     }
+    return QIL_OK;
 }
 // launcher side: wake the chains whose tickets have arrived
 static inline void lockstep_wake_arrived(qil_lockstep* ls) {
@@ -702,6 +722,46 @@ static void lockstep_run(qil_lockstep* ls, bool timing) {
     ls->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
+// CPUs this process may keep busy: the cgroup quota (cpu.max, v2; cfs_quota_us / cfs_period_us, v1) or the affinity mask, whichever
+// is smaller, divided by the ranks that share the node (LOCAL_WORLD_SIZE of torch.distributed.run / bench.py's spawner);
+// QIL_CPU_BUDGET overrides.  The launchers of a lock-step batch POLL, so their number must stay below it: the GPU boxes give a
+// process 16 CPUs of quota, and 8 ranks x (4 launchers + a chain thread awake) exceed it -- every thread of the cgroup is then
+// throttled for the rest of the scheduler period.
+int qil_cpu_budget() {
+    static const int budget = []() {
+        if (const char* e = getenv("QIL_CPU_BUDGET")) return std::max(1, atoi(e));
+        double cpus = (double)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::min(cpus, (double)std::max(1, CPU_COUNT(&set)));
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) cpus = std::min(cpus, (double)atoll(q) / (double)period);
+            fclose(f);
+        } else {
+            long long quota = -1, period = 0;
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+                fclose(g);
+            }
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(g, "%lld", &period) != 1) period = 0;
+                fclose(g);
+            }
+            if (quota > 0 && period > 0) cpus = std::min(cpus, (double)quota / (double)period);
+        }
+        int ranks = 1;
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+        return std::max(1, (int)(cpus / ranks));
+    }();
+    return budget;
+}
+extern "C" int qil_host_cpu_budget(int* out) {
+    QIL_REQUIRE(out, QIL_EINVAL_ARG, "null out");
+    *out = qil_cpu_budget();
+    return QIL_OK;
+}
+
 int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int64_t, qil_context*)>& place,
                      const std::function<int(int64_t, qil_context*)>& fn) {
     if (nb <= 0) return QIL_OK;
@@ -716,13 +776,15 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     // them as one table launch; up to 4 such groups run side by side on streams of their own (one per hardware queue).  One
     // group is a serial stream -- measured, compress! chi 256 -> 128: 8 chains 146-160 ms as one group against 136 ms on 8
     // streams, 4 chains 109 against 75 ms -- so small batches keep the stream-per-chain form and lock-step takes over where
-    // the 4 hardware queues are the limit: from 12 chains on (QIL_BATCH_LOCKSTEP = 0: never, 1: always, default: auto).
+    // the 4 hardware queues are the limit: from 5 chains on (QIL_BATCH_LOCKSTEP = 0: never, 1: always, default: auto).
     const int ls_mode = getenv("QIL_BATCH_LOCKSTEP") ? atoi(getenv("QIL_BATCH_LOCKSTEP")) : -1;
     const bool lockstep = ls_mode == 1 || (ls_mode != 0 && nb >= 5);
     constexpr int kMaxGroups = 4;
     const int nw = (home->lending || home->parent) ? 1
                    : (int)std::min<int64_t>(nb, lockstep ? QIL_MAXB * kMaxGroups : std::max(1, max_workers));
-    const int ng = lockstep ? std::min(kMaxGroups, nw) : 0;      // all four queues, the chains dealt over them; slot k belongs to group k % ng
+    // all four queues, the chains dealt over them; slot k belongs to group k % ng -- but never more polling launchers than the
+    // process's CPU budget leaves room for next to one chain thread that is awake (qil_cpu_budget)
+    const int ng = lockstep ? std::max(1, std::min(std::min(kMaxGroups, nw), qil_cpu_budget() - 1)) : 0;
     if (nw <= 1) {
         int first = QIL_OK;
         std::string msg;
@@ -770,6 +832,10 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
             ls.stream = own_stream[(size_t)g];                   // group 0: the home stream; group g: its first slot's own stream
             if (g && hipStreamWaitEvent(ls.stream, ready, 0) != hipSuccess) {
                 (void)hipEventDestroy(ready);
+                for (int k = 1; k < nw; ++k) {                    // place() has moved chains to the workers: hand them back
+                    const std::vector<qil_chain*> held(slot_ctx(k)->chains.begin(), slot_ctx(k)->chains.end());
+                    for (qil_chain* c : held) chain_move(c, home);
+                }
                 return qil_fail(QIL_EHIP, "hipStreamWaitEvent failed");
             }
         }
@@ -839,11 +905,19 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     }
     if (lockstep) {                                               // one launcher per group; this thread serves group 0
         std::vector<std::thread> launchers;
-        for (int g = 1; g < ng; ++g) launchers.emplace_back([&, g]() {
-            (void)hipSetDevice(home->device);
-            lockstep_run(&lsg[(size_t)g], batch_debug);
-        });
+        std::vector<int> unserved;                                // groups whose launcher thread could not be started
+        for (int g = 1; g < ng; ++g) {
+            try {
+                launchers.emplace_back([&, g]() {
+                    (void)hipSetDevice(home->device);
+                    lockstep_run(&lsg[(size_t)g], batch_debug);
+                });
+            } catch (const std::system_error&) {
+                unserved.push_back(g);                            // (thread exhaustion: this thread serves the group after its own)
+            }
+        }
         lockstep_run(&lsg[0], batch_debug);
+        for (int g : unserved) lockstep_run(&lsg[(size_t)g], batch_debug);
         for (auto& t : launchers) t.join();
     } else {
         drive(0);

@@ -4184,7 +4184,11 @@ int qil_read_back_wait(qil_context* ctx, uint64_t ticket, void* host_dst, size_t
     const unsigned long long* word = reinterpret_cast<const unsigned long long*>(base + qil_context::kRbSlots * qil_context::kRbSlotBytes);
     const auto t0 = std::chrono::steady_clock::now();
     long long spins = 0;
-    if (ctx->lockstep) qil_lockstep_park(ctx, word, ticket);      // (sleeps; the group's launcher watches the word)
+    if (ctx->lockstep) {                                         // (sleeps; the group's launcher watches the word)
+        const int pst = qil_lockstep_park(ctx, word, ticket);
+        if (pst != QIL_OK)
+            return qil_fail(pst, "read-back %llu of a lock-step chain did not arrive (a combined launch failed, or 60 s passed)", (unsigned long long)ticket);
+    }
     while (__atomic_load_n(word, __ATOMIC_ACQUIRE) < ticket) {
         __builtin_ia32_pause();
         if ((++spins & 0xfffff) == 0) {                          // a launch that never ran must not hang the caller

@@ -1758,7 +1758,7 @@ def test_randomised_truncation_pipeline_against_oracle(qil, seed):
     v_ref = O.mps_to_vector(O.SignalMPS(a, amplitude=amp))
     err_h = np.linalg.norm(qil.mps_to_vector(psi) - v_ref)
     err_o = np.linalg.norm(O.mps_to_vector(ref) - v_ref)
-    assert err_h <= 1.5 * err_o + 1e-9 * np.linalg.norm(v_ref)          # as good an approximation as the reference's
+    assert err_h <= 1.05 * err_o + 1e-10 * np.linalg.norm(v_ref)        # as good an approximation as the reference's (measured: equal to 1e-11)
     # apply (exact) and the fused apply-and-truncate (lossless setting reproduces apply)
     W, psi = qil.SingleSiteMPO(w), qil.SignalMPS(a, amplitude=amp)
     dense = O.mps_to_vector(O.apply(O.SingleSiteMPO(w), O.SignalMPS(a, amplitude=amp)))
@@ -1821,7 +1821,7 @@ def test_compress_wide_bonds_against_oracle(qil, L, chi, maxdim, dtype):
     assert abs(psi.amplitude - ref.amplitude) < 1e-9 * ref.amplitude
     got, want = qil.coefficient_batch(psi, bits), O.coefficient_batch(ref, bits)
     scale = np.abs(before).max()
-    assert np.abs(got - want).max() < 1e-7 * scale
+    assert np.abs(got - want).max() < 1e-9 * scale            # north_star's tolerance (measured 1e-11 ... 4e-10)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
@@ -1851,11 +1851,47 @@ def test_compress_rank_deficient_bonds_take_the_deflated_svd(qil, chi, rank, dty
     assert psi.bond_dims == ref.bond_dims and max(psi.bond_dims) <= rank
     assert abs(psi.amplitude - ref.amplitude) < 1e-9 * ref.amplitude
     got, want = qil.coefficient_batch(psi, bits), O.coefficient_batch(ref, bits)
-    assert np.abs(got - want).max() < 1e-7 * np.abs(want).max()
+    assert np.abs(got - want).max() < 1e-9 * np.abs(want).max()          # north_star's tolerance (measured <= 4e-10)
     # the gauge the sweep leaves behind: every site but the first is right-orthonormal to rounding
     for t in psi.to_host()[1:]:
         m = t.reshape(t.shape[0], -1)
         assert np.abs(m @ m.conj().T - np.eye(m.shape[0])).max() < 1e-11
+
+
+def test_bench_truncate_operands_against_oracle(qil):
+    """The number bench.py prints as truncate.cpu_baseline.hip_vs_cpu_truncated_state, as a test: the bench's own operands
+    (bench.truncate_operands: n = 24 structured signal, signal_ztmps(:rsvd, k = 15), genuine build_zt_mpo(psi, 2 pi); product
+    bond ~1008) through the exact route compress!(apply(W, psi); maxdim = 64, tol = 1e-8) (src/linalg/apply.jl:75-122 +
+    src/mps.jl:913-973) on the HIP path and in the oracle: equal bond dimensions, 256 coefficients within north_star's 1e-9
+    of the scale.  (The one-factor SVD drops rows of its triangular factor below 1e-6 of the caller's cutoff -- qil_compress's
+    header comment --, which is what moved this figure from 1e-11 to 4e-10 in r03.)"""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    n = 24
+    W, psi = bench.truncate_operands(qil, n)
+    assert max(c * d for c, d in zip(psi.bond_dims, W.bond_dims)) >= 900           # the bond-~1008 product of the bench
+    prod = W * psi
+    ref = O.SignalMPS([t.copy() for t in prod.to_host()], amplitude=prod.amplitude)
+    bits = np.random.default_rng(3).integers(0, 2, size=(256, 2 * n)).astype(np.uint8)
+    exact = qil.apply_coefficient_batch(W, psi, bits)
+    scale = np.abs(exact).max()
+    qil.compress(prod, maxdim=bench.TRUNCATE_MAXDIM, tol=bench.TRUNCATE_TOL)
+    O.compress(ref, maxdim=bench.TRUNCATE_MAXDIM, tol=bench.TRUNCATE_TOL)
+    assert prod.bond_dims == ref.bond_dims and max(prod.bond_dims) <= bench.TRUNCATE_MAXDIM
+    got, want = qil.coefficient_batch(prod, bits), O.coefficient_batch(ref, bits)
+    assert np.abs(got - want).max() <= 1e-9 * scale, np.abs(got - want).max() / scale
+    assert abs(prod.amplitude - ref.amplitude) <= 1e-9 * ref.amplitude
+    # both routes stay within the algorithm's own error against the exact product (1.8e-5 measured)
+    assert np.abs(got - exact).max() <= 1e-4 * scale
+    # the fused route on the same operands: bonds capped, closer to the exact product than the reference's own route
+    fused = qil.apply_compress(W, psi, maxdim=bench.TRUNCATE_MAXDIM, tol=bench.TRUNCATE_TOL)
+    assert max(fused.bond_dims) <= bench.TRUNCATE_MAXDIM
+    assert np.abs(qil.coefficient_batch(fused, bits) - exact).max() <= np.abs(want - exact).max() + 1e-9 * scale
 
 
 def test_zt_tutorial_pole_scans_reproduce_published_peaks(qil, pins):
