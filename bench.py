@@ -469,6 +469,11 @@ class Ranks:
             sys.exit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={self.world} ranks")
 
     @property
+    def backend_used(self):
+        """"nccl" (= RCCL on ROCm) / "gloo" when a process group is up, None for a bare single process."""
+        return self.backend if self.dist is not None else None
+
+    @property
     def device(self):
         return f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu"
 
@@ -584,7 +589,8 @@ def run_apply(args, rk):
                    "output_bytes_per_step": abytes, "parallelism": f"replicas x{world} (one signal per GPU)",
                    "mpo": ("genuine build_zt_mpo(24, 2 pi), natural bonds %d, zero-embedded + gauge-mixed to 128"
                            % max(t.shape[3] for t in w_natural[:-1])) if genuine else "seeded random fill",
-                   "ranks_reported_by_collective_backend": world, "lib_sha16": lib_sha16()},
+                   "ranks_reported_by_collective_backend": world, "collective_backend": rk.backend_used,
+                   "lib_sha16": lib_sha16()},
         "max_coeff_err": err_oracle if err_oracle is not None else err_lazy,
         "coeff_err": {"materialised_vs_lazy_hip": err_lazy, "materialised_vs_cpu_oracle": err_oracle,
                       "queries": args.queries, "kind": "max relative"},
@@ -623,17 +629,18 @@ def run_sweep(args, rk):
     psi = qil.signal_ztmps(x, method="rsvd", k=15, p=5, q=2, cutoff=1e-12)
     sig = np.linspace(0.25, 16.0, nsig)
     bits = np.random.default_rng(7).integers(0, 2, size=(nsamp, 2 * n)).astype(np.uint8)
-    dist = rk.dist if rk.world > 1 else None
+    forced = rk.dist is not None and rk.world == 1              # QIL_BENCH_FORCE_DIST=1: the collective path in a world of one
+    dist = rk.dist if (rk.world > 1 or forced) else None
     dev = rk.device if dist is not None and rk.backend == "nccl" else None
     res = None
     for _ in range(args.warmup):
-        res = qil.damping_sweep(psi, sig, bits, dist=dist, device=dev)
+        res = qil.damping_sweep(psi, sig, bits, dist=dist, device=dev, always_gather=forced)
     rk.barrier(ctx)
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = qil.damping_sweep(psi, sig, bits, dist=dist, device=dev)
+        res = qil.damping_sweep(psi, sig, bits, dist=dist, device=dev, always_gather=forced)
     rk.barrier(ctx)
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
@@ -696,7 +703,7 @@ def run_sweep(args, rk):
                    "damping_values": nsig, "samples_per_value": nsamp, "mps_bonds_max": max(psi.bond_dims),
                    "mpo_bonds_max": max(max(W.bond_dims) for W in Ws),
                    "parallelism": f"64 damping values round-robin over {rk.world} rank(s), one all_gather",
-                   "ranks_reported_by_collective_backend": rk.world,
+                   "ranks_reported_by_collective_backend": rk.world, "collective_backend": rk.backend_used,
                    "values_per_rank": [len(range(r, nsig, rk.world)) for r in range(rk.world)],
                    "lib_sha16": lib_sha16()},
         "max_coeff_err": err, "coeff_err": {"vs_closed_form_rel_to_signal_peak": err, "queries": nsig * nsamp},

@@ -19,10 +19,11 @@ def shard_items(n_items: int, world: int, rank: int):
     return list(range(rank, n_items, world))
 
 
-def gather_results(local: dict, n_items: int, width: int, dist=None, device=None):
+def gather_results(local: dict, n_items: int, width: int, dist=None, device=None, always_gather=False):
     """All ranks contribute {item index -> complex vector of length `width`}; returns the
-    (n_items, width) complex array in item order on every rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    (n_items, width) complex array in item order on every rank.  `always_gather`: run the collective even in a world of
+    one rank (exercises the RCCL path on a 1-GPU box: bench.py with QIL_BENCH_FORCE_DIST=1)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always_gather):
         out = np.zeros((n_items, width), dtype=np.complex128)
         for i, v in local.items():
             out[i] = v
@@ -47,16 +48,16 @@ def gather_results(local: dict, n_items: int, width: int, dist=None, device=None
     return out
 
 
-def sweep(items, work_fn, width: int, dist=None, device=None):
+def sweep(items, work_fn, width: int, dist=None, device=None, always_gather=False):
     """Run ``work_fn(item) -> complex vector (width,)`` on this rank's share of ``items`` and
     gather all results in item order."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     local = {i: work_fn(items[i]) for i in shard_items(len(items), world, rank)}
-    return gather_results(local, len(items), width, dist if world > 1 else None, device)
+    return gather_results(local, len(items), width, dist if (world > 1 or always_gather) else None, device, always_gather)
 
 
-def damping_sweep(psi, sigmas, bits, build_mpo=None, dist=None, device=None, cutoff=1e-14, maxdim=1000):
+def damping_sweep(psi, sigmas, bits, build_mpo=None, dist=None, device=None, cutoff=1e-14, maxdim=1000, always_gather=False):
     """BASELINE.json configs[3]: one paired-register signal x many damping values.
 
     psi        device ZTMPS (replicated on every rank; it is MBs)
@@ -77,7 +78,7 @@ def damping_sweep(psi, sigmas, bits, build_mpo=None, dist=None, device=None, cut
             W = PairedSiteMPO(build_mpo(sig), sites=psi.site_ids, ctx=psi.ctx)
             return coefficient_batch(apply(W, psi), bits)
 
-        return sweep(sigmas, work, bits.shape[0], dist, device)
+        return sweep(sigmas, work, bits.shape[0], dist, device, always_gather)
     from .builders import build_dt_mpo_batch
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
@@ -87,4 +88,4 @@ def damping_sweep(psi, sigmas, bits, build_mpo=None, dist=None, device=None, cut
         Ws = build_dt_mpo_batch(psi, [sigmas[i] for i in mine], cutoff, maxdim, psi.ctx)
         res = apply_coefficient_sweep(Ws, psi, bits)
         local = {i: res[k] for k, i in enumerate(mine)}
-    return gather_results(local, len(sigmas), bits.shape[0], dist if world > 1 else None, device)
+    return gather_results(local, len(sigmas), bits.shape[0], dist if (world > 1 or always_gather) else None, device, always_gather)
