@@ -33,7 +33,7 @@ constexpr int PB_NT = 256;                          // threads per workgroup (4 
 constexpr int PB_NG = PB_NT / 16;                   // 16-lane DPP rows
 constexpr int PB_MAXL = 256;                        // chain length 2n
 constexpr int PB_DMAX = 56;                         // hard cap of any bond inside the kernel
-constexpr int PB_NCYC = 16;                          // 8 cycle categories + SVD statistics
+constexpr int PB_NCYC = 13;                          // 8 cycle categories + SVD statistics
 
 struct PbArgs {
     int n, L, dcap;
@@ -45,7 +45,6 @@ struct PbArgs {
     int* dims_out;                      // per value: L + 1 bond dims (with the two edges)
     int* status;                        // per value: 0 ok, else the capacity check that failed
     int arena_doubles;
-    int gram;                           // Gram-space sweeps (r04) instead of the vector rounds
     unsigned long long* cycles;         // optional: per value PB_NCYC counters
 };
 
@@ -581,407 +580,8 @@ __device__ void pb_jacobi_t(double* A, int lda, int m, int n, PbState& st, doubl
     }
 }
 
-// ------------------------------------------------------------------ Gram-space sweeps (r04)
-// The vector rounds above pay ~2 000 cycles per tournament round whatever the column length: loads of both columns, a
-// dot product + DPP reduction, the rotation's dependent chain, the update, the stores and a workgroup barrier -- for every one
-// of the n - 1 rounds of every sweep, including the last sweep that finds nothing to rotate.  Here a sweep is
-//   (1) G = A^T A of the active columns, once, on all 256 threads (2 x 2 register blocks, the rows split four ways inside
-//       every quad of lanes, quad_perm adds -- a fixed summation order);
-//   (2) convergence from this FRESH Gram matrix (|g_pq| <= tol sqrt(g_pp g_qq) for every pair: the same test on the same
-//       dot products as the vector rounds) -- a converged operand costs one Gram matrix, not a sweep;
-//   (3) the tournament in Gram space: G is held as 2 x 2 blocks in REGISTERS, block (i, j) = pair i x pair j, with the
-//       accumulated rotations J beside it.  A round = the owners of the diagonal blocks derive their pair's rotation from
-//       (g_pp, g_qq, g_pq) -- no loads, no dot product, no reduction --, every block takes R_i^T B R_j (8 multiply-adds), and
-//       the ring movement of the tournament (top row one pair to the right, bottom row one pair to the left) goes through a
-//       position-indexed LDS image of G and J.  Up to 16 columns the 64 blocks are the 64 lanes of ONE wave: no workgroup
-//       barrier inside a sweep (LDS operations of one wave complete in order); beyond that the blocks are dealt over the
-//       256 threads with two barriers per round;
-//   (4) A[:, active] <- A[:, active] J on all threads (register-blocked, read - barrier - write).
-// Entries of G that have been through rotations carry their rounding: they decide ANGLES only.  Every rotation is an exact
-// plane rotation whatever its angle, J is orthogonal to rounding, and what is accepted as converged is judged on fresh dot
-// products of the rotated columns -- the singular values (column norms of A at the end) are those of the vector rounds.
-// (Numpy model of exactly this block / position scheme first: same sweep counts as the vector tournament on graded,
-// rank-deficient and flat operands of 2 ... 52 columns, singular values to the same relative accuracy.)
-__device__ __forceinline__ int pb_ring_src(int p, int Np) {      // the position whose column moves to position p
-    if (p == 0) return 0;                                         // top of pair 0 stays
-    if (p == 2) return 1;                                         // top of pair 1 <- bottom of pair 0
-    if (!(p & 1)) return p - 2;                                   // top of pair i <- top of pair i - 1
-    if (p == 2 * Np - 1) return 2 * Np - 2;                       // bottom of the last pair <- its own top
-    return p + 2;                                                 // bottom of pair i <- bottom of pair i + 1
-}
-
-template <bool ONEWAVE>
-__device__ __forceinline__ void pb_gsync() {
-    if (ONEWAVE) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-        __syncthreads();
-    }
-}
-
-// The rounds of one sweep.  Gp (npad x npad, ld) holds the Gram matrix of the compacted active columns in natural order
-// (position p = active column p; a padding position has a zero row and column); on exit Jp (npad x npad, ld) holds J with
-// rows = active columns and columns = final positions.  BPT blocks per thread; ONEWAVE: the caller runs this on wave 0 only.
-template <int BPT, bool ONEWAVE>
-__device__ void pb_gram_rounds(double* __restrict__ Gp, double* __restrict__ Jp, int ld, int npad, PbState& st, double tol) {
-    constexpr int NTH = ONEWAVE ? 64 : PB_NT;
-    const int tid = threadIdx.x;
-    const int Np = npad >> 1, nblk = Np * Np;
-    double g[BPT][4], jv[BPT][4];                                  // [2 a + b]
-    int bi[BPT], bj[BPT], sr0[BPT], sr1[BPT], sc0[BPT], sc1[BPT];
-    bool own[BPT];
-#pragma unroll
-    for (int u = 0; u < BPT; ++u) {
-        const int e = tid + NTH * u;
-        own[u] = e < nblk;
-        const int ee = own[u] ? e : 0;
-        bi[u] = ee % Np;
-        bj[u] = ee / Np;
-        const double* gp = Gp + (2 * bi[u]) * ld + 2 * bj[u];
-        g[u][0] = gp[0];
-        g[u][1] = gp[1];
-        g[u][2] = gp[ld];
-        g[u][3] = gp[ld + 1];
-        jv[u][0] = jv[u][3] = bi[u] == bj[u] ? 1.0 : 0.0;
-        jv[u][1] = jv[u][2] = 0.0;
-        sr0[u] = pb_ring_src(2 * bi[u], Np) * ld;
-        sr1[u] = pb_ring_src(2 * bi[u] + 1, Np) * ld;
-        sc0[u] = pb_ring_src(2 * bj[u], Np);
-        sc1[u] = pb_ring_src(2 * bj[u] + 1, Np);
-    }
-    pb_gsync<ONEWAVE>();                                           // everybody has read Gp before anybody overwrites it
-    for (int round = 0; round < npad - 1; ++round) {
-        // phase A: the owner of diagonal block (i, i) derives pair i's rotation (at most one diagonal block per thread for
-        // Np <= 26: (Np + 1) i mod 256 is injective there)
-        double al = 0.0, be = 0.0, gg = 0.0;
-        int di = -1;
-#pragma unroll
-        for (int u = 0; u < BPT; ++u)
-            if (own[u] && bi[u] == bj[u]) {
-                al = g[u][0];
-                be = g[u][3];
-                gg = g[u][1];
-                di = bi[u];
-            }
-        bool rotated = false;
-        double aln = al, ben = be;
-        if (di >= 0) {
-            double c = 1.0, sg = 0.0, sn;
-            bool big;
-            if (al > 0.0 && be > 0.0 && pb_rotation(al, be, gg, tol, c, sn, big)) {
-                rotated = true;
-                sg = gg >= 0 ? sn : -sn;
-                const double cs2 = 2.0 * c * sn * fabs(gg), c2 = c * c, s2 = sn * sn;
-                aln = fma(c2, al, fma(s2, be, -cs2));
-                ben = fma(s2, al, fma(c2, be, cs2));
-            } else {
-                c = 1.0;
-            }
-            st.kap[di] = c;
-            st.dif[di] = sg;
-        }
-        pb_gsync<ONEWAVE>();
-        // phase B: B <- R_i^T B R_j, J <- J R_j  (x' = c x - s y, y' = s x + c y on the pair's columns / rows)
-        const bool last = round == npad - 2;
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) {
-            if (!own[u]) continue;
-            const double ci = st.kap[bi[u]], si = st.dif[bi[u]], cj = st.kap[bj[u]], sj = st.dif[bj[u]];
-            const double t00 = fma(-sj, g[u][1], cj * g[u][0]), t01 = fma(sj, g[u][0], cj * g[u][1]);
-            const double t10 = fma(-sj, g[u][3], cj * g[u][2]), t11 = fma(sj, g[u][2], cj * g[u][3]);
-            g[u][0] = fma(-si, t10, ci * t00);
-            g[u][1] = fma(-si, t11, ci * t01);
-            g[u][2] = fma(si, t00, ci * t10);
-            g[u][3] = fma(si, t01, ci * t11);
-            if (bi[u] == bj[u] && rotated) {                       // the annihilated pair, exactly; norms by the stable formulas
-                g[u][0] = aln;
-                g[u][3] = ben;
-                g[u][1] = g[u][2] = 0.0;
-            }
-            const double j00 = fma(-sj, jv[u][1], cj * jv[u][0]), j01 = fma(sj, jv[u][0], cj * jv[u][1]);
-            const double j10 = fma(-sj, jv[u][3], cj * jv[u][2]), j11 = fma(sj, jv[u][2], cj * jv[u][3]);
-            jv[u][0] = j00;
-            jv[u][1] = j01;
-            jv[u][2] = j10;
-            jv[u][3] = j11;
-            double* jp = Jp + (2 * bi[u]) * ld + 2 * bj[u];
-            jp[0] = j00;
-            jp[1] = j01;
-            jp[ld] = j10;
-            jp[ld + 1] = j11;
-            if (!last) {
-                double* gp = Gp + (2 * bi[u]) * ld + 2 * bj[u];
-                gp[0] = g[u][0];
-                gp[1] = g[u][1];
-                gp[ld] = g[u][2];
-                gp[ld + 1] = g[u][3];
-            }
-        }
-        pb_gsync<ONEWAVE>();
-        if (last) break;
-        // phase C: the ring movement -- new block (i, j) [a][b] = old G[src(2 i + a)][src(2 j + b)]; J moves its columns only
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) {
-            if (!own[u]) continue;
-            g[u][0] = Gp[sr0[u] + sc0[u]];
-            g[u][1] = Gp[sr0[u] + sc1[u]];
-            g[u][2] = Gp[sr1[u] + sc0[u]];
-            g[u][3] = Gp[sr1[u] + sc1[u]];
-            const double* jp = Jp + (2 * bi[u]) * ld;
-            jv[u][0] = jp[sc0[u]];
-            jv[u][1] = jp[sc1[u]];
-            jv[u][2] = jp[ld + sc0[u]];
-            jv[u][3] = jp[ld + sc1[u]];
-        }
-        // (the next phase B overwrites Gp / Jp only after the barrier that follows phase A)
-    }
-}
-
-// G[p][q] = a_p . a_q of the active columns (positions p, q < nact; act[] in st) into Gp (npad x npad, ld), zero padding
-// row / column included.  2 x 2 blocks of G on the upper triangle, one block per quad of lanes and pass, the rows dealt
-// r = kc, kc + 4, ... to the quad's four lanes, then two quad_perm adds.
-template <int MU4>                                                // rows in chunks of 4 MU4
-__device__ void pb_gram_matrix(const double* __restrict__ A, int lda, int m, int nact, int npad, const PbState& st,
-                               double* __restrict__ Gp, int ld) {
-    const int tid = threadIdx.x, kc = tid & 3, q = tid >> 2;
-    const int Np = npad >> 1;
-    const int nb = Np * (Np + 1) / 2;
-    for (int e = q; e < nb; e += PB_NT / 4) {
-        // e -> (bi <= bj): row-major enumeration of the upper triangle
-        int bi = 0, rem = e;
-        while (rem >= Np - bi) {
-            rem -= Np - bi;
-            ++bi;
-        }
-        const int bj = bi + rem;
-        const int p0 = 2 * bi, p1 = p0 + 1, q0 = 2 * bj, q1 = q0 + 1;
-        const double* a0 = A + lda * st.act[p0];
-        const double* a1 = A + lda * st.act[min(p1, nact - 1)];
-        const double* b0 = A + lda * st.act[min(q0, nact - 1)];
-        const double* b1 = A + lda * st.act[min(q1, nact - 1)];
-        const double m1 = p1 < nact ? 1.0 : 0.0, n0 = q0 < nact ? 1.0 : 0.0, n1 = q1 < nact ? 1.0 : 0.0;
-        double g00 = 0, g01 = 0, g10 = 0, g11 = 0;
-        for (int rb = 0; rb < m; rb += 4 * MU4) {
-            double x0[MU4], x1[MU4], y0[MU4], y1[MU4];
-#pragma unroll
-            for (int u = 0; u < MU4; ++u) {
-                const int r = rb + kc + 4 * u;
-                const int rr = min(r, m - 1);
-                const double ok = r < m ? 1.0 : 0.0;
-                x0[u] = a0[rr] * ok;
-                x1[u] = a1[rr] * ok;
-                y0[u] = b0[rr];
-                y1[u] = b1[rr];
-            }
-#pragma unroll
-            for (int u = 0; u < MU4; ++u) {
-                g00 = fma(x0[u], y0[u], g00);
-                g01 = fma(x0[u], y1[u], g01);
-                g10 = fma(x1[u], y0[u], g10);
-                g11 = fma(x1[u], y1[u], g11);
-            }
-        }
-        g00 += dpp_mov<0xB1>(g00);
-        g01 += dpp_mov<0xB1>(g01);
-        g10 += dpp_mov<0xB1>(g10);
-        g11 += dpp_mov<0xB1>(g11);
-        g00 += dpp_mov<0x4E>(g00);
-        g01 += dpp_mov<0x4E>(g01);
-        g10 += dpp_mov<0x4E>(g10);
-        g11 += dpp_mov<0x4E>(g11);
-        if (kc == 0) {
-            g00 *= n0;
-            g01 *= n1;
-            g10 *= m1 * n0;
-            g11 *= m1 * n1;
-            Gp[p0 * ld + q0] = g00;
-            Gp[p0 * ld + q1] = g01;
-            Gp[p1 * ld + q0] = g10;
-            Gp[p1 * ld + q1] = g11;
-            if (bi != bj) {
-                Gp[q0 * ld + p0] = g00;
-                Gp[q1 * ld + p0] = g01;
-                Gp[q0 * ld + p1] = g10;
-                Gp[q1 * ld + p1] = g11;
-            } else {
-                Gp[p1 * ld + q0] = g01;                              // the diagonal block, symmetric to the last bit
-            }
-        }
-    }
-}
-
-// squared norms of the n columns of A into st.sig (one column per 16-lane row and pass)
-__device__ __forceinline__ void pb_col_norms2(const double* __restrict__ A, int lda, int m, int n, PbState& st, bool root) {
-    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    for (int j = grp; j < n; j += PB_NG) {
-        const double* a = A + lda * j;
-        double v = 0;
-        for (int rb = 0; rb < m; rb += 64) {
-            double xs[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = rb + l16 + 16 * u;
-                xs[u] = r < m ? a[r] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v = fma(xs[u], xs[u], v);
-        }
-        v = row16_sum(v);
-        if (l16 == 0) st.sig[j] = root ? sqrt(v) : v;
-    }
-}
-
-// A[:, act[slot]] <- sum_k A[:, act[k]] Jp[k][p] for every position p but the padding one (pstar, -1 if none);
-// slot = p - (p > pstar).  2 rows x 2 positions per work item, all items of a thread read before the barrier, written after it.
-template <int NIT>
-__device__ void pb_gram_apply(double* __restrict__ A, int lda, int m, int nact, int npad, const PbState& st,
-                              const double* __restrict__ Jp, int ld, int pstar) {
-    const int tid = threadIdx.x;
-    const int Np = npad >> 1, mr = (m + 1) >> 1, nit = mr * Np;
-    double o[NIT][4];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int e = tid + PB_NT * it;
-        o[it][0] = o[it][1] = o[it][2] = o[it][3] = 0.0;
-        if (e >= nit) continue;
-        const int r0 = 2 * (e % mr), r1 = min(r0 + 1, m - 1), p0 = 2 * (e / mr);
-        const double* j0 = Jp + p0;
-        for (int k = 0; k < nact; ++k) {
-            const double* ak = A + lda * st.act[k];
-            const double a0 = ak[r0], a1 = ak[r1], w0 = j0[k * ld], w1 = j0[k * ld + 1];
-            o[it][0] = fma(a0, w0, o[it][0]);
-            o[it][1] = fma(a0, w1, o[it][1]);
-            o[it][2] = fma(a1, w0, o[it][2]);
-            o[it][3] = fma(a1, w1, o[it][3]);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int e = tid + PB_NT * it;
-        if (e >= nit) continue;
-        const int r0 = 2 * (e % mr), r1 = r0 + 1, p0 = 2 * (e / mr), p1 = p0 + 1;
-        if (p0 != pstar) {
-            double* d = A + lda * st.act[p0 - (pstar >= 0 && p0 > pstar)];
-            d[r0] = o[it][0];
-            if (r1 < m) d[r1] = o[it][2];
-        }
-        if (p1 != pstar) {
-            double* d = A + lda * st.act[p1 - (pstar >= 0 && p1 > pstar)];
-            d[r0] = o[it][1];
-            if (r1 < m) d[r1] = o[it][3];
-        }
-    }
-    __syncthreads();
-}
-
-// One-sided Jacobi with the sweeps run in Gram space (see above).  `scratch` = 2 npad (npad + 1) doubles of LDS.  Returns
-// false (nothing touched) when the scratch does not hold the two images.
-template <int MU4>
-__device__ bool pb_jacobi_gram(double* A, int lda, int m, int n, PbState& st, double tol, double negligible, int max_sweeps,
-                               double* scratch, int scratch_doubles, bool prof) {
-    const int tid = threadIdx.x;
-    constexpr int NIT = (52 * 26 + PB_NT - 1) / PB_NT;
-    {
-        const int npmax = n + (n & 1);
-        if (2 * npmax * (npmax + 1) > scratch_doubles || n > 2 * 26 || ((m + 1) >> 1) * (npmax >> 1) > NIT * PB_NT) return false;
-    }
-    int sweeps = 0, rounds = 0, nact = n;
-    for (;;) {
-        // squared column norms -> the active set (negligible columns leave the tournament)
-        pb_col_norms2(A, lda, m, n, st, false);
-        if (tid == 0) {
-            st.rot = 0;
-            st.rot2 = 0;
-            st.rank = -1;
-        }
-        __syncthreads();
-        if (tid < n) {
-            const double mine = st.sig[tid];
-            const bool keep = mine >= negligible && mine > 0.0;
-            int pos = 0, tot = 0;
-#pragma unroll
-            for (int q = 0; q < PB_DMAX; ++q) {
-                const double o = q < n ? st.sig[q] : 0.0;
-                const bool kq = o >= negligible && o > 0.0;
-                pos += kq && q < tid;
-                tot += kq;
-            }
-            if (keep) st.act[pos] = tid;
-            if (tid == 0) st.nact = tot;
-        }
-        __syncthreads();
-        nact = st.nact;
-        if (nact < 2 || sweeps >= max_sweeps) break;
-        const int npad = nact + (nact & 1), ld = npad + 1;
-        double* Gp = scratch;
-        double* Jp = scratch + npad * ld;
-        unsigned long long tp = prof && tid == 0 ? __builtin_readcyclecounter() : 0;
-        auto stamp = [&](int cat) {
-            if (prof && tid == 0) {
-                const unsigned long long t = __builtin_readcyclecounter();
-                st.cyc[cat] += t - tp;
-                tp = t;
-            }
-        };
-        pb_gram_matrix<MU4>(A, lda, m, nact, npad, st, Gp, ld);
-        __syncthreads();
-        // convergence on the fresh Gram matrix: any pair above tol -> another sweep; any pair above the quadratic level ->
-        // the sweep after it is needed too
-        for (int e = tid; e < nact * nact; e += PB_NT) {
-            const int p = e % nact, q = e / nact;
-            if (p >= q) continue;
-            const double gpq = Gp[p * ld + q], ab = Gp[p * ld + p] * Gp[q * ld + q], g2 = gpq * gpq;
-            if (g2 > tol * tol * ab && g2 != 0.0) st.rot = 1;
-            if (g2 > (kQuadraticOff * kQuadraticOff) * ab) st.rot2 = 1;
-        }
-        __syncthreads();
-        const int any = st.rot, big = st.rot2;
-        stamp(13);
-        if (!any) break;
-        if (npad <= 16) {
-            if (tid < 64) pb_gram_rounds<1, true>(Gp, Jp, ld, npad, st, tol);
-            __syncthreads();
-        } else if (npad <= 32) {
-            pb_gram_rounds<1, false>(Gp, Jp, ld, npad, st, tol);
-        } else if (npad <= 44) {
-            pb_gram_rounds<2, false>(Gp, Jp, ld, npad, st, tol);
-        } else {
-            pb_gram_rounds<3, false>(Gp, Jp, ld, npad, st, tol);
-        }
-        // the padding position (odd nact): the one column of J that is still the unit vector of the padding row
-        if (npad != nact && tid < npad && Jp[nact * ld + tid] == 1.0) st.rank = tid;
-        __syncthreads();
-        stamp(14);
-        pb_gram_apply<NIT>(A, lda, m, nact, npad, st, Jp, ld, st.rank);
-        stamp(15);
-        rounds += npad - 1;
-        ++sweeps;
-        if (!big) break;                                          // quadratic phase: that sweep left rounding-level residue
-    }
-    // singular values = norms of the rotated columns
-    pb_col_norms2(A, lda, m, n, st, true);
-    __syncthreads();
-    if (prof && tid == 0) {
-        st.cyc[8] += 1;
-        st.cyc[9] += n;
-        st.cyc[10] += sweeps;
-        st.cyc[11] += rounds;
-        st.cyc[12] += nact;
-    }
-    return true;
-}
-
 __device__ void pb_jacobi(double* A, int lda, int m, int n, PbState& st, double tol, double negligible, int max_sweeps,
-                          bool prof, double* scratch, int scratch_doubles, bool gram) {
-    if (gram) {
-        bool done;
-        if (m <= 32) done = pb_jacobi_gram<8>(A, lda, m, n, st, tol, negligible, max_sweeps, scratch, scratch_doubles, prof);
-        else done = pb_jacobi_gram<16>(A, lda, m, n, st, tol, negligible, max_sweeps, scratch, scratch_doubles, prof);
-        if (done) return;
-    }
+                          bool prof) {
     if (n > 32) {                                     // more than 16 pairs a round: 8-lane rows, 32 pairs at once
         if (m <= 80) pb_jacobi_t<8, 10>(A, lda, m, n, st, tol, negligible, max_sweeps, prof);
         else if (m <= 112) pb_jacobi_t<8, 14>(A, lda, m, n, st, tol, negligible, max_sweeps, prof);
@@ -1197,11 +797,7 @@ __device__ void pb_truncate(PbState& st, const PbArgs& a, PbChain ch, double* ar
         __syncthreads();
         f = (st.red[0] + st.red[1]) + (st.red[2] + st.red[3]);
         pb_tick(st, 4, prof);
-        {
-            // LDS behind the copy of M[i] is free until the factors are formed (VT / US are written after the sweeps)
-            double* scratch = Mo + d * w;
-            pb_jacobi(Wk, ldw, rows, cols, st, 1e-15, 1e-30 * f, 40, prof, scratch, a.arena_doubles - (ldw * cols + d * w), a.gram != 0);
-        }
+        pb_jacobi(Wk, ldw, rows, cols, st, 1e-15, 1e-30 * f, 40, prof);
         pb_tick(st, 5, prof);
         // stable descending order + the ITensors truncation rule (qil_truncation_rank)
         if (tid < cols) {
@@ -1455,7 +1051,6 @@ static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* 
     a.dims_out = static_cast<int*>(dmeta);
     a.status = a.dims_out + (size_t)B * (L + 1);
     a.arena_doubles = arena_doubles;
-    a.gram = !(getenv("QIL_DT_GRAM") && atoi(getenv("QIL_DT_GRAM")) == 0);
     a.cycles = static_cast<unsigned long long*>(dcyc);
     if (prof) QIL_TRY(qil_timer_start(ctx));
     hipLaunchKernelGGL(dt_build_persistent, dim3(B), dim3(PB_NT), (size_t)arena_doubles * 8, qil_stream(ctx), a);
@@ -1500,9 +1095,8 @@ static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* 
             const unsigned long long* cb = cyc.data() + (size_t)bmax * PB_NCYC;
             for (int c = 0; c < 8; ++c) fprintf(stderr, " %s %.1f%%", names[c], 100.0 * cb[c] / std::max<double>((double)tmax, 1));
             const double nsb = std::max<double>((double)cb[8], 1.0);
-            fprintf(stderr, "; %llu SVDs, mean columns %.1f, sweeps %.2f, rounds %.1f; Gram sweeps: Gram matrix + flags %.1f%%, rounds %.1f%% (%.0f cycles per round), apply %.1f%% of the svd-jacobi cycles\n",
-                    cb[8], cb[9] / nsb, cb[10] / nsb, cb[11] / nsb, 100.0 * cb[13] / std::max<double>((double)cb[5], 1), 100.0 * cb[14] / std::max<double>((double)cb[5], 1),
-                    (double)cb[14] / std::max<double>((double)cb[11], 1), 100.0 * cb[15] / std::max<double>((double)cb[5], 1));
+            fprintf(stderr, "; %llu SVDs, mean columns %.1f, sweeps %.2f, rounds %.1f (%.0f cycles per round)\n", cb[8], cb[9] / nsb, cb[10] / nsb, cb[11] / nsb,
+                    (double)cb[5] / std::max<double>((double)cb[11], 1.0));
         }
         qil_ctx_free(ctx, dcyc);
     }
