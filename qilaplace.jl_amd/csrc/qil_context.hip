@@ -681,42 +681,46 @@ static void lockstep_run(qil_lockstep* ls, bool timing) {
         }
         waiting = false;
         spins = 0;
-        qil_launch_req* sel[QIL_MAXB];
-        int slot_of[QIL_MAXB], nsel = 0;
+        // The furthest-behind head decides the kernel class of this launch, and EVERY ring head of that class rides it -- also
+        // the heads of chains that are further along.  (Until r04 only heads at exactly the same (key, position) were combined:
+        // chains of different shapes -- the 64 (operator, state) pairs of a damping sweep: different bond dimensions, different
+        // split-K decisions and sweep counts -- are almost never at the same position, and 88 % of their launches carried ONE
+        // request: 240 k launches per batch of 64 pairs, the four streams launch-rate-bound at 4 us each.  A head that is issued
+        // early keeps its chain's own order; chains that are ahead advance only while their next kernel is of the class the
+        // laggard needs, which is what re-aligns them.)
+        int lead = -1;
         for (int s = 0; s < ls->nslots; ++s)
-            if (heads[s] != tails[s] && ls->q[s].ring[heads[s] % QIL_RING].progress == headkey &&
-                ls->q[s].ring[heads[s] % QIL_RING].seq == headseq) {
-                sel[nsel] = &ls->q[s].ring[heads[s] % QIL_RING];
-                slot_of[nsel++] = s;
-            }
-        bool taken[QIL_MAXB] = {};
-        for (int i = 0; i < nsel; ++i) {
-            if (taken[i]) continue;
-            qil_launch_req* grp[QIL_MAXB];
-            int gs[QIL_MAXB], n = 0;
-            for (int j = i; j < nsel; ++j) {
-                qil_launch_req* r = sel[j];
-                if (taken[j] || r->kern != sel[i]->kern || r->lds != sel[i]->lds || r->block.x != sel[i]->block.x ||
-                    r->block.y != sel[i]->block.y || r->block.z != sel[i]->block.z)
-                    continue;
-                taken[j] = true;
-                gs[n] = slot_of[j];
-                grp[n++] = r;
-            }
-            const auto tl0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            const int st = sel[i]->launch_group(grp, n, ls->stream);
-            if (timing) ls->launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count();
-            ++ls->launches;
-            ls->requests += n;
-            ++ls->group_hist[n];
-            for (int k = 0; k < n; ++k) {
-                qil_chainq& q = ls->q[gs[k]];
-                if (st != QIL_OK) {
-                    int ok = QIL_OK;
-                    q.status.compare_exchange_strong(ok, st);
+            if (heads[s] != tails[s]) {
+                const qil_launch_req& r = ls->q[s].ring[heads[s] % QIL_RING];
+                if (r.progress == headkey && r.seq == headseq) {
+                    lead = s;
+                    break;
                 }
-                q.head.store(q.head.load(std::memory_order_relaxed) + 1, std::memory_order_release);
             }
+        if (lead < 0) continue;
+        const qil_launch_req* lr = &ls->q[lead].ring[heads[lead] % QIL_RING];
+        qil_launch_req* grp[QIL_MAXB];
+        int gs[QIL_MAXB], n = 0;
+        for (int s = 0; s < ls->nslots && n < QIL_MAXB; ++s) {
+            if (heads[s] == tails[s]) continue;
+            qil_launch_req* r = &ls->q[s].ring[heads[s] % QIL_RING];
+            if (r->kern != lr->kern || r->block.x != lr->block.x || r->block.y != lr->block.y || r->block.z != lr->block.z) continue;
+            gs[n] = s;
+            grp[n++] = r;
+        }
+        const auto tl0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        const int st = lr->launch_group(grp, n, ls->stream);
+        if (timing) ls->launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count();
+        ++ls->launches;
+        ls->requests += n;
+        ++ls->group_hist[n];
+        for (int k = 0; k < n; ++k) {
+            qil_chainq& q = ls->q[gs[k]];
+            if (st != QIL_OK) {
+                int ok = QIL_OK;
+                q.status.compare_exchange_strong(ok, st);
+            }
+            q.head.store(q.head.load(std::memory_order_relaxed) + 1, std::memory_order_release);
         }
     }
     ls->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();

@@ -112,7 +112,11 @@ int qil_launch_group(qil_launch_req* const* reqs, int n, hipStream_t s) {
         memcpy(&t.it[i], reqs[i]->blob, sizeof(qil_pack<A...>));
     }
     for (int i = n; i < QIL_MAXB; ++i) t.gx[i] = t.gy[i] = t.gz[i] = 0;
-    hipLaunchKernelGGL((qil_kn<F, A...>), dim3(maxflat, (unsigned)n), reqs[0]->block, reqs[0]->lds, s, t);
+    // requests of one class may ask for different amounts of dynamic LDS (it follows the operand's shape): the launch takes the
+    // largest -- an operand that gets more than it asked for runs the same code on the same data
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) lds = std::max(lds, reqs[i]->lds);
+    hipLaunchKernelGGL((qil_kn<F, A...>), dim3(maxflat, (unsigned)n), reqs[0]->block, lds, s, t);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return qil_fail(QIL_EHIP, "combined launch failed: %s", hipGetErrorString(e));
     return QIL_OK;
