@@ -276,6 +276,21 @@ def truncate_operands(qil, n=24):
     return qil.build_zt_mpo(psi, 2 * np.pi), psi
 
 
+def truncate_roofline_batch64(t_batch):
+    """f64 matrix-core work of ONE 64-pair qil_apply_compress_batch (counted by the PMC pass of this build,
+    tools/collect_pmc_truncate.py) over the batch time measured here."""
+    pmc, src = pmc_truncate()
+    if not pmc or "apply_compress_batch64_zt" not in pmc:
+        return {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS, "achieved": None, "frac": None, "source": src,
+                "model": "no PMC pass of this build for the 64-pair batch under profiles/"}
+    b = pmc["apply_compress_batch64_zt"]
+    return {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS, "source": src,
+            "achieved": b["mfma_f64_flops"] / t_batch / 1e12, "frac": b["mfma_f64_flops"] / t_batch / 1e12 / F64_MFMA_PEAK_TFLOPS,
+            "mfma_f64_flops_per_batch": b["mfma_f64_flops"], "dispatches_per_batch": b["dispatches"],
+            "mfma_busy_share_of_simd_cycles": b["mfma_busy_cycles"] / (t_batch * 2.4e9 * 1024.0),
+            "model": "counted: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 per batch (3-repetition minus 1-repetition PMC run) over the batch time measured here"}
+
+
 def truncate_block(qil, ctx, reps=3, cpu=True):
     """The 'truncate' of apply-and-truncate on the pipeline's own operands (cfg4-shaped): n=24 structured signal
     encoded to chi ~15, genuine zT MPO (D ~89), product bond ~1008, truncated to maxdim 64 at tol 1e-8.  Every figure is the
@@ -343,6 +358,39 @@ def truncate_block(qil, ctx, reps=3, cpu=True):
             t_many[nbig] = time.perf_counter() - t0
             del many
     del one
+    # The batch as the operating point of the truncate half: the 64 (operator, state) pairs of a cfg4-shaped
+    # damping sweep -- 64 genuine zT operators of linspace(0.25, 16, 64) x the encoded signal -- through ONE
+    # qil_apply_compress_batch (fused apply-and-truncate per pair, maxdim 64, tol 1e-8), against one pair alone
+    sig64 = np.linspace(0.25, 16.0, 64)
+    W64 = qil.build_zt_mpo_batch(psi, sig64)
+    ctx.synchronize()
+    t_pair = []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        one_pair = qil.apply_compress(W64[32], psi, maxdim=maxdim, tol=tol)
+        ctx.synchronize()
+        if r:
+            t_pair.append(time.perf_counter() - t0)
+    t_b64 = []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        outs64 = qil.apply_compress_batch(W64, psi, maxdim=maxdim, tol=tol)
+        ctx.synchronize()
+        if r:
+            t_b64.append(time.perf_counter() - t0)
+    bits64 = np.random.default_rng(4).integers(0, 2, size=(64, 2 * n)).astype(np.uint8)
+    c_b, c_1 = qil.coefficient_batch(outs64[32], bits64), qil.coefficient_batch(one_pair, bits64)
+    batch64 = {
+        "op": "qil_apply_compress_batch: 64 (zT operator, signal) pairs, wr = linspace(0.25, 16, 64), n=24 paired, maxdim 64, tol 1e-8",
+        "product_bond_max": int(max(max(c * d for c, d in zip(psi.bond_dims, Wk.bond_dims)) for Wk in W64)),
+        "one_pair_ms": sum(t_pair) / reps * 1e3, "batch_ms": sum(t_b64) / reps * 1e3, "batch_ms_min": min(t_b64) * 1e3,
+        "batch_over_one_pair": (sum(t_b64) / reps) / (sum(t_pair) / reps), "pairs_per_s": 64 / (sum(t_b64) / reps),
+        "pairs_per_s_one_at_a_time": 1 / (sum(t_pair) / reps), "site_truncations_per_s": 64 * 2 * n / (sum(t_b64) / reps),
+        "bonds_max": int(max(max(o.bond_dims) for o in outs64)),
+        "item_32_equals_the_pair_alone": bool(np.array_equal(c_b, c_1)),
+    }
+    t_batch64 = sum(t_b64) / reps
+    del W64, outs64, one_pair
     bits = np.random.default_rng(3).integers(0, 2, size=(256, 2 * n)).astype(np.uint8)
     c_f, c_e = qil.coefficient_batch(fused, bits), qil.coefficient_batch(prod, bits)
     c_x = qil.apply_coefficient_batch(W, psi, bits)
@@ -411,8 +459,10 @@ def truncate_block(qil, ctx, reps=3, cpu=True):
         "compress_batch_of_32_ms": t_many[32] * 1e3, "batch_of_32_over_single": t_many[32] / t_one,
         "compress_batch_of_64_ms": t_many[64] * 1e3, "batch_of_64_over_single": t_many[64] / t_one,
         "chains_per_s_batch_of_32": 32 / t_many[32], "chains_per_s_batch_of_64": 64 / t_many[64], "chains_per_s_single": 1 / t_one,
+        "batch64": batch64,
         "cpu_baseline": cpu_res,
         "roofline": truncate_roofline(t_exact, t_one, f_exact, f_fused, t_fused),
+        "roofline_batch64": truncate_roofline_batch64(t_batch64),
     }
 
 

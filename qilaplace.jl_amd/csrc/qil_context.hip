@@ -3,6 +3,7 @@
 
 #include "qil_internal.h"
 #include "qil_launch.h"
+#include "qil_lockstep_core.h"
 
 #include <linux/futex.h>
 #include <sys/syscall.h>
@@ -480,127 +481,41 @@ static void chain_move(qil_chain* c, qil_context* to) {
 }
 
 // ---------------------------------------------------------------- lock-step batches (see qil_launch.h)
-constexpr unsigned QIL_RING = 256;       // launch requests a chain may be ahead of the launcher
-struct qil_chainq {
-    qil_launch_req ring[QIL_RING];
-    alignas(64) std::atomic<unsigned> head{0};     // next request to issue (launcher)
-    alignas(64) std::atomic<unsigned> tail{0};     // next free entry (the chain's thread)
-    std::atomic<uint64_t> key{0};                  // where the chain is working (mirrors ctx->progress_key)
-    std::atomic<unsigned> seq{0};                  // launches it has queued since the key last changed
-    std::atomic<int> live{1};
-    std::atomic<int> status{0};                    // first failed launch of this chain
-    // a chain thread that waits for a read-back SLEEPS here (futex) and the group's launcher, which polls anyway, watches the
-    // ticket word for it: the GPU boxes give a process a CPU quota (16 CPUs), and 32 chain threads spinning on their tickets
-    // exhaust it -- every thread is then throttled for the rest of the scheduler period (measured: three 45-55 ms stalls of
-    // all four queues per 32-chain batch)
-    std::atomic<uint32_t> parked{0};
-    const unsigned long long* wait_word = nullptr;
-    unsigned long long wait_ticket = 0;
-};
-struct qil_lockstep {
-    int nslots = 0;
-    qil_chainq* q = nullptr;
-    hipStream_t stream = nullptr;                  // the one stream all slots share
-    long long requests = 0, launches = 0, timeouts = 0;
-    double launch_us = 0, total_us = 0;            // QIL_BATCH_DEBUG: time inside the launch calls / of the launcher loop
-    long long group_hist[QIL_MAXB + 1] = {};
-};
+// The rings, the launcher loop and the park / wake protocol are the HIP-free templates of qil_lockstep_core.h (the same code
+// runs under ThreadSanitizer in tests/lockstep_stress.cpp); here they are bound to qil_launch_req and the HIP stream.
+static_assert(QIL_LS_MAXB == QIL_MAXB, "qil_lockstep_core.h and qil_launch.h disagree on the operands per combined launch");
+using qil_chainq = qil_chainq_t<qil_launch_req>;
+struct qil_lockstep : qil_lockstep_t<qil_launch_req, hipStream_t> {};
 
 void qil_progress_step(qil_context* ctx, bool new_pass, long long step) {
     if (!ctx) return;
     uint64_t pass = ctx->progress_key >> 40;
     if (new_pass) ++pass;
     ctx->progress_key = (pass << 40) | ((uint64_t)(step & 0xfffff) << 16);
-    if (ctx->lockstep) {
-        ctx->lockstep->q[ctx->ls_slot].seq.store(0, std::memory_order_relaxed);
-        ctx->lockstep->q[ctx->ls_slot].key.store(ctx->progress_key, std::memory_order_release);
-    }
+    if (ctx->lockstep) qil_ls_set_key(ctx->lockstep->q[ctx->ls_slot], ctx->progress_key);
 }
 void qil_progress_phase(qil_context* ctx, int phase) {
     if (!ctx) return;
     const uint64_t nk = (ctx->progress_key & ~0xffffull) | (uint64_t)(phase & 0xffff);
     if (nk == ctx->progress_key) return;
     ctx->progress_key = nk;
-    if (ctx->lockstep) {
-        ctx->lockstep->q[ctx->ls_slot].seq.store(0, std::memory_order_relaxed);
-        ctx->lockstep->q[ctx->ls_slot].key.store(nk, std::memory_order_release);
-    }
+    if (ctx->lockstep) qil_ls_set_key(ctx->lockstep->q[ctx->ls_slot], nk);
 }
 
-static inline void futex_wait_for(std::atomic<uint32_t>* a, uint32_t expected, long timeout_ns) {
-    timespec ts{0, timeout_ns};
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(a), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
-}
-static inline void futex_wake_one(std::atomic<uint32_t>* a) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(a), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
-}
-// chain side: sleep until *word >= ticket (the launcher wakes the thread; the timeout only bounds a lost wake-up).  Returns
-// QIL_OK when the ticket has arrived, the chain's failed-launch status if a combined launch of this chain failed meanwhile (its
-// read-back kernel may never run), QIL_EHIP after 60 s -- the caller must not wait for ever on a device that has faulted.
+// chain side: sleep until *word >= ticket.  QIL_OK, the chain's failed-launch status, or QIL_EHIP after 60 s.
 int qil_lockstep_park(qil_context* ctx, const unsigned long long* word, unsigned long long ticket) {
-    qil_chainq& q = ctx->lockstep->q[ctx->ls_slot];
-    const auto t0 = std::chrono::steady_clock::now();
-    while (__atomic_load_n(word, __ATOMIC_ACQUIRE) < ticket) {
-        const int st = q.status.load(std::memory_order_acquire);
-        if (st != QIL_OK && q.head.load(std::memory_order_acquire) == q.tail.load(std::memory_order_relaxed)) return st;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return QIL_EHIP;
-        q.wait_word = word;
-        q.wait_ticket = ticket;
-        q.parked.store(1, std::memory_order_release);
-        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) >= ticket) {
-            q.parked.store(0, std::memory_order_relaxed);
-            break;
-        }
-        futex_wait_for(&q.parked, 1, 20 * 1000 * 1000);
-        q.parked.store(0, std::memory_order_relaxed);
-    }
-    return QIL_OK;
-}
-// launcher side: wake the chains whose tickets have arrived
-static inline void lockstep_wake_arrived(qil_lockstep* ls) {
-    for (int s = 0; s < ls->nslots; ++s) {
-        qil_chainq& q = ls->q[s];
-        if (q.parked.load(std::memory_order_acquire) == 1 && __atomic_load_n(q.wait_word, __ATOMIC_ACQUIRE) >= q.wait_ticket) {
-            uint32_t one = 1;
-            if (q.parked.compare_exchange_strong(one, 2, std::memory_order_acq_rel)) futex_wake_one(&q.parked);
-        }
-    }
-}
-static inline void spin_pause(int& spins) {
-    if (++spins < (1 << 14))
-        __builtin_ia32_pause();
-    else
-        std::this_thread::yield();
+    return qil_ls_park(ctx->lockstep->q[ctx->ls_slot], word, ticket, QIL_EHIP);
 }
 
 qil_launch_req* qil_lockstep_begin(qil_lockstep* ls, qil_context* ctx) {
-    qil_chainq& q = ls->q[ctx->ls_slot];
-    const unsigned t = q.tail.load(std::memory_order_relaxed);
-    int spins = 0;
-    if (t - q.head.load(std::memory_order_acquire) >= QIL_RING) {                       // ring full
-        const auto t0 = std::chrono::steady_clock::now();
-        while (t - q.head.load(std::memory_order_acquire) >= QIL_RING) spin_pause(spins);
-        if (ctx->dbg_times) ctx->dbg_ring_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    }
-    qil_launch_req* r = &q.ring[t % QIL_RING];
-    r->progress = ctx->progress_key;
-    r->seq = q.seq.load(std::memory_order_relaxed);
-    return r;
+    return qil_ls_begin(ls->q[ctx->ls_slot], ctx->progress_key, ctx->dbg_times ? &ctx->dbg_ring_us : nullptr);
 }
 int qil_lockstep_commit(qil_lockstep* ls, qil_context* ctx) {
-    qil_chainq& q = ls->q[ctx->ls_slot];
-    q.seq.store(q.seq.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
-    q.tail.store(q.tail.load(std::memory_order_relaxed) + 1, std::memory_order_release);
-    const int st = q.status.load(std::memory_order_relaxed);
+    const int st = qil_ls_commit(ls->q[ctx->ls_slot]);
     return st == QIL_OK ? QIL_OK : qil_fail(st, "a combined launch of this chain failed");
 }
 void qil_lockstep_drain(qil_context* ctx) {
-    qil_lockstep* ls = ctx->lockstep;
-    if (!ls) return;
-    qil_chainq& q = ls->q[ctx->ls_slot];
-    const unsigned t = q.tail.load(std::memory_order_relaxed);
-    int spins = 0;
-    while (q.head.load(std::memory_order_acquire) != t) spin_pause(spins);
+    if (ctx->lockstep) qil_ls_drain(ctx->lockstep->q[ctx->ls_slot]);
 }
 
 hipError_t qil_stream_sync(qil_context* ctx) {
@@ -622,109 +537,7 @@ hipError_t qil_event_sync(qil_context* ctx, hipEvent_t ev) {
     return hipEventSynchronize(ev);
 }
 
-// the launcher: until every chain has left and every ring is empty.  A launch goes out when every chain that is no further
-// along than the heads to be issued has queued its own next step (so that they share the launch) -- or after `patience` of
-// waiting for such a chain (it may be deep in host work or waiting for the device).
-static void lockstep_run(qil_lockstep* ls, bool timing) {
-    int spins = 0;
-    const auto t_begin = std::chrono::steady_clock::now();
-    // (measured, 8 chains chi 256: 50 us -> 7441 launches / 161 ms, 200 us -> 7039 / 160 ms, 1 ms -> 6979 / 155 ms, 5 ms -> 6976 / 146 ms)
-    const auto patience = std::chrono::microseconds(2000);
-    bool waiting = false;
-    std::chrono::steady_clock::time_point wait_since;
-    for (;;) {
-        lockstep_wake_arrived(ls);
-        // order = (progress key, position inside the key's segment): chains running the same program queue the same kernel
-        // at the same position, so serving the smallest position first re-aligns chains that are one step apart
-        uint64_t headkey = ~0ull, idlekey = ~0ull;
-        unsigned headseq = ~0u, idleseq = ~0u;
-        bool any = false;
-        unsigned heads[QIL_MAXB], tails[QIL_MAXB];
-        for (int s = 0; s < ls->nslots; ++s) {
-            qil_chainq& q = ls->q[s];
-            const int live = q.live.load(std::memory_order_acquire);
-            tails[s] = q.tail.load(std::memory_order_acquire);
-            heads[s] = q.head.load(std::memory_order_relaxed);
-            if (heads[s] != tails[s]) {
-                any = true;
-                const qil_launch_req& r = q.ring[heads[s] % QIL_RING];
-                if (r.progress < headkey || (r.progress == headkey && r.seq < headseq)) {
-                    headkey = r.progress;
-                    headseq = r.seq;
-                }
-            } else if (live) {
-                any = true;
-                const uint64_t k = q.key.load(std::memory_order_acquire);
-                const unsigned sq = q.seq.load(std::memory_order_relaxed);
-                if (k < idlekey || (k == idlekey && sq < idleseq)) {
-                    idlekey = k;
-                    idleseq = sq;
-                }
-            }
-        }
-        if (!any) break;
-        if (headkey == ~0ull) {                                 // nothing queued anywhere
-            spin_pause(spins);
-            continue;
-        }
-        if (idlekey < headkey || (idlekey == headkey && idleseq <= headseq)) {   // a chain that is not ahead has not queued this step yet
-            const auto now = std::chrono::steady_clock::now();
-            if (!waiting) {
-                waiting = true;
-                wait_since = now;
-            }
-            if (now - wait_since < patience) {
-                __builtin_ia32_pause();
-                continue;
-            }
-            ++ls->timeouts;
-        }
-        waiting = false;
-        spins = 0;
-        // The furthest-behind head decides the kernel class of this launch, and EVERY ring head of that class rides it -- also
-        // the heads of chains that are further along.  (Until r04 only heads at exactly the same (key, position) were combined:
-        // chains of different shapes -- the 64 (operator, state) pairs of a damping sweep: different bond dimensions, different
-        // split-K decisions and sweep counts -- are almost never at the same position, and 88 % of their launches carried ONE
-        // request: 240 k launches per batch of 64 pairs, the four streams launch-rate-bound at 4 us each.  A head that is issued
-        // early keeps its chain's own order; chains that are ahead advance only while their next kernel is of the class the
-        // laggard needs, which is what re-aligns them.)
-        int lead = -1;
-        for (int s = 0; s < ls->nslots; ++s)
-            if (heads[s] != tails[s]) {
-                const qil_launch_req& r = ls->q[s].ring[heads[s] % QIL_RING];
-                if (r.progress == headkey && r.seq == headseq) {
-                    lead = s;
-                    break;
-                }
-            }
-        if (lead < 0) continue;
-        const qil_launch_req* lr = &ls->q[lead].ring[heads[lead] % QIL_RING];
-        qil_launch_req* grp[QIL_MAXB];
-        int gs[QIL_MAXB], n = 0;
-        for (int s = 0; s < ls->nslots && n < QIL_MAXB; ++s) {
-            if (heads[s] == tails[s]) continue;
-            qil_launch_req* r = &ls->q[s].ring[heads[s] % QIL_RING];
-            if (r->kern != lr->kern || r->block.x != lr->block.x || r->block.y != lr->block.y || r->block.z != lr->block.z) continue;
-            gs[n] = s;
-            grp[n++] = r;
-        }
-        const auto tl0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        const int st = lr->launch_group(grp, n, ls->stream);
-        if (timing) ls->launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count();
-        ++ls->launches;
-        ls->requests += n;
-        ++ls->group_hist[n];
-        for (int k = 0; k < n; ++k) {
-            qil_chainq& q = ls->q[gs[k]];
-            if (st != QIL_OK) {
-                int ok = QIL_OK;
-                q.status.compare_exchange_strong(ok, st);
-            }
-            q.head.store(q.head.load(std::memory_order_relaxed) + 1, std::memory_order_release);
-        }
-    }
-    ls->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
-}
+static void lockstep_run(qil_lockstep* ls, bool timing) { qil_ls_run(ls, timing); }
 
 // CPUs this process may keep busy: the cgroup quota (cpu.max, v2; cfs_quota_us / cfs_period_us, v1) or the affinity mask, whichever
 // is smaller, divided by the ranks that share the node (LOCAL_WORLD_SIZE of torch.distributed.run / bench.py's spawner);

@@ -2232,6 +2232,101 @@ def test_batches_on_a_second_context_and_one_worker(qil, monkeypatch):
         assert b.bond_dims == r.bond_dims
 
 
+def test_batch_stress_two_contexts_two_threads_with_failures(qil):
+    """Stress of the lock-step batch runner: 200 batch calls -- compress_batch, apply_compress_batch and
+    signal_mps_batch of 5 ... 32 items in random order -- issued back to back from TWO host threads on TWO contexts at once,
+    with an allocation failure injected into the item that runs on the calling context's own slot of some 32-item batches (the
+    items are shuffled, so it is a random item).  Every successful call returns exactly the tensors of the one-at-a-time calls
+    (bit-identical), a failing call raises and leaves no device memory behind, the next call on that context works, and nothing
+    hangs (the 10-minute per-test timeout is the watchdog)."""
+    import threading
+    rng0 = np.random.default_rng(2024)
+    L = 9
+    specs = [(chi, dt) for chi in (8, 12, 16, 24) for dt in (np.float64, np.complex128)]
+    mps_data = [random_mps_data(saturated_profile(L, chi), rng0, dtype=dt) for chi, dt in specs for _ in range(4)]      # 32 chains
+    w_data = [random_mpo_data(saturated_profile(L, D, base=4), rng0, dtype=dt) for D, dt in ((4, np.float64), (6, np.complex128), (8, np.float64))]
+    sigs = [np.sin(0.01 * (j + 1) * np.arange(2 ** 12)) * np.exp(-1e-3 * np.arange(2 ** 12)) + 1e-3 * rng0.standard_normal(2 ** 12)
+            for j in range(16)]
+    # one-at-a-time references on the default context
+    ref_c = [qil.compress(qil.SignalMPS([t.copy() for t in a]), maxdim=6, tol=1e-9).to_host() for a in mps_data]
+    Wd = [qil.SingleSiteMPO(w) for w in w_data]
+    ref_a = {}
+    for wi, W in enumerate(Wd):
+        for ai in range(0, len(mps_data), 3):
+            ref_a[(wi, ai)] = qil.apply_compress(W, qil.SignalMPS(mps_data[ai]), maxdim=8, tol=1e-8).to_host()
+    ref_s = [qil.signal_mps(x, method="rsvd", k=12, p=4, q=1).to_host() for x in sigs]
+    del Wd
+    errors, counts = [], {"calls": 0, "failed": 0}
+    lock = threading.Lock()
+
+    def same(got, want, what):
+        if len(got) != len(want) or any(not np.array_equal(g, w) for g, w in zip(got, want)):
+            raise AssertionError(f"{what}: batch result differs from the one-at-a-time result")
+
+    def worker(seed):
+        try:
+            ctx = qil.Context(0)
+            rng = np.random.default_rng(seed)
+            Ws = [qil.SingleSiteMPO(w, ctx=ctx) for w in w_data]
+            for call in range(100):
+                kind = int(rng.integers(0, 3))
+                inject = kind == 0 and rng.random() < 0.25
+                nb = 32 if inject else int(rng.integers(5, 33))
+                if kind == 0:
+                    idx = rng.permutation(len(mps_data))[:nb]
+                    items = [qil.SignalMPS([t.copy() for t in mps_data[j]], ctx=ctx) for j in idx]
+                    if inject:
+                        ctx.fail_alloc_after(int(rng.integers(0, 40)))
+                    try:
+                        qil.compress_batch(items, maxdim=6, tol=1e-9)
+                        failed = False
+                    except MemoryError:
+                        failed = True
+                    finally:
+                        ctx.fail_alloc_after(None)
+                    if inject and failed:
+                        with lock:
+                            counts["failed"] += 1
+                        assert ctx.unowned_bytes() == 0
+                        for it in items:                                   # in-place operands are still whole chains
+                            assert np.isfinite(qil.norm(it))
+                    else:
+                        for j, it in zip(idx, items):
+                            same(it.to_host(), ref_c[j], f"compress_batch item {j}")
+                    del items
+                elif kind == 1:
+                    keys = [list(ref_a)[int(t)] for t in rng.integers(0, len(ref_a), size=nb)]
+                    psis = {ai: qil.SignalMPS(mps_data[ai], ctx=ctx) for _, ai in keys}
+                    outs = qil.apply_compress_batch([Ws[wi] for wi, _ in keys], [psis[ai] for _, ai in keys], maxdim=8, tol=1e-8)
+                    for key, o in zip(keys, outs):
+                        same(o.to_host(), ref_a[key], f"apply_compress_batch pair {key}")
+                    del outs, psis
+                else:
+                    idx = rng.integers(0, len(sigs), size=min(nb, 12))
+                    outs = qil.signal_mps_batch([sigs[int(j)] for j in idx], method="rsvd", k=12, p=4, q=1, ctx=ctx)
+                    for j, o in zip(idx, outs):
+                        same(o.to_host(), ref_s[int(j)], f"signal_mps_batch item {j}")
+                    del outs
+                assert ctx.unowned_bytes() == 0
+                with lock:
+                    counts["calls"] += 1
+            del Ws
+            import gc
+            gc.collect()
+            ctx.close()
+        except BaseException as e:          # noqa: BLE001  (reported on the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (11, 22)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert counts["calls"] == 200 and counts["failed"] >= 3, counts
+    assert qil.default_context().unowned_bytes() == 0
+
+
 def test_signal_batch_encoders_equal_item_by_item(qil):
     """qil_signal_mps_batch / qil_signal_ztmps_batch: the signals of a sweep encoded concurrently give the tensors of the
     one-at-a-time encoders (SVD and RSVD, real and complex, more signals than slots); all or nothing on failure."""

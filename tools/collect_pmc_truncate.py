@@ -3,9 +3,10 @@
 f64 MFMA flops), SQ_VALU_MFMA_BUSY_CYCLES and SQ_INSTS_VALU summed over every dispatch of
   * the exact route of the bench's truncate block, compress!(W_zt psi; maxdim=64, tol=1e-8) on the bond-1008 product
     (tools/_exact_compress_time.py), and
-  * compress! chi 256 -> 128 on 24 sites (tools/_compress_one.py 256 f64),
+  * compress! chi 256 -> 128 on 24 sites (tools/_compress_one.py 256 f64), and
+  * (r04) ONE qil_apply_compress_batch of the 64 (zT operator, signal) pairs of a damping sweep (tools/_apply_compress_batch64.py),
 each as the DIFFERENCE of a 3-repetition and a 1-repetition run (the set-up -- encode, MPO build, warm-up -- cancels), per
-repetition.  Writes gpurun_out/r03_pmc_truncate.json keyed to the library's sha256 (copy it to profiles/): bench.py reports
+repetition.  Writes gpurun_out/r04_pmc_truncate.json keyed to the library's sha256 (copy it to profiles/): bench.py reports
 `truncate.roofline` from it only while the sha matches the library it runs.  PMC passes serialise the kernels, so times come
 from the un-profiled bench run, never from here.
 
@@ -31,7 +32,13 @@ def one_pass(tag, script_args):
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out, exist_ok=True)
     cmd = ["rocprofv3", "--pmc"] + COUNTERS + ["-d", out, "--output-format", "csv", "--", sys.executable] + script_args
-    subprocess.run(cmd, check=True, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL)
+    for attempt in range(4):          # (the profiler's interception layer crashes on multi-threaded batches about one run in three)
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out, exist_ok=True)
+        if subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL).returncode == 0:
+            break
+    else:
+        raise RuntimeError("rocprofv3 --pmc failed four times: " + " ".join(script_args))
     tot = collections.defaultdict(float)
     per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = 0
@@ -68,9 +75,12 @@ def main():
     rec = {"lib_sha16": sha,
            "_note": "per repetition, (3-repetition run - 1-repetition run) / 2; flops = SQ_INSTS_VALU_MFMA_MOPS_F64 * 512",
            "exact_compress_product_1008": workload("exact", "_exact_compress_time.py", lambda r: [str(r)]),
-           "compress_chi256_24_sites": workload("chi256", "_compress_one.py", lambda r: ["256", "f64", str(r)])}
+           "compress_chi256_24_sites": workload("chi256", "_compress_one.py", lambda r: ["256", "f64", str(r)]),
+           # the batch as the operating point of the truncate half: 64 (zT operator, signal) pairs of a damping sweep through
+           # ONE qil_apply_compress_batch (tools/_apply_compress_batch64.py 64 zt <repetitions>)
+           "apply_compress_batch64_zt": workload("batch64", "_apply_compress_batch64.py", lambda r: ["64", "zt", str(r)])}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r03_pmc_truncate.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r04_pmc_truncate.json"), "w"), indent=1)
     print(json.dumps(rec))
 
 
