@@ -292,6 +292,20 @@ int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n, int dty
 int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff,
                            int64_t maxdim, const int64_t* site_ids, qil_mpo** out);
 
+/* build_qft_mpo(n, sites; cutoff=1e-14, maxdim=1000) src/transforms/qft_transformer.jl:121-165 ENTIRELY on the device: one
+ * launch of one workgroup runs the whole chain of zip-ups (:13-66) and truncating zip-downs (:69-101) with the tensors in
+ * LDS (bonds <= 8, <= 16 before a truncation); only the 2 x 2 gate blocks of control_Hphase_mpo (qft_gates.jl:43-97)
+ * come from the host.  Result: a SingleSiteMPO handle (complex) with the reference's bond dimensions and, to rounding,
+ * its dense operator (gauges differ).  *fallback = 1 (and no handle) when a bond exceeded the in-LDS capacity: the
+ * caller takes the generic route (qil_apply_mpo_mpo + qil_mpo_compress per layer).                                    */
+int qil_build_qft_mpo(qil_context* ctx, int64_t n, double cutoff, int64_t maxdim, const int64_t* site_ids,
+                      qil_mpo** out, int* fallback);
+/* The paired-register QFT half of build_zt_mpo (src/transforms/zt_transformer.jl:78-99: identity extension, zip_to_combine
+ * "down", zip_to_compress "down" per block control_Hphase_ztmps_mpo, zt_gates.jl:12-114), same persistent kernel; a
+ * PairedSiteMPO handle over 2 n tensors main_1, copy_1, ...                                                          */
+int qil_build_zt_qft_chain(qil_context* ctx, int64_t n, double cutoff, int64_t maxdim, const int64_t* site_ids,
+                           qil_mpo** out, int* fallback);
+
 /* C (m x n) = opA(A) * opB(B) on host operands, column-major; op: 0 = N, 1 = T, 2 = H, 3 = conj.
  * The f64-MFMA GEMM every contraction of the truncation/encode path goes through (the `*` of
  * mps.jl:930,947; rsvd.jl:79,89,93,98,114); exported as a utility and test hook.                */

@@ -371,7 +371,20 @@ def zt_qft_chain_tensors(n, cutoff=1e-14, maxdim=1000):
 
 
 # ------------------------------------------------------------------ QFT chains assembled ON THE DEVICE
-def qft_mpo_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
+def _persistent_chain(fn, cls, n, ids, cutoff, maxdim, ctx):
+    """One launch of the persistent complex chain builder (csrc/qil_build_chain.hip); None when a bond exceeded its in-LDS
+    capacity (the caller takes the generic device route)."""
+    import ctypes as C
+    from . import _lib as L
+    out, fb = C.c_void_p(), C.c_int(0)
+    arr = (C.c_int64 * len(ids))(*ids)
+    L.check(fn(ctx.handle, int(n), float(cutoff), -1 if maxdim is None else int(maxdim), arr, C.byref(out), C.byref(fb)))
+    if fb.value:
+        return None
+    return cls(ctx=ctx, _handle=C.c_void_p(out.value))
+
+
+def qft_mpo_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None, persistent=True):
     """build_qft_mpo (qft_transformer.jl:121-165) with every factorisation on the GPU: round `it` multiplies the chain by the
     block control_Hphase_mpo(n - it) on its trailing sites -- the window product of apply(W1, W2) (apply.jl:124-199 ->
     qil_apply_mpo_mpo), exact, the bonds multiply -- and re-truncates it with zip_to_compress_mpo "up" (exact QR gauge
@@ -384,6 +397,11 @@ def qft_mpo_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
         raise ValueError(f"build_qft_mpo: Number of qubits 'n' must be at least 1. Found n={n}")
     ctx = ctx or default_context()
     ids = [int(i) for i in sites] if sites is not None else list(range(1, n + 1))
+    if persistent:
+        from . import _lib as L
+        W = _persistent_chain(L.lib.qil_build_qft_mpo, SingleSiteMPO, n, ids, cutoff, maxdim, ctx)
+        if W is not None:
+            return W
     M = SingleSiteMPO(_qft_block(n), sites=ids, ctx=ctx)
     for it in range(1, n):
         B = SingleSiteMPO(_qft_block(n - it), sites=ids[it:], ctx=ctx)
@@ -392,7 +410,7 @@ def qft_mpo_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
     return M
 
 
-def zt_qft_chain_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
+def zt_qft_chain_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None, persistent=True):
     """The paired-register QFT half of build_zt_mpo (zt_transformer.jl:78-99) on the GPU: for k = 2..n the chain (2k - 2
     sites) is multiplied by control_Hphase_ztmps_mpo(k) (2k sites; the two new sites see the identity: the window product
     pads the shorter operand exactly as the reference's identity extension does) and compressed "down"
@@ -403,6 +421,11 @@ def zt_qft_chain_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None):
         raise ValueError(f"build_zt_mpo: n must be >= 1. Found n={n}")
     ctx = ctx or default_context()
     ids = [int(i) for i in sites] if sites is not None else list(range(1, 2 * n + 1))
+    if persistent:
+        from . import _lib as L
+        W = _persistent_chain(L.lib.qil_build_zt_qft_chain, PairedSiteMPO, n, ids, cutoff, maxdim, ctx)
+        if W is not None:
+            return W
     Q = PairedSiteMPO(_zt_block(1), sites=ids[:2], ctx=ctx)
     for k in range(2, n + 1):
         B = PairedSiteMPO(_zt_block(k), sites=ids[:2 * k], ctx=ctx)
