@@ -269,16 +269,17 @@ def _n_of(x):
     return len(x) if hasattr(x, "handle") else int(x)
 
 
-def build_qft_mpo(n_or_psi, sites=None, cutoff=1e-14, maxdim=1000, ctx=None, device=False):
-    """build_qft_mpo(n, sites; cutoff, maxdim) / build_qft_mpo(psi::SignalMPS; ...).  `device`: every factorisation of the
-    chain on the GPU (`qft_mpo_device`); default: the host chain (`qft_mpo_tensors`; D <= 8, milliseconds)."""
+def build_qft_mpo(n_or_psi, sites=None, cutoff=1e-14, maxdim=1000, ctx=None, device=None):
+    """build_qft_mpo(n, sites; cutoff, maxdim) / build_qft_mpo(psi::SignalMPS; ...).  Default (`device` None / True): the whole
+    chain in one launch of the persistent complex builder (`qft_mpo_device` -> qil_build_qft_mpo; r04: n = 24 in 11 ms against
+    13 ms for the host chain + upload, n = 8 0.8 against 1.6 ms); `device=False`: the host chain (`qft_mpo_tensors`, numpy)."""
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
     n = _n_of(n_or_psi)
     if sites is not None and len(sites) != n:
         raise ValueError(f"build_qft_mpo: Number of sites must be equal to n. Found length(sites)={len(sites)}, n={n}")
     if psi is not None and sites is None:
         sites, ctx = psi.site_ids, ctx or psi.ctx
-    if device:
+    if device is None or device:
         return qft_mpo_device(n, sites, cutoff, maxdim, ctx)
     return SingleSiteMPO(qft_mpo_tensors(n, cutoff, maxdim), sites=sites, ctx=ctx)
 

@@ -1466,7 +1466,7 @@ def test_device_qft_builders(qil, pins):
     assert W.site_ids == ids
     fx = np.fft.fft(x) / np.sqrt(2 ** n)
     err_d = np.abs(qil.mps_to_vector(W * psi, reverse=True) - fx).max()
-    err_h = np.abs(qil.mps_to_vector(qil.build_qft_mpo(psi) * psi, reverse=True) - fx).max()
+    err_h = np.abs(qil.mps_to_vector(qil.build_qft_mpo(psi, device=False) * psi, reverse=True) - fx).max()
     # MPO cutoff 1e-14: ~1e-7 per truncated bond either way (measured 9.5e-7 on the device chain)
     assert err_d < 5e-6 and err_d < 5 * max(err_h, 1e-7), (err_d, err_h)
     # the paired chain: same operator as the host chain (and the oracle's) ...
@@ -1491,6 +1491,61 @@ def test_device_qft_builders(qil, pins):
         assert rel(qil.coefficient_batch(Wd * psi, bits), qil.coefficient_batch(Wh * psi, bits)) < 1e-9
     with pytest.raises(ValueError, match="qft must be"):
         qil.build_zt_mpo_batch(3, [1.0], qft="gpu")
+
+
+def test_persistent_qft_builders(qil, pins):
+    """The persistent complex chain builder (csrc/qil_build_chain.hip, r04): build_qft_mpo (qft_transformer.jl:121-165) and the
+    paired QFT chain of build_zt_mpo (zt_transformer.jl:78-99) in ONE launch each.  Same bond dimensions as the host chains
+    and as the generic device route for n = 2 .. 24 at cutoff 1e-14 and 1e-15, dense operators equal the oracle's (n <= 6,
+    1e-12), the reference's max-bond series, site labels, a cap that binds, the FFT itself at n = 16, and the default route of
+    build_qft_mpo IS this kernel."""
+    from helpers import dense_mpo
+    series = pins["mpo_maxbond_n2_30"]["qft"]
+    for n in (1, 2, 3, 4, 5, 6):
+        W = qil.qft_mpo_device(n)                                       # persistent=True
+        G = qil.qft_mpo_device(n, persistent=False)                     # window products + zip_to_compress per layer
+        ref = O.build_qft_mpo(n)
+        assert W.bond_dims == ref.bond_dims == G.bond_dims and not W.paired
+        assert np.abs(dense_mpo(W.to_host()) - dense_mpo(ref.data)).max() < 1e-12, n
+        Q = qil.zt_qft_chain_device(n)
+        Qh = qil.zt_qft_chain_tensors(n)
+        assert Q.paired and Q.bond_dims == [t.shape[3] for t in Qh[:-1]] == qil.zt_qft_chain_device(n, persistent=False).bond_dims
+        assert np.abs(dense_mpo(Q.to_host()) - dense_mpo(Qh)).max() < 1e-12, n
+    for n in (7, 8, 12, 16, 20, 24):
+        for cutoff in (1e-14, 1e-15):
+            W = qil.qft_mpo_device(n, cutoff=cutoff, maxdim=None)
+            assert W.bond_dims == [t.shape[3] for t in qil.qft_mpo_tensors(n, cutoff, None)[:-1]], (n, cutoff)
+            if cutoff == 1e-15 and n - 2 < len(series):
+                assert max(W.bond_dims) == series[n - 2], (n, W.bond_dims)
+            Q = qil.zt_qft_chain_device(n, cutoff=cutoff, maxdim=None)
+            assert Q.bond_dims == [t.shape[3] for t in qil.zt_qft_chain_tensors(n, cutoff, None)[:-1]], (n, cutoff)
+    # maxdim binds: the cap of the truncating sweeps
+    W = qil.qft_mpo_device(12, cutoff=1e-14, maxdim=5)
+    assert max(W.bond_dims) == 5 and W.bond_dims == [t.shape[3] for t in qil.qft_mpo_tensors(12, 1e-14, 5)[:-1]]
+    # the transform: default build_qft_mpo (this kernel) on a labelled signal against numpy's FFT
+    n = 16
+    x = np.random.default_rng(5).standard_normal(2 ** n)
+    psi = qil.signal_mps(x, cutoff=1e-14)
+    ids = [3 + 5 * i for i in range(n)]
+    psi = qil.SignalMPS(psi.to_host(), amplitude=psi.amplitude, sites=ids)
+    W = qil.build_qft_mpo(psi)
+    assert W.site_ids == ids and W.to_host()[0].dtype == np.complex128
+    fx = np.fft.fft(x) / np.sqrt(2 ** n)
+    err_d = np.abs(qil.mps_to_vector(W * psi, reverse=True) - fx).max()
+    err_h = np.abs(qil.mps_to_vector(qil.build_qft_mpo(psi, device=False) * psi, reverse=True) - fx).max()
+    assert err_d < 5e-6 and err_d < 5 * max(err_h, 1e-7), (err_d, err_h)
+    # the whole zT build with the persistent halves, against the host builder on sampled coefficients
+    n = 6
+    a = random_mps_data(saturated_profile(2 * n, 6), np.random.default_rng(4))
+    zpsi = qil.ZTMPS(a)
+    bits = np.random.default_rng(5).integers(0, 2, size=(128, 2 * n))
+    Wd = qil.build_zt_mpo_batch(zpsi, [2 * np.pi], qft="device")[0]
+    Wh = qil.build_zt_mpo(zpsi, 2 * np.pi, device=False)
+    assert Wd.bond_dims == Wh.bond_dims
+    assert rel(qil.coefficient_batch(Wd * zpsi, bits), qil.coefficient_batch(Wh * zpsi, bits)) < 1e-9
+    with pytest.raises(Exception, match="at least 1"):
+        qil.qft_mpo_device(0)
+    assert qil.default_context().unowned_bytes() == 0
 
 
 def test_failed_calls_leave_no_device_memory_behind(qil):

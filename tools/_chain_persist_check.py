@@ -36,3 +36,5 @@ def host_chain():
     B._ZT_Q_CACHE.clear(); return qil.zt_qft_chain_tensors(n)
 print(f"n=24 paired QFT chain: persistent {timeit(lambda: qil.zt_qft_chain_device(n)):.1f} ms, generic device route {timeit(lambda: qil.zt_qft_chain_device(n, persistent=False)):.1f} ms, "
       f"host numpy {timeit(host_chain):.1f} ms")
+for n in (6, 8, 12, 16):
+    print(f"n={n} build_qft_mpo: persistent {timeit(lambda: qil.qft_mpo_device(n)):.2f} ms, host numpy + upload {timeit(lambda: qil.build_qft_mpo(n, device=False)):.2f} ms")
