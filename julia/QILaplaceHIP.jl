@@ -17,7 +17,7 @@ using ..Mpo: SingleSiteMPO, PairedSiteMPO
 using ..ApplyMPO: _as_single_site_mpo
 
 export DeviceMPS, DeviceMPO, to_device, to_host, signal_mps_device, marginal, mps_block, apply_compress,
-    compress_mpo!, build_dt_mpo_batch, apply_coefficient_sweep, apply!, rsvd_device, svd_device
+    compress_mpo!, build_dt_mpo_batch, build_qft_mpo_device, build_zt_qft_chain_device, apply_coefficient_sweep, apply!, rsvd_device, svd_device
 
 const LIB = get(ENV, "QILHIP_LIB", "libqilhip.so")
 
@@ -458,6 +458,30 @@ function build_dt_mpo_batch(psi::DeviceMPS, wrs::AbstractVector{<:Real}; cutoff:
                 (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Cdouble, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
                 ctx().h, n, length(w), w, cutoff, maxdim, _site_ids(psi.sites), hs))
     return [finalizer(_free!, DeviceMPO(h, copy(psi.sites), true)) for h in hs]
+end
+# build_qft_mpo(psi::SignalMPS; cutoff, maxdim) (qft_transformer.jl:121-165) entirely on the device: one launch of the
+# persistent complex chain builder; falls back (fallback flag) only if a bond left its in-LDS capacity, in which case the
+# reference's own host builder is the route to take (build_qft_mpo(n, sites) of QILaplace.jl, then to_device).
+function build_qft_mpo_device(psi::DeviceMPS; cutoff::Float64=1e-14, maxdim::Int=1000)
+    psi.paired && throw(ArgumentError("build_qft_mpo: needs a single-register (SignalMPS) operand"))
+    n = length(psi.sites)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    fb = Ref{Cint}(0)
+    check(ccall((:qil_build_qft_mpo, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}, Ref{Cint}),
+                ctx().h, n, cutoff, maxdim, _site_ids(psi.sites), h, fb))
+    fb[] != 0 && error("build_qft_mpo_device: a bond exceeded the in-LDS capacity of the persistent builder; build on the host and to_device it")
+    return finalizer(_free!, DeviceMPO(h[], copy(psi.sites), false))
+end
+# the paired-register QFT half of build_zt_mpo (zt_transformer.jl:78-99) on the device, labelled with psi's 2n sites
+function build_zt_qft_chain_device(psi::DeviceMPS; cutoff::Float64=1e-14, maxdim::Int=1000)
+    psi.paired || throw(ArgumentError("build_zt_mpo: needs a paired-register (ZTMPS) operand"))
+    n = length(psi.sites) ÷ 2
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    fb = Ref{Cint}(0)
+    check(ccall((:qil_build_zt_qft_chain, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}, Ref{Cint}),
+                ctx().h, n, cutoff, maxdim, _site_ids(psi.sites), h, fb))
+    fb[] != 0 && error("build_zt_qft_chain_device: a bond exceeded the in-LDS capacity of the persistent builder")
+    return finalizer(_free!, DeviceMPO(h[], copy(psi.sites), true))
 end
 
 end # module
