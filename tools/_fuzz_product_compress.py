@@ -36,7 +36,7 @@ for case in range(ncase):
     e2 = np.abs(qil.coefficient_batch(fused, bits) - want).max() / scale
     etr = np.abs(want - before).max() / scale                     # the truncation's own error: fused may differ by that much
     # verdict: compress!(apply) against the oracle (the parity claim), and -- since r02 (sketched zip-up + variational
-    # sweep, DESIGN 3.5) -- the fused route too: same bond dimensions, and no further from the oracle's truncated state than
+    # sweep, DESIGN.md 3.5) -- the fused route too: same bond dimensions, and no further from the oracle's truncated state than
     # the truncation's own error (so at most 2x that from the exact product)
     ok = prod.bond_dims == ref.bond_dims and abs(prod.amplitude - ref.amplitude) < 1e-8 * ref.amplitude and e1 < 1e-7 \
         and fused.bond_dims == ref.bond_dims and e2 <= etr + 1e-9

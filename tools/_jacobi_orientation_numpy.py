@@ -1,6 +1,6 @@
 """numpy model of the one-sided Jacobi iteration of the one-factor SVD (round-robin pairing, the library's block pairing with
 blocks of 8 / 16, its tolerances): sweeps needed on the columns of R against the columns of R^T, for flat (Gaussian) and
-graded spectra.  CPU only:  python tools/_jacobi_orientation_numpy.py   ("Which factor to rotate")
+graded spectra.  CPU only:  python tools/_jacobi_orientation_numpy.py   (MEASUREMENTS.md 3.4, "Which factor to rotate")
 flat: 10 sweeps in every variant; graded over 2 / 6 / 12 decades: R 14 / 24-26 / 38-40 sweeps, R^T 11-12."""
 import numpy as np, sys
 rng = np.random.default_rng(1)
