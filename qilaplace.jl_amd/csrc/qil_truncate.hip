@@ -974,15 +974,13 @@ static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* 
     QIL_TRY(qil_ctx_activate(ctx));
     qil_call_scope call_scope(ctx);
     if (maxdim <= 0) maxdim = kNoCap;
-    // intermediate bond cap of the zip-up and the variational sweep (tuning aid QIL_ZIP_FACTOR, read per call)
-    // default max(1.5 maxdim, maxdim + 16): with the variational sweep behind it the zip-up only has to deliver a basis that
-    // contains the kept space -- 200 random flat-spectrum products and the oracle tests give the same final accuracy as with
-    // 2 maxdim (r01 / early r02), in 0.16 instead of 0.24 s on the bench's product; 1.5 maxdim alone (oversampling 4 at
-    // maxdim = 8) fails 2 of 200
-    const double zip_factor = 1.5;
+    // intermediate bond cap of the zip-up and the variational sweep: maxdim + 16.  With the variational sweep behind it the zip-up
+    // only has to deliver a basis that contains the kept space: an oversampling of 16 columns gives the same verdicts as 2 maxdim
+    // (r01), max(1.5 maxdim, maxdim + 16) (r02/r03) -- 200 random flat-spectrum products with maxdim 8 ... 128 each, 0 bad
+    // (tools/_fuzz_product_compress.py, QIL_FUZZ_ZIP=plus16) -- and the oracle tests, while an oversampling of 4 (1.5 maxdim at
+    // maxdim = 8) fails 2 of 200.  Bench product, maxdim 64: cap 96 117 ms, cap 80 108.6 ms (MEASUREMENTS R04.7).
     const int64_t zip_over = 16;
-    if (zip_maxdim <= 0)
-        zip_maxdim = maxdim > kNoCap / 2 ? kNoCap : std::max<int64_t>(maxdim + zip_over, (int64_t)std::ceil(zip_factor * (double)maxdim));
+    if (zip_maxdim <= 0) zip_maxdim = maxdim > kNoCap / 2 ? kNoCap : maxdim + zip_over;
     const double cutoff = tol * tol / ((double)(N - 1) * sweeps);
     const double zip_cutoff = cutoff * 1e-2;
     const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;

@@ -32,7 +32,9 @@ for case in range(ncase):
     O.compress(ref, maxdim=maxdim, tol=tol)
     got, want = qil.coefficient_batch(prod, bits), O.coefficient_batch(ref, bits)
     e1 = np.abs(got - want).max() / scale
-    fused = qil.apply_compress(W, psi, maxdim=maxdim, tol=tol)
+    zc = os.environ.get("QIL_FUZZ_ZIP")            # cap of the zip-up under test: "plus16" = maxdim + 16, "f125" = max(maxdim + 16, 1.25 maxdim); default: the library's
+    zip_cap = None if not zc else (maxdim + 16 if zc == "plus16" else max(maxdim + 16, int(np.ceil(1.25 * maxdim))))
+    fused = qil.apply_compress(W, psi, maxdim=maxdim, tol=tol, zip_maxdim=zip_cap)
     e2 = np.abs(qil.coefficient_batch(fused, bits) - want).max() / scale
     etr = np.abs(want - before).max() / scale                     # the truncation's own error: fused may differ by that much
     # verdict: compress!(apply) against the oracle (the parity claim), and -- since r02 (sketched zip-up + variational
