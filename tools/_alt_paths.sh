@@ -13,3 +13,4 @@ run QIL_BATCH_LOCKSTEP=0 QIL_BATCH_WORKERS=3 QIL_ENCODE_PAR_DEPTH=5
 run QIL_BATCH_WORKERS=1 QIL_ENCODE_PAR_DEPTH=0
 run QIL_DT_BUILDER=launches
 run QIL_DT_DCAP=24
+run QIL_CPU_BUDGET=2                     # one launcher thread, one lock-step group (a rank that gets 2 CPUs of an 8-rank node's quota)
