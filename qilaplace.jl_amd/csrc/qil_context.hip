@@ -597,11 +597,13 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     const int ls_mode = getenv("QIL_BATCH_LOCKSTEP") ? atoi(getenv("QIL_BATCH_LOCKSTEP")) : -1;
     const bool lockstep = ls_mode == 1 || (ls_mode != 0 && nb >= 5);
     constexpr int kMaxGroups = 4;
-    const int nw = (home->lending || home->parent) ? 1
-                   : (int)std::min<int64_t>(nb, lockstep ? QIL_MAXB * kMaxGroups : std::max(1, max_workers));
     // all four queues, the chains dealt over them; slot k belongs to group k % ng -- but never more polling launchers than the
-    // process's CPU budget leaves room for next to one chain thread that is awake (qil_cpu_budget)
-    const int ng = lockstep ? std::max(1, std::min(std::min(kMaxGroups, nw), qil_cpu_budget() - 1)) : 0;
+    // process's CPU budget leaves room for next to one chain thread that is awake (qil_cpu_budget), and never more than QIL_MAXB
+    // chains per group (a table launch carries at most that many operands; the launcher's scan arrays are that long)
+    const int ng_cap = lockstep ? std::max(1, std::min(kMaxGroups, qil_cpu_budget() - 1)) : 0;
+    const int nw = (home->lending || home->parent) ? 1
+                   : (int)std::min<int64_t>(nb, lockstep ? QIL_MAXB * ng_cap : std::max(1, max_workers));
+    const int ng = lockstep ? std::min(ng_cap, nw) : 0;
     if (nw <= 1) {
         int first = QIL_OK;
         std::string msg;

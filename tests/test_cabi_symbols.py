@@ -83,3 +83,27 @@ def test_plain_c99_client_compiles_and_links(tmp_path):
     """The header is C (not C++): a C99 translation unit using the boundary compiles warning-free and links against
     libqilhip.so.  (It is RUN by the GPU suite.)"""
     _build_c_client(tmp_path)
+
+
+def test_host_cpu_budget_follows_quota_ranks_and_override():
+    """qil_host_cpu_budget (no GPU needed): min(cgroup quota, affinity) / LOCAL_WORLD_SIZE, QIL_CPU_BUDGET overrides -- what caps the
+    polling launcher threads of the lock-step batches when 8 ranks share a node's CPU quota (VERDICT r03 #4)."""
+    import subprocess
+    import sys
+    code = "import qilaplace_jl_amd as q; print(q.host_cpu_budget())"
+
+    def run(**env):
+        e = dict(os.environ, **env)
+        for k in ("QIL_CPU_BUDGET", "LOCAL_WORLD_SIZE"):
+            if k not in env:
+                e.pop(k, None)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=e, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return int(r.stdout.strip().splitlines()[-1])
+
+    base = run()
+    avail = len(os.sched_getaffinity(0))
+    assert 1 <= base <= avail
+    assert run(QIL_CPU_BUDGET="3") == 3
+    assert run(LOCAL_WORLD_SIZE="2") == max(1, base // 2)
+    assert run(LOCAL_WORLD_SIZE="1000") == 1

@@ -2382,6 +2382,35 @@ def test_batch_stress_two_contexts_two_threads_with_failures(qil):
     assert qil.default_context().unowned_bytes() == 0
 
 
+def test_batches_under_a_two_cpu_budget():
+    """A rank that gets 2 CPUs of a shared node quota (QIL_CPU_BUDGET / cgroup quota / LOCAL_WORLD_SIZE, qil_host_cpu_budget)
+    runs ONE launcher group: at most 16 chains in flight, the others queue behind them.  40 chains through compress_batch in a
+    fresh process with that budget: same tensors as one at a time.  (Found by tools/_alt_paths.sh in r04: the first version of the
+    cap put all 40 chains into the one group -- more slots than a table launch has operands.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import qilaplace_jl_amd as qil
+from helpers import random_mps_data, saturated_profile
+assert qil.host_cpu_budget() == 2
+rng = np.random.default_rng(5)
+data = [random_mps_data(saturated_profile(8, int(chi)), rng) for chi in rng.integers(6, 20, size=40)]
+ref = [qil.compress(qil.SignalMPS([t.copy() for t in a]), maxdim=5, tol=1e-9).to_host() for a in data]
+items = [qil.SignalMPS([t.copy() for t in a]) for a in data]
+qil.compress_batch(items, maxdim=5, tol=1e-9)
+assert all(np.array_equal(x, y) for it, r in zip(items, ref) for x, y in zip(it.to_host(), r))
+assert qil.default_context().unowned_bytes() == 0
+print("BUDGET2_OK")
+""" % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, QIL_CPU_BUDGET="2"))
+    assert "BUDGET2_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_signal_batch_encoders_equal_item_by_item(qil):
     """qil_signal_mps_batch / qil_signal_ztmps_batch: the signals of a sweep encoded concurrently give the tensors of the
     one-at-a-time encoders (SVD and RSVD, real and complex, more signals than slots); all or nothing on failure."""
