@@ -1578,6 +1578,8 @@ def test_failed_calls_leave_no_device_memory_behind(qil):
             ("signal_ztmps", lambda: qil.signal_ztmps(x, cutoff=1e-10, maxdim=16)),
             ("svd_trunc (block path)", lambda: qil.svd_trunc(A, cutoff=1e-12)),
             ("build_dt_mpo_batch", lambda: qil.build_dt_mpo_batch(4, [0.5, 1.5])),
+            ("build_qft_mpo (persistent chain builder)", lambda: qil.build_qft_mpo(6)),
+            ("zt_qft_chain_device (persistent chain builder)", lambda: qil.zt_qft_chain_device(4)),
         ]
 
     names = [n for n, _ in ops(None, None, None)]
