@@ -263,9 +263,11 @@ __global__ void widen_real_to_complex(const double* __restrict__ in, c64* __rest
         out[i] = c64{in[i], 0.0};
 }
 
-int check_apply_operands(const qil_mpo* W, const qil_mps* psi) {
+int check_apply_operands(const qil_mpo* W, const qil_mps* psi, bool shared_state = false) {
     QIL_REQUIRE(W && psi, QIL_EINVAL_ARG, "apply: null handle");
-    QIL_REQUIRE(W->ctx == psi->ctx, QIL_EINVAL_ARG, "apply: MPO and MPS belong to different contexts");
+    // shared_state: the batch runner's items read ONE state that stays in the home context (read-only for the duration of the
+    // call, ordered behind the home stream by the batch's `ready` event) while their operators sit in the slots' contexts
+    QIL_REQUIRE(shared_state || W->ctx == psi->ctx, QIL_EINVAL_ARG, "apply: MPO and MPS belong to different contexts");
     if (W->paired || psi->paired) {
         // apply(W::PairedSiteMPO, psi::ZTMPS): length(W.data) == 2 * length(psi.sites_main)  (apply.jl:202-203)
         QIL_REQUIRE(W->paired && psi->paired, QIL_EINVAL_ARG,
@@ -353,8 +355,17 @@ extern "C" int qil_apply_into(const qil_mpo* W, const qil_mps* psi, qil_mps* out
     return launch_apply(W, psi, out);
 }
 
-extern "C" int qil_apply(const qil_mpo* W, const qil_mps* psi, qil_mps** out) {
-    QIL_TRY(check_apply_operands(W, psi));
+static int apply_new(const qil_mpo* W, const qil_mps* psi, qil_mps** out, bool shared_state);
+
+extern "C" int qil_apply(const qil_mpo* W, const qil_mps* psi, qil_mps** out) { return apply_new(W, psi, out, false); }
+
+// apply with the result (and every launch) in W's context while psi belongs to another context of the same device: the items of
+// a batch share the caller's state instead of cloning it into every slot (r04: the 64 slots of a damping sweep made 3 024
+// device-to-device copies of psi's sites per sweep)
+int qil_apply_shared_state(const qil_mpo* W, const qil_mps* psi, qil_mps** out) { return apply_new(W, psi, out, true); }
+
+static int apply_new(const qil_mpo* W, const qil_mps* psi, qil_mps** out, bool shared_state) {
+    QIL_TRY(check_apply_operands(W, psi, shared_state));
     QIL_REQUIRE(out, QIL_EINVAL_ARG, "qil_apply: null out");
     const int64_t n = W->n();
     std::vector<int64_t> bonds((size_t)(n > 1 ? n - 1 : 0));

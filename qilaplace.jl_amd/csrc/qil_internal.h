@@ -150,6 +150,7 @@ void qil_ctx_event_release(qil_context* ctx, hipEvent_t e);
 // `bytes` (a multiple of 4, 4-byte aligned source) of device memory to the host, ordered after everything this context has
 // launched: qil_read_back = post + wait; posted read-backs complete in order, at most kRbSlots - 1 may be outstanding.
 // Larger blocks than a slot take the copy-command + stream-synchronisation route.
+int qil_apply_shared_state(const qil_mpo* W, const qil_mps* psi, qil_mps** out);   // (qil_apply.hip) psi may live in another context of the device
 int qil_lockstep_park(qil_context* ctx, const unsigned long long* word, unsigned long long ticket);   // (qil_context.hip)
 int qil_read_back_post(qil_context* ctx, const void* dev_src, size_t bytes, uint64_t* ticket);
 int qil_read_back_wait(qil_context* ctx, uint64_t ticket, void* host_dst, size_t bytes);

@@ -10,6 +10,7 @@
 // One workgroup owns one query and walks all sites inside ONE launch; each output entry is a
 // dot product along the contiguous alpha axis, reduced with wavefront shuffles.
 #include "qil_internal.h"
+#include "qil_launch.h"
 #include <set>
 #include <mutex>
 #include <map>
@@ -185,6 +186,57 @@ __global__ void select_slice(const T* __restrict__ Tm, long long nb, int cr, con
                          : Tm[q + nb * (bit + 2 * beta)];
     }
 }
+
+// The same three steps in the table form of qil_launch.h: in a lock-step batch (the per-operator read-outs of a damping sweep)
+// the `select_slice` of up to 16 chains is ONE launch instead of one per chain and site (r04: 3 072 launches of 3.5 us per sweep
+// of 64 operators, each of which also drained its chain's ring to get onto the stream).
+template <class T>
+__device__ __forceinline__ void select_slice_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ Tm, long long nb, int cr,
+                                                  const uint8_t* __restrict__ bits, int n, int site, T* __restrict__ Vn) {
+    const long long total = nb * cr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long q = t % nb;
+        const long long beta = t / nb;
+        const int bit = bits[q * n + site];
+        Vn[t] = bit == 2 ? add_t(Tm[q + nb * (2 * beta)], Tm[q + nb * (1 + 2 * beta)]) : Tm[q + nb * (bit + 2 * beta)];
+    }
+}
+template <class T>
+struct select_slice_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        select_slice_body<T>(b, g, a...);
+    }
+};
+template <class T>
+__device__ __forceinline__ void fill_ones_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ v, long long n) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) v[t] = one_t(T{});
+}
+template <class T>
+struct fill_ones_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        fill_ones_body<T>(b, g, a...);
+    }
+};
+template <class T>
+__device__ __forceinline__ void finish_coeff_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ v, long long nb,
+                                                  double amplitude, c64* __restrict__ out) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nb; t += (long long)gridDim.x * blockDim.x) {
+        const c64 r = to_c64(v[t]);
+        out[t] = c64{r.re * amplitude, r.im * amplitude};
+    }
+}
+template <class T>
+struct finish_coeff_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        finish_coeff_body<T>(b, g, a...);
+    }
+};
 
 template <class T>
 __global__ void fill_ones(T* __restrict__ v, long long n) {
@@ -407,25 +459,22 @@ static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* db
         QIL_TRY(qil_ctx_alloc(ctx, (size_t)(2 * nb * maxchi) * esz, &Tm));
         const bool cx = psi->dtype == QIL_C64;
         const unsigned g1 = (unsigned)std::min<long long>((nb + 255) / 256, 4096);
-        if (cx) hipLaunchKernelGGL(fill_ones<c64>, dim3(g1), dim3(256), 0, qil_stream(ctx), (c64*)V, (long long)nb);
-        else hipLaunchKernelGGL(fill_ones<double>, dim3(g1), dim3(256), 0, qil_stream(ctx), (double*)V, (long long)nb);
+        if (cx) QIL_TRY((qil_klaunch<fill_ones_k<c64>>(ctx, dim3(g1), dim3(256), 0, (c64*)V, (long long)nb)));
+        else QIL_TRY((qil_klaunch<fill_ones_k<double>>(ctx, dim3(g1), dim3(256), 0, (double*)V, (long long)nb)));
         for (int64_t i = 0; i < n; ++i) {
             const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
             QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 0, 0, nb, 2 * cr, cl, V, nb, psi->site[(size_t)i], cl, Tm, nb));
             const unsigned g = (unsigned)std::min<long long>((nb * cr + 255) / 256, 65536);
             if (cx)
-                hipLaunchKernelGGL(select_slice<c64>, dim3(g), dim3(256), 0, qil_stream(ctx), (const c64*)Tm,
-                                   (long long)nb, (int)cr, dbits, (int)n, (int)i, (c64*)Vn);
+                QIL_TRY((qil_klaunch<select_slice_k<c64>>(ctx, dim3(g), dim3(256), 0, (const c64*)Tm, (long long)nb, (int)cr,
+                                                          (const uint8_t*)dbits, (int)n, (int)i, (c64*)Vn)));
             else
-                hipLaunchKernelGGL(select_slice<double>, dim3(g), dim3(256), 0, qil_stream(ctx), (const double*)Tm,
-                                   (long long)nb, (int)cr, dbits, (int)n, (int)i, (double*)Vn);
+                QIL_TRY((qil_klaunch<select_slice_k<double>>(ctx, dim3(g), dim3(256), 0, (const double*)Tm, (long long)nb, (int)cr,
+                                                             (const uint8_t*)dbits, (int)n, (int)i, (double*)Vn)));
             std::swap(V, Vn);
         }
-        if (cx) hipLaunchKernelGGL(finish_coeff<c64>, dim3(g1), dim3(256), 0, qil_stream(ctx), (const c64*)V,
-                                   (long long)nb, psi->amplitude, (c64*)dout);
-        else hipLaunchKernelGGL(finish_coeff<double>, dim3(g1), dim3(256), 0, qil_stream(ctx), (const double*)V,
-                                (long long)nb, psi->amplitude, (c64*)dout);
-        QIL_HIP(hipGetLastError());
+        if (cx) QIL_TRY((qil_klaunch<finish_coeff_k<c64>>(ctx, dim3(g1), dim3(256), 0, (const c64*)V, (long long)nb, psi->amplitude, (c64*)dout)));
+        else QIL_TRY((qil_klaunch<finish_coeff_k<double>>(ctx, dim3(g1), dim3(256), 0, (const double*)V, (long long)nb, psi->amplitude, (c64*)dout)));
         qil_ctx_free(ctx, V);
         qil_ctx_free(ctx, Vn);
         qil_ctx_free(ctx, Tm);
@@ -496,7 +545,7 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
     }
     auto one = [&](const qil_mpo* W, const qil_mps* state, int64_t j) {
         qil_mps* prod = nullptr;
-        QIL_TRY(qil_apply(W, state, &prod));
+        QIL_TRY(qil_apply_shared_state(W, state, &prod));
         const int st = coefficient_enqueue(prod, nb, dbits, static_cast<char*>(dout) + (size_t)(j * nb) * 16);
         qil_mps_destroy(prod);
         return st;
@@ -504,23 +553,11 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
     static const bool concurrent = true;   // tuning aid
     if (concurrent && distinct && nw >= 4) {
         // every value's product + read-out is a chain of ~100 small launches: the values run concurrently on the context's
-        // streams.  The operators move to their slot for the duration of the call (bookkeeping only), every slot reads its
-        // own copy of the state (MBs), bits and results are shared device buffers.
-        std::map<qil_context*, qil_mps*> copy;            // slot -> its copy of psi, made by the slot's first item
-        std::mutex copy_mutex;
+        // streams.  The operators move to their slot for the duration of the call (bookkeeping only); the state, the bits and the
+        // results are shared device buffers (the state is read-only here and every slot's stream waits for the home stream first).
         const int st = qil_run_batch_on(
             ctx, nw, [&](int64_t j, qil_context* slot) { qil_chain_rebind(const_cast<qil_mpo*>(Ws[j]), slot); },
-            [&](int64_t j, qil_context* work) {
-                const qil_mps* state = psi;
-                if (work != ctx) {
-                    std::lock_guard<std::mutex> lock(copy_mutex);
-                    qil_mps*& c = copy[work];
-                    if (!c) QIL_TRY(qil_mps_clone_to(work, psi, &c));
-                    state = c;
-                }
-                return one(Ws[j], state, j);
-            });
-        for (auto& kv : copy) qil_mps_destroy(kv.second);      // back in the home context like every chain of the batch
+            [&](int64_t j, qil_context*) { return one(Ws[j], psi, j); });
         QIL_TRY(st);
     } else {
         for (int64_t j = 0; j < nw; ++j) QIL_TRY(one(Ws[j], psi, j));
