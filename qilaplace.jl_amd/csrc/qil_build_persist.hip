@@ -799,7 +799,9 @@ __device__ void pb_truncate(PbState& st, const PbArgs& a, PbChain ch, double* ar
         pb_tick(st, 4, prof);
         pb_jacobi(Wk, ldw, rows, cols, st, 1e-15, 1e-30 * f, 40, prof);
         pb_tick(st, 5, prof);
-        // stable descending order + the ITensors truncation rule (qil_truncation_rank)
+        // stable descending order + the ITensors truncation rule (qil_truncation_rank).  Every column's thread finds its own sorted
+        // position and leaves there its index, its square and its reciprocal (r04: the rule below used to re-read all 56 possible
+        // entries through the permutation, three fully unrolled passes on one lane: 12.7 k cycles per SVD, MEASUREMENTS R04.11)
         if (tid < cols) {
             const double s = st.sig[tid];
             int pos = 0;
@@ -809,41 +811,45 @@ __device__ void pb_truncate(PbState& st, const PbArgs& a, PbChain ch, double* ar
                 pos += (o > s) || (o == s && q < tid);
             }
             st.perm[pos] = tid;
+            st.nrp[pos] = s * s;
+            st.inv[pos] = s > 0.0 ? 1.0 / s : 0.0;
         }
         __syncthreads();
         if (tid == 0) {
-            // qil_truncation_rank on the sorted squares, read into registers first (sequential sums in host order)
-            double p2[PB_DMAX];
-#pragma unroll
-            for (int q = 0; q < PB_DMAX; ++q) {
-                const double sv = q < cols ? st.sig[st.perm[q]] : 0.0;
-                p2[q] = sv * sv;
-            }
+            // the rule on the sorted squares, sums in the host's order (ascending for the total, from the tail for the discarded
+            // weight), eight entries loaded per trip and only as many trips as there are columns
             int kk = cols;
-            if (!(p2[0] > 0.0) || cols == 1) kk = 1;
+            if (!(st.nrp[0] > 0.0) || cols == 1) kk = 1;
             else {
                 double terr = 0.0, scale = 0.0;
+                for (int q0 = 0; q0 < cols; q0 += 8) {
+                    double v[8];
 #pragma unroll
-                for (int q = 0; q < PB_DMAX; ++q) scale += p2[q];
+                    for (int u = 0; u < 8; ++u) v[u] = q0 + u < cols ? st.nrp[q0 + u] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) scale += v[u];            // (+ 0.0 beyond the last column: exact)
+                }
                 if (scale == 0.0) scale = 1.0;
                 const double lim = a.cutoff * scale;
                 bool open = true;
+                for (int q0 = ((cols - 1) >> 3) << 3; q0 >= 0 && open; q0 -= 8) {
+                    double v[8];
 #pragma unroll
-                for (int q = PB_DMAX - 1; q >= 1; --q) {
-                    if (q < cols && open) {
-                        if ((long long)(q + 1) > a.maxdim || terr + p2[q] <= lim) {
-                            terr += p2[q];
-                            kk = q;
-                        } else open = false;
+                    for (int u = 0; u < 8; ++u) v[u] = q0 + u < cols ? st.nrp[q0 + u] : 0.0;
+#pragma unroll
+                    for (int u = 7; u >= 0; --u) {
+                        const int q = q0 + u;
+                        if (q >= 1 && q < cols && open) {
+                            if ((long long)(q + 1) > a.maxdim || terr + v[u] <= lim) {
+                                terr += v[u];
+                                kk = q;
+                            } else open = false;
+                        }
                     }
                 }
                 if (kk < 1) kk = 1;
             }
             st.rank = kk;
-        }
-        if (tid < cols) {
-            const double s = st.sig[st.perm[tid]];
-            st.inv[tid] = s > 0.0 ? 1.0 / s : 0.0;
         }
         __syncthreads();
         const int rk = st.rank;
