@@ -57,6 +57,29 @@ def sweep(items, work_fn, width: int, dist=None, device=None, always_gather=Fals
     return gather_results(local, len(items), width, dist if (world > 1 or always_gather) else None, device, always_gather)
 
 
+def damping_sample_bits(n: int, nsamp: int, seed: int = 7, kmax: int = 64):
+    """(nsamp, 2n) paired-register configurations for checking a damping sweep where its values are NOT negligible.
+
+    The DT output is x_j exp(-sigma k j / N) / sqrt(N) (test/test_dt_transformer.jl:60-92), so uniformly random (k, j)
+    at n = 24 give k j / N ~ 1e6 and every reference value underflows to 0.0 -- a check against zeros.  The reference's
+    own tests and tutorial look at small k (test/test_dt_transformer.jl:211-238, docs/src/tutorials/dt.jl:150-197).
+    Strata: 1/8 the k = 0 row (undamped signal), 3/8 k in {1, 2, 3} with uniform j, 1/2 k uniform in [0, kmax) with
+    log-uniform j (j < 2^m, m uniform in 10..n).  Returns (bits, k, j); main bits are LSB first on the even positions,
+    copy bits MSB first on the odd ones (mps.jl:421-444)."""
+    r = np.random.default_rng(seed)
+    N = 1 << n
+    q = nsamp // 8
+    rest = nsamp - 4 * q
+    kmax = min(kmax, N)
+    kk = np.concatenate([np.zeros(q, np.int64), r.integers(1, min(4, N), 3 * q), r.integers(0, kmax, rest)]).astype(np.int64)
+    m = r.integers(min(10, n), n + 1, rest)
+    jj = np.concatenate([r.integers(0, N, 4 * q), (r.random(rest) * 2.0 ** m).astype(np.int64)]).astype(np.int64)
+    bits = np.zeros((nsamp, 2 * n), dtype=np.uint8)
+    bits[:, 0::2] = (kk[:, None] >> np.arange(n)[None, :]) & 1
+    bits[:, 1::2] = (jj[:, None] >> np.arange(n - 1, -1, -1)[None, :]) & 1
+    return bits, kk, jj
+
+
 def damping_sweep(psi, sigmas, bits, build_mpo=None, dist=None, device=None, cutoff=1e-14, maxdim=1000, always_gather=False):
     """BASELINE.json configs[3]: one paired-register signal x many damping values.
 

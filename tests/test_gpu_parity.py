@@ -468,31 +468,54 @@ def test_damping_sweep_single_rank(qil):
     assert qil.apply_coefficient_sweep([], psi, bits).shape == (0, 3 * N)
 
 
-def test_config4_damping_sweep_full_size(qil):
-    """BASELINE.json configs[3] at full size on one GPU: n = 24, 64 damping values through `damping_sweep` with the
-    batched device builder, 1024 sampled coefficients per value against the closed form x_j e^{-sigma k j / N} / sqrt(N)
-    (test/test_dt_transformer.jl:60-92; the reference's DT bound is 1e-7 * max(1, |.|), MPO-cutoff limited)."""
-    n, N = 24, 2 ** 24
+def _config4_signal(n):
+    N = 2 ** n
     j = np.arange(N, dtype=np.float64)
     rng = np.random.default_rng(1001)                       # :multi_sin_exp-like structured signal (Signals.jl:64-85)
     ak = rng.random(10)
     ak /= np.linalg.norm(ak)
     wk = 40.0 / N * (rng.random(10) - 0.5)
     lk = -2.0 / N * rng.random(10)
-    x = sum(ak[k] * np.sin(wk[k] * j) * np.exp(lk[k] * j) for k in range(10))
+    return sum(ak[k] * np.sin(wk[k] * j) * np.exp(lk[k] * j) for k in range(10))
+
+
+def test_config4_damping_sweep_full_size(qil):
+    """BASELINE.json configs[3] at full size on one GPU: n = 24, 64 damping values through `damping_sweep` with the
+    batched device builder, 1024 sampled coefficients per value against the closed form x_j e^{-sigma k j / N} / sqrt(N)
+    (test/test_dt_transformer.jl:60-92, checked where the output is non-zero as test_dt_transformer.jl:211-238 does; the
+    reference's DT bound is 1e-7 * max(1, |.|), MPO-cutoff limited).  The samples are `damping_sample_bits` (small k,
+    log-uniform j): uniformly random (k, j) make every reference value underflow to 0.0 at n = 24, so the
+    share of non-negligible reference values is asserted here, per damping value."""
+    n, N = 24, 2 ** 24
+    x = _config4_signal(n)
     psi = qil.signal_ztmps(x, method="rsvd", k=15, p=5, q=2, cutoff=1e-12)
     sig = np.linspace(0.25, 16.0, 64)
-    bits = np.random.default_rng(7).integers(0, 2, size=(1024, 2 * n)).astype(np.uint8)
+    bits, kk, jj = qil.damping_sample_bits(n, 1024, seed=7)
+    assert (kk == 0).sum() >= 128 and kk.max() < 64
     got = qil.damping_sweep(psi, sig, bits)
     assert got.shape == (64, 1024)
-    kk = (bits[:, 0::2].astype(np.int64) * (1 << np.arange(n))[None, :]).sum(1)                  # main bits: k, LSB first
-    jj = (bits[:, 1::2].astype(np.int64) * (1 << np.arange(n - 1, -1, -1))[None, :]).sum(1)      # copy bits: j, MSB first
     peak = np.abs(x).max() / np.sqrt(N)
+    worst = 0.0
     for r, s in enumerate(sig):
         ref = x[jj] * np.exp(-s * kk * jj / N) / np.sqrt(N)
-        # encode (rsvd k=15, cutoff 1e-12) + MPO cutoff 1e-14: measured 6.4e-11 of the signal peak (profiles/r02_bench_sweep.json);
-        # the reference's own DT bound is 1e-7 * max(1, |.|) (test/test_dt_transformer.jl:234)
-        assert np.abs(got[r] - ref).max() < 1e-8 * peak, (r, s, np.abs(got[r] - ref).max() / peak)
+        live = np.abs(ref) > 1e-6 * peak
+        assert live.mean() >= 0.5, (r, s, live.mean())                    # never against zeros again
+        assert (np.abs(ref) > 1e-2 * peak).mean() >= 0.2, (r, s)          # ... and a fifth of them of the signal's own size
+        # encode (rsvd k=15, cutoff 1e-12) + MPO cutoff 1e-14; the reference's own DT bound is 1e-7 * max(1, |.|)
+        # (test/test_dt_transformer.jl:234)
+        err = np.abs(got[r] - ref).max() / peak
+        worst = max(worst, err)
+        assert err < 1e-8, (r, s, err)
+    # ... and the operators themselves at n = 24: four of the 64 damping values against the oracle's build_dt_mpo
+    # (numpy restatement of dt_transformer.jl:312-412) on the SAME encoded psi, through the oracle's lazy <bits|W psi>:
+    # 1e-9 of the signal peak (both sides truncate the MPO at 1e-14)
+    ph = O.SignalMPS(psi.to_host(), amplitude=psi.amplitude)
+    for r in (0, 21, 42, 63):
+        Wc = O.build_dt_mpo(n, float(sig[r]))
+        ref = O.lazy_coefficient_batch(Wc, ph, bits)
+        assert (np.abs(ref) > 1e-6 * peak).mean() >= 0.5
+        err = np.abs(got[r] - ref).max() / peak
+        assert err < 1e-9, (r, sig[r], err)
 
 
 # ---------------------------------------------------------------- f64-MFMA GEMM (fragment layout check)

@@ -49,7 +49,7 @@ def main():
     ctx.synchronize()
     t_encode = time.perf_counter() - t0
     sig = np.linspace(0.25, 16.0, args.sigmas)
-    bits = np.random.default_rng(7).integers(0, 2, size=(args.samples, 2 * n)).astype(np.uint8)
+    bits, _, _ = qil.damping_sample_bits(n, args.samples, seed=7)      # non-negligible closed-form values (sweep.py)
     mine = qil.shard_items(len(sig), world, rank)
     import torch  # noqa: F401  (kept out of the timed region)
     if dist is not None:
