@@ -481,11 +481,19 @@ def _config4_signal(n):
 
 def test_config4_damping_sweep_full_size(qil):
     """BASELINE.json configs[3] at full size on one GPU: n = 24, 64 damping values through `damping_sweep` with the
-    batched device builder, 1024 sampled coefficients per value against the closed form x_j e^{-sigma k j / N} / sqrt(N)
-    (test/test_dt_transformer.jl:60-92, checked where the output is non-zero as test_dt_transformer.jl:211-238 does; the
-    reference's DT bound is 1e-7 * max(1, |.|), MPO-cutoff limited).  The samples are `damping_sample_bits` (small k,
-    log-uniform j): uniformly random (k, j) make every reference value underflow to 0.0 at n = 24, so the
-    share of non-negligible reference values is asserted here, per damping value."""
+    batched device builder, 1024 sampled coefficients per value, checked where the output is NOT negligible
+    (test/test_dt_transformer.jl:211-238 checks every entry of small cases; uniformly random (k, j) at n = 24 make every
+    closed-form value underflow to 0.0 -- VERDICT r04 -- so the samples are `damping_sample_bits` and the share of
+    non-negligible reference values is asserted per damping value).  Three legs:
+      (a) 4 of the 64 operators against the oracle's build_dt_mpo (numpy restatement of dt_transformer.jl:312-412) on the SAME
+          encoded psi through the oracle's lazy <bits|W psi>: 1e-9 of the signal peak -- the parity statement;
+      (b) all 64 against the closed form x_j e^{-sigma k j / N} / sqrt(N) (test_dt_transformer.jl:60-92).  At the reference's
+          default MPO cutoff 1e-14 the operator's own truncation limits this: 3.5e-5 of the signal peak at sigma = 0.25 falling
+          to 1.3e-6 at 16 -- the numpy oracle shows the same 3.4806e-05 to five digits (r05 measurement) --, i.e. 1e-12 in the
+          reference's normalisation (unit-norm signal, absolute 1e-7 max(1, |.|), test_dt_transformer.jl:234);
+      (c) convergence: a tighter encode (k = 25, cutoff 1e-16) and MPO cutoff 1e-18 (truncated bonds 35 > the persistent
+          builder's LDS plan: the launch-per-step builder of csrc/qil_build.hip serves it) bring the closed-form error to
+          2.8e-7 (oracle, sigma = 0.25) / 2.5e-9 (sigma = 16): bound 1e-6."""
     n, N = 24, 2 ** 24
     x = _config4_signal(n)
     psi = qil.signal_ztmps(x, method="rsvd", k=15, p=5, q=2, cutoff=1e-12)
@@ -495,27 +503,30 @@ def test_config4_damping_sweep_full_size(qil):
     got = qil.damping_sweep(psi, sig, bits)
     assert got.shape == (64, 1024)
     peak = np.abs(x).max() / np.sqrt(N)
-    worst = 0.0
+    # (a) parity with the oracle's operators, non-vacuous
+    ph = O.SignalMPS(psi.to_host(), amplitude=psi.amplitude)
+    for r in (0, 21, 42, 63):
+        ref = O.lazy_coefficient_batch(O.build_dt_mpo(n, float(sig[r])), ph, bits)
+        assert (np.abs(ref) > 1e-6 * peak).mean() >= 0.5
+        err = np.abs(got[r] - ref).max() / peak
+        assert err < 1e-9, (r, sig[r], err)
+    # (b) closed form
     for r, s in enumerate(sig):
         ref = x[jj] * np.exp(-s * kk * jj / N) / np.sqrt(N)
         live = np.abs(ref) > 1e-6 * peak
         assert live.mean() >= 0.5, (r, s, live.mean())                    # never against zeros again
         assert (np.abs(ref) > 1e-2 * peak).mean() >= 0.2, (r, s)          # ... and a fifth of them of the signal's own size
-        # encode (rsvd k=15, cutoff 1e-12) + MPO cutoff 1e-14; the reference's own DT bound is 1e-7 * max(1, |.|)
-        # (test/test_dt_transformer.jl:234)
-        err = np.abs(got[r] - ref).max() / peak
-        worst = max(worst, err)
-        assert err < 1e-8, (r, s, err)
-    # ... and the operators themselves at n = 24: four of the 64 damping values against the oracle's build_dt_mpo
-    # (numpy restatement of dt_transformer.jl:312-412) on the SAME encoded psi, through the oracle's lazy <bits|W psi>:
-    # 1e-9 of the signal peak (both sides truncate the MPO at 1e-14)
-    ph = O.SignalMPS(psi.to_host(), amplitude=psi.amplitude)
-    for r in (0, 21, 42, 63):
-        Wc = O.build_dt_mpo(n, float(sig[r]))
-        ref = O.lazy_coefficient_batch(Wc, ph, bits)
-        assert (np.abs(ref) > 1e-6 * peak).mean() >= 0.5
-        err = np.abs(got[r] - ref).max() / peak
-        assert err < 1e-9, (r, sig[r], err)
+        err = np.abs(got[r] - ref).max()
+        assert err < 1e-4 * peak, (r, s, err / peak)
+        assert err / psi.amplitude < 1e-7 * max(1.0, np.abs(ref).max() / psi.amplitude)      # the reference's own bound
+    # (c) convergence with the cutoffs
+    psi2 = qil.signal_ztmps(x, method="rsvd", k=25, p=5, q=2, cutoff=1e-16)
+    s2 = [0.25, 16.0]
+    got2 = qil.damping_sweep(psi2, s2, bits, cutoff=1e-18)
+    for r, s in enumerate(s2):
+        ref = x[jj] * np.exp(-s * kk * jj / N) / np.sqrt(N)
+        err = np.abs(got2[r] - ref).max() / peak
+        assert err < 1e-6, (s, err)
 
 
 # ---------------------------------------------------------------- f64-MFMA GEMM (fragment layout check)
@@ -1085,7 +1096,7 @@ def test_bench_configs_block_small(qil):
         assert "error" not in blk[name], blk[name]
         assert set(bc.CONFIGS_BLOCK_KEYS[name]) <= set(blk[name])
     assert blk["cfg2"]["max_coeff_err"] < 1e-9 and 0 < blk["cfg2"]["roofline"]["frac"] < 1.2
-    assert blk["cfg4"]["max_coeff_err"] < 1e-7
+    assert blk["cfg4"]["max_coeff_err"] < 1e-5 and blk["cfg4"]["reference_samples_above_1e-6_peak"]["count"] > 0
     assert blk["cfg5"]["max_coeff_err"] < 2e-7 and blk["cfg5"]["lazy_vs_materialised_rel"] < 1e-11
     assert blk["cfg5"]["encode_roofline"]["mfma"]["algorithmic_flops"] == 6 * 2 * 2 ** 16 * 29
     # the read-out entry on a small materialised product (the bench passes the 80 GB one)
