@@ -586,16 +586,15 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     // One chain per hardware queue: the runtime multiplexes streams onto 4 queues, and streams that share one serialise
     // (measured with rocprofv3 --kernel-trace: a fifth stream lands on an occupied queue and its chain runs at half speed).
     // The calling thread drives the home stream itself, so nw chains use nw streams.
-    static const int max_workers = getenv("QIL_BATCH_WORKERS") ? atoi(getenv("QIL_BATCH_WORKERS")) : 8;   // tuning aid (8 streams on the 4 queues: 2.09x single for 8 chains, 4 streams: 2.22x)
+    constexpr int max_workers = 8;                              // (8 streams on the 4 queues: 2.09x single for 8 chains, 4 streams: 2.22x)
     // a context that is already one slot of a running batch (the home context during its own batch, or a worker) runs
     // nested batches inline: the slots are taken, and the batch mutex is held by the outer call
     // Lock-step groups (qil_launch.h): up to QIL_MAXB chains share ONE stream and a launcher that issues the same step of all of
     // them as one table launch; up to 4 such groups run side by side on streams of their own (one per hardware queue).  One
     // group is a serial stream -- measured, compress! chi 256 -> 128: 8 chains 146-160 ms as one group against 136 ms on 8
     // streams, 4 chains 109 against 75 ms -- so small batches keep the stream-per-chain form and lock-step takes over where
-    // the 4 hardware queues are the limit: from 5 chains on (QIL_BATCH_LOCKSTEP = 0: never, 1: always, default: auto).
-    const int ls_mode = getenv("QIL_BATCH_LOCKSTEP") ? atoi(getenv("QIL_BATCH_LOCKSTEP")) : -1;
-    const bool lockstep = ls_mode == 1 || (ls_mode != 0 && nb >= 5);
+    // the 4 hardware queues are the limit: from 5 chains on.
+    const bool lockstep = nb >= 5;
     constexpr int kMaxGroups = 4;
     // all four queues, the chains dealt over them; slot k belongs to group k % ng -- but never more polling launchers than the
     // process's CPU budget leaves room for next to one chain thread that is awake (qil_cpu_budget), and never more than QIL_MAXB

@@ -3338,9 +3338,10 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     // (measured, compress! on 24 sites: f64 chi 256 -> 128 69.9 ms with the Gram rounds, 70.4 ms with the vector rounds; c64 107
     // against 103 ms -- a Gram round of 2 x 16 columns takes 20 us where two vector rounds of 2 x 8 take 18, both bound by the
     // latency of the rotation rounds, tools/micro/gram_round_cost.hip -- so complex operands keep the vector rounds)
-    static const int gram = getenv("QIL_SVD_GRAM") ? atoi(getenv("QIL_SVD_GRAM")) : 1;   // 0 = vector-ALU block rounds, 2 = Gram rounds for c64 too
+    // (r04 measured the c64 Gram rounds once more -- exact compress!(apply) 302 against 272 ms, chi 256 equal -- and r05 removed
+    // the QIL_SVD_GRAM switch with them: f64 operands take the Gram rounds, complex ones the vector rounds)
     int gbb = 0;
-    if (gram == 2 || (gram == 1 && sizeof(T) == 8)) {
+    if (sizeof(T) == 8) {
         if (gram_round_lds<T, 16>((int)k) <= 160 * 1024) gbb = 16;
         else if (gram_round_lds<T, 8>((int)k) <= 160 * 1024) gbb = 8;
     }
@@ -3536,7 +3537,9 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         }
         return QIL_OK;
     };
-    if (gbb) {
+    bool gram_done = false;
+    if constexpr (sizeof(T) == 8) if (gbb) {                     // (no complex instantiation of the Gram-round kernels: r05)
+        gram_done = true;
         // Gram-matrix block rounds on the matrix cores.  The host stays ONE SWEEP AHEAD of its read-backs: sweep s + 1 is
         // enqueued before the flags of sweep s have come back, each of its launches first looks at those flags on the device
         // and does nothing if sweep s had already converged -- the stream never waits for a host round trip.
@@ -3565,7 +3568,8 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
             if (!hv[1]) break;
         }
         QIL_TRY(st);
-    } else
+    }
+    if (!gram_done)
     for (; sweeps < 40; ++sweeps) {
         QIL_TRY(qil_dev_zero(ctx, flag, 2 * sizeof(int)));
         QIL_TRY(launch_rounds());
@@ -4035,8 +4039,7 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     // Cholesky QR first where it pays (from a few panels on) and while it keeps succeeding on this context: a numerically
     // rank-deficient operand (product bonds, deficient sketches) costs the attempt a Gram product, a partial factorisation and
     // one synchronisation, so after a refusal the next attempts are skipped
-    static const bool cholqr = !(getenv("QIL_QR_CHOL") && atoi(getenv("QIL_QR_CHOL")) == 0);   // 0 = Householder / CGS2 panels only
-    if (cholqr && n >= 64 && n <= 1024 && m >= n && m * n <= (1LL << 22)) {
+    if (n >= 64 && n <= 1024 && m >= n && m * n <= (1LL << 22)) {
         if (ctx->cholqr_skip > 0) {
             --ctx->cholqr_skip;
         } else {
@@ -4210,8 +4213,7 @@ int qil_read_back_wait(qil_context* ctx, uint64_t ticket, void* host_dst, size_t
 }
 int qil_read_back(qil_context* ctx, void* host_dst, const void* dev_src, size_t bytes) {
     if (bytes == 0) return QIL_OK;
-    static const bool polled = !(getenv("QIL_READBACK") && atoi(getenv("QIL_READBACK")) == 0);
-    if (!polled || bytes > qil_context::kRbSlotBytes || (bytes & 3) || ((uintptr_t)dev_src & 3)) {
+    if (bytes > qil_context::kRbSlotBytes || (bytes & 3) || ((uintptr_t)dev_src & 3)) {
         QIL_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, qil_stream(ctx)));
         QIL_HIP(qil_stream_sync(ctx));
         if (ctx->rb_done == ctx->rb_ticket) ctx->rb_done = ++ctx->rb_ticket;   // (nothing posted is outstanding: everything launched so far is complete)

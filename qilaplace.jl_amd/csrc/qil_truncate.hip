@@ -94,9 +94,8 @@ static int svd_trunc_lowrank(qil_context* ctx, int dtype, int64_t m, int64_t n, 
                              int64_t maxdim, int64_t mindim, int absorb, int64_t* rank, void** U_out, void** Vh_out,
                              std::vector<double>* S_out, int* done) {
     *done = 0;
-    static const bool enabled = !(getenv("QIL_SVD_LOWRANK") && atoi(getenv("QIL_SVD_LOWRANK")) == 0);   // tuning aid
     const int64_t r0 = std::min(m, n);
-    if (!enabled || r0 < 384 || !(cutoff > 0)) return QIL_OK;
+    if (r0 < 384 || !(cutoff > 0)) return QIL_OK;
     const size_t e = qil_elem_size(dtype);
     const int cj = dtype == QIL_C64 ? 2 : 1;
     const int nre = dtype == QIL_C64 ? 2 : 1;
