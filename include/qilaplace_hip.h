@@ -81,26 +81,14 @@ int qil_context_synchronize(qil_context* ctx);
 int qil_context_trim(qil_context* ctx);
 int qil_context_mem_info(qil_context* ctx, int64_t* pool_bytes_in_use, int64_t* pool_bytes_cached,
                          int64_t* device_free, int64_t* device_total);
-/* Testing aid: the n-th pool allocation from now (0 = the next one) fails with QIL_ENOMEM; n < 0 switches the
- * injection off.  Used to check that a failing call leaves no device memory behind and its operands intact. */
-int qil_context_fail_alloc_after(qil_context* ctx, int64_t n);
-/* Testing aid: pool bytes in use that no MPS/MPO handle owns.  Zero between calls -- every temporary is back in
- * the pool whether the last call succeeded or failed.                                                        */
-int qil_context_unowned_bytes(qil_context* ctx, int64_t* out);
 /* Host CPUs the batch runners of this process may keep busy: min(cgroup CPU quota, affinity mask) / LOCAL_WORLD_SIZE
  * (the ranks torch.distributed.run / bench.py place on this node), overridden by QIL_CPU_BUDGET.  The lock-step batch
  * entry points (qil_*_batch) never run more polling launcher threads than this minus one.  No reference counterpart
  * (the reference is single-threaded Julia + BLAS threads, benchmarking.md:12).                                      */
 int qil_host_cpu_budget(int* out);
 
-/* HIP-event timing on the context's stream (hipEventRecord / hipEventElapsedTime). */
-int qil_timer_start(qil_context* ctx);
-int qil_timer_stop(qil_context* ctx, double* elapsed_ms);   /* synchronises the stop event */
-/* Per-kernel profile: when enabled every launch of the site-contraction kernel is
- * bracketed by its own event pair; read returns launches and summed device ms since
- * the last reset (synchronises).                                                   */
-int qil_profile_enable(qil_context* ctx, int on);
-int qil_profile_read(qil_context* ctx, int64_t* n_launches, double* total_ms, int reset);
+/* (fault injection, pool accounting, HIP-event timers and the apply-kernel profile are not part of the boundary:
+ * include/qilaplace_hip_testing.h) */
 
 /* ------------------------------------------------------------------ containers (T1-T3) */
 /* Construct from HOST tensors.  bond_dims: the n-1 internal bonds.  site_ids: n
@@ -315,10 +303,6 @@ int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n
 /* Thin QR with non-negative real diagonal (qr(...; positive=true), rsvd.jl:83,90,94) of a host operand
  * A (m x n, m >= n, column-major): Q (m x n), R (n x n).  Utility / test hook.                       */
 int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R);
-/* Diagnostic: device-resident time of the same GEMM (operands generated in HBM, HIP events). */
-int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
-                         int reps, double* ms_per_call);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,11 +1,12 @@
-"""Host-side producers of the transform MPOs (the operand ``W`` of the hot path).
+"""Producers of the transform MPOs (the operand ``W`` of the hot path): device builders by default, host chains beside them.
 
-In the reference the builders are CPU code as well (tiny latency-bound QR/SVD chains on tensors with
-D <= 8 / 18 / 92): src/transforms/qft_transformer.jl:121-165, dt_transformer.jl:312-412,
-zt_transformer.jl:41-112, with the gate blocks of src/circuits/{qft,dt,zt}_gates.jl.  They stay on the
-host here too (SURVEY.md section 8b "who calls it"; a batched device port is 8f-1) and hand the finished
-tensors to the GPU once.  ``build_*_mpo`` return device handles (SingleSiteMPO / PairedSiteMPO);
-``*_tensors`` return the numpy site tensors W[a, s_in, s_out, b].
+Reference: src/transforms/qft_transformer.jl:121-165, dt_transformer.jl:312-412, zt_transformer.jl:41-112, with the gate
+blocks of src/circuits/{qft,dt,zt}_gates.jl -- CPU chains of tiny latency-bound QR / SVD steps (D <= 8 / 18 / 92).
+``build_qft_mpo`` / ``build_dt_mpo(_batch)`` / ``build_zt_mpo(_batch)`` build in HBM (the persistent
+kernels of csrc/qil_build_persist.hip and qil_build_chain.hip, one launch per chain / per damping sweep; only 2 x 2 gate
+blocks come from the host) and return device handles (SingleSiteMPO / PairedSiteMPO).  The numpy chains of this file
+(``*_tensors``, ``device=False``) remain as the independent restatement the device builders are tested against and as the
+route for tiny n; they return the site tensors W[a, s_in, s_out, b].
 
 Implementation notes: every sweep is written once, for the left-to-right direction; the right-to-left
 ("up") variants of the reference run the same routine on the mirrored chain.  Truncation is the

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "qilaplace_hip.h"
+#include "qilaplace_hip_testing.h"
 
 // ---------------------------------------------------------------- errors
 void qil_set_error(const char* fmt, ...);

@@ -978,8 +978,10 @@ static int apply_compress_on(qil_context* ctx, const qil_mpo* W, const qil_mps* 
     // (r01), max(1.5 maxdim, maxdim + 16) (r02/r03) -- 200 random flat-spectrum products with maxdim 8 ... 128 each, 0 bad
     // (tools/_fuzz_product_compress.py, QIL_FUZZ_ZIP=plus16) -- and the oracle tests, while an oversampling of 4 (1.5 maxdim at
     // maxdim = 8) fails 2 of 200.  Bench product, maxdim 64: cap 96 117 ms, cap 80 108.6 ms (MEASUREMENTS R04.7).
+    // The evidence covers maxdim <= 128 with flat spectra only: beyond that a relative floor of 1.125 maxdim
+    // keeps the oversampling proportional (maxdim 256: 288, 512: 576) until a slowly-decaying case at that size is fuzzed.
     const int64_t zip_over = 16;
-    if (zip_maxdim <= 0) zip_maxdim = maxdim > kNoCap / 2 ? kNoCap : maxdim + zip_over;
+    if (zip_maxdim <= 0) zip_maxdim = maxdim > kNoCap / 2 ? kNoCap : std::max(maxdim + zip_over, maxdim + (maxdim + 7) / 8);
     const double cutoff = tol * tol / ((double)(N - 1) * sweeps);
     const double zip_cutoff = cutoff * 1e-2;
     const bool wc = W->dtype == QIL_C64, ac = psi->dtype == QIL_C64;

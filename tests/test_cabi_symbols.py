@@ -9,10 +9,25 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "qilaplace_hip.h")).read()
+TESTING_HOOKS = {"qil_context_fail_alloc_after", "qil_context_unowned_bytes", "qil_timer_start", "qil_timer_stop",
+                 "qil_profile_enable", "qil_profile_read", "qil_gemm_device_time"}
+
+
+def _symbols_of(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(qil_[a-z0-9_]+)\s*\(", src)))
+    return set(re.findall(r"\b(qil_[a-z0-9_]+)\s*\(", src))
+
+
+def _declared_symbols():
+    """Boundary (include/qilaplace_hip.h) + test / measurement hooks (include/qilaplace_hip_testing.h)."""
+    return sorted(_symbols_of("qilaplace_hip.h") | _symbols_of("qilaplace_hip_testing.h"))
+
+
+def test_testing_hooks_live_in_their_own_header():
+    """fault injection, pool accounting, timers and the kernel profile are not part of SURVEY 8(b)'s interface."""
+    assert _symbols_of("qilaplace_hip_testing.h") == TESTING_HOOKS
+    assert not (_symbols_of("qilaplace_hip.h") & TESTING_HOOKS)
 
 
 def test_header_declares_the_boundary():
