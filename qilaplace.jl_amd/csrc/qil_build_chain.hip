@@ -248,6 +248,7 @@ __global__ __launch_bounds__(CB_NT) void chain_build_persistent(CbArgs a) {
                 st.blk_dl = a.blkdims[2 * (step.blk + t)];
                 st.blk_dr = a.blkdims[2 * (step.blk + t) + 1];
             }
+            if (B1 > CB_DCAP || Da * 4 * B1 > (int)CB_SITE_CAP) CB_FAIL(1);    // (before the load: Ms holds one stored site)
             for (int e = tid; e < Da * 4 * B1; e += CB_NT) Ms[e] = site(t)[e];
             __syncthreads();
             const int B2 = st.blk_dr;
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(CB_NT) void chain_build_persistent(CbArgs a) {
                 }
                 __syncthreads();
                 nb = st.rank;
+                if (nb > CB_DCAP || rows * nb > (int)CB_SITE_CAP) CB_FAIL(6);   // (before the store: a stored site holds CB_SITE_CAP entries)
                 for (int e = tid; e < rows * nb; e += CB_NT) {
                     const int row = e % rows, j = e / rows;
                     dst[e] = scale_t(A[row + rows * st.perm[j]], st.inv[j]);           // (r, i, o | new bond)
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(CB_NT) void chain_build_persistent(CbArgs a) {
             } else {
                 // fat core: Q = identity on the rows, the core itself is the remainder
                 nb = rows;
+                if (nb > CB_DCAP || rows * rows > (int)CB_SITE_CAP) CB_FAIL(6);
                 for (int e = tid; e < rows * rows; e += CB_NT) dst[e] = (e % rows) == (e / rows) ? c64{1, 0} : c64{0, 0};
                 for (int e = tid; e < rows * cols; e += CB_NT) Tn[e] = A0[e];
             }
@@ -634,11 +637,12 @@ int qil_build_chain_persistent(qil_context* ctx, int kind, int64_t n, double cut
         QIL_HIP(hipMemcpyAsync(static_cast<c64*>(ws) + (long long)i * CB_SITE_CAP, init_flat.data() + (size_t)i * 16,
                                (size_t)init[(size_t)i].dl * 4 * init[(size_t)i].dr * sizeof(c64), hipMemcpyHostToDevice, s));
     constexpr size_t lds_bytes = (size_t)(2 * CB_DCAP * CB_DCAP * 2 + CB_SITE_CAP + 2 * (4 * CB_DCAP * 2 * CB_DCAP) + CB_SITE_CAP) * sizeof(c64);
-    static bool attr = false;
-    if (!attr) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_build_persistent), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes));
-        attr = true;
+    static qil_lds_grant grant;                                  // per device; a refusal sends the caller down the generic route
+    if (grant.ensure(ctx->device, reinterpret_cast<const void*>(&chain_build_persistent), lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        release();
+        *fallback = 1;
+        return QIL_OK;
     }
     CbArgs a;
     a.nsteps = (int)steps.size();

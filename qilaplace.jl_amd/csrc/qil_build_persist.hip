@@ -1019,11 +1019,11 @@ static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* 
     if (const char* e = getenv("QIL_DT_DCAP")) dcap = std::max(8, std::min(PB_DMAX, atoi(e)));
     const long long site_cap = (long long)dcap * 4 * dcap;
     const int arena_doubles = (160 * 1024 - 8 * 1024) / 8;
-    static bool attr = false;
-    if (!attr) {
-        QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dt_build_persistent),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, arena_doubles * 8));
-        attr = true;
+    static qil_lds_grant grant;                                  // per device; a refusal sends the caller to the launch-per-step builder
+    if (grant.ensure(ctx->device, reinterpret_cast<const void*>(&dt_build_persistent), (size_t)arena_doubles * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        *fallback = 1;
+        return QIL_OK;
     }
     const int gstride = 2 * (int)n + 2;
     std::vector<double> gates((size_t)B * gstride, 0.0);

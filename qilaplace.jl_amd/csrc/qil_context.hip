@@ -263,9 +263,13 @@ qil_call_scope::qil_call_scope(qil_context* c)
     if (c) {
         c->cholqr_skip = 0;
         // ... and so does the R^-1 block CholeskyQR2 parks for a certificate (cholqr2 / certify_no_truncation): it is state of
-        // ONE call.  A pointer that survived the previous call is released if the pool still knows the block as live, and
-        // forgotten either way, so no call can free or certify against a block that has been handed out again since.
-        if (c->rinv && c->live_blocks.count(c->rinv)) qil_ctx_free(c, c->rinv);
+        // ONE call.  A pointer that survived the previous call is released only if the pool still knows THAT allocation
+        // (same address AND same allocation serial, not owned by a handle: the address alone may have been handed out again,
+        // ADVICE r04), and forgotten either way, so no call can free or certify against somebody else's block.
+        if (c->rinv) {
+            auto it = c->live_blocks.find(c->rinv);
+            if (it != c->live_blocks.end() && it->second.serial == c->rinv_serial && !it->second.owned) qil_ctx_free(c, c->rinv);
+        }
         c->rinv = nullptr;
         c->rinv_for = nullptr;
         c->want_rinv = false;
@@ -679,7 +683,7 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
         const bool in_step = lockstep && w->lockstep;            // (a slot whose thread could not be started runs alone afterwards)
         w->dbg_times = batch_debug;
         int s0 = QIL_OK;
-        if ((k || lockstep) && (hipSetDevice(w->device) != hipSuccess || (!lockstep && hipStreamWaitEvent(w->stream, ready, 0) != hipSuccess))) s0 = QIL_EHIP;
+        if ((k || lockstep) && (hipSetDevice(w->device) != hipSuccess || (!in_step && w != home && hipStreamWaitEvent(w->stream, ready, 0) != hipSuccess))) s0 = QIL_EHIP;
         for (int64_t j = k; j < nb; j += nw) {
             const auto tj0 = std::chrono::steady_clock::now();
             const int s = s0 != QIL_OK ? s0 : fn(j, w);
@@ -707,23 +711,18 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
     std::vector<std::thread> threads;
     threads.reserve((size_t)nw - 1);
     std::vector<int> inline_slots;                            // slots whose thread could not be started run here afterwards
-    // lock-step: every slot, the home one included, runs on a thread of its own and this thread is the launcher
-    for (int k = lockstep ? 0 : 1; k < nw; ++k) {
-        try {
-            threads.emplace_back(drive, k);
-        } catch (const std::system_error&) {
-            inline_slots.push_back(k);
-            if (lockstep) {
-                qil_context* w = slot_ctx(k);
-                w->lockstep->q[w->ls_slot].live.store(0, std::memory_order_release);
-                w->lockstep = nullptr;
-                w->stream = own_stream[(size_t)k];
-            }
-        }
-    }
-    if (lockstep) {                                               // one launcher per group; this thread serves group 0
-        std::vector<std::thread> launchers;
-        std::vector<int> unserved;                                // groups whose launcher thread could not be started
+    auto demote = [&](int k) {                                // slot k leaves its lock-step group: its own stream, plain launches
+        qil_context* w = slot_ctx(k);
+        w->lockstep->q[w->ls_slot].live.store(0, std::memory_order_release);
+        w->lockstep = nullptr;
+        w->stream = own_stream[(size_t)k];
+    };
+    // lock-step: one launcher per group, this thread serves group 0.  The launchers start BEFORE any chain thread:
+    // a group whose launcher thread cannot be started (thread exhaustion) is dissolved here, while nothing has been queued --
+    // its chains run on their own streams with plain launches instead of filling rings nobody serves until group 0 is done
+    // (spurious QIL_EHIP after qil_ls_park's 60 s).
+    std::vector<std::thread> launchers;
+    if (lockstep)
         for (int g = 1; g < ng; ++g) {
             try {
                 launchers.emplace_back([&, g]() {
@@ -731,11 +730,20 @@ int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int
                     lockstep_run(&lsg[(size_t)g], batch_debug);
                 });
             } catch (const std::system_error&) {
-                unserved.push_back(g);                            // (thread exhaustion: this thread serves the group after its own)
+                for (int k = g; k < nw; k += ng) demote(k);
             }
         }
+    // every slot, the home one included, runs on a thread of its own in the lock-step form
+    for (int k = lockstep ? 0 : 1; k < nw; ++k) {
+        try {
+            threads.emplace_back(drive, k);
+        } catch (const std::system_error&) {
+            inline_slots.push_back(k);
+            if (lockstep && slot_ctx(k)->lockstep) demote(k);
+        }
+    }
+    if (lockstep) {
         lockstep_run(&lsg[0], batch_debug);
-        for (int g : unserved) lockstep_run(&lsg[(size_t)g], batch_debug);
         for (auto& t : launchers) t.join();
     } else {
         drive(0);

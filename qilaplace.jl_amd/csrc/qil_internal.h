@@ -18,6 +18,26 @@
 #include "qilaplace_hip.h"
 #include "qilaplace_hip_testing.h"
 
+#include <atomic>
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE (a `static bool` granted it on the first GPU only,
+// and a context on a second GPU of the same process then failed its launch).  One of these per kernel: the bytes granted so
+// far on each device; concurrent callers may both set the attribute, which is harmless.
+struct qil_lds_grant {
+    static constexpr int kDevices = 64;
+    std::atomic<size_t> bytes[kDevices] = {};
+    hipError_t ensure(int device, const void* fn, size_t want) {
+        const int d = device >= 0 && device < kDevices ? device : -1;
+        if (d >= 0 && want <= bytes[d].load(std::memory_order_acquire)) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess && d >= 0) {
+            size_t cur = bytes[d].load(std::memory_order_relaxed);
+            while (cur < want && !bytes[d].compare_exchange_weak(cur, want, std::memory_order_release)) {}
+        }
+        return e;
+    }
+};
+
 // ---------------------------------------------------------------- errors
 void qil_set_error(const char* fmt, ...);
 int qil_fail(int code, const char* fmt, ...);
@@ -71,6 +91,7 @@ struct qil_context {
     // (want_rinv) and takes the block over (rinv, valid for the R at rinv_for; the caller frees it)
     bool want_rinv = false;
     void* rinv = nullptr;
+    uint64_t rinv_serial = 0;            // allocation serial of the parked block (the call scope frees it only if it still matches)
     const void* rinv_for = nullptr;
     // small device -> host read-backs without a copy command or a stream synchronisation (qil_read_back): kRbSlots slots of
     // kRbSlotBytes in pinned, device-visible memory + a ticket word a kernel writes behind the data; the host polls the word

@@ -127,14 +127,9 @@ int qil_klaunch(qil_context* ctx, dim3 grid, dim3 block, size_t lds, A... args) 
     static_assert((std::is_trivially_copyable<A>::value && ...), "kernel arguments must be trivially copyable");
     static_assert(sizeof(qil_pack<A...>) <= QIL_PACK_MAX, "argument pack too large for a combined launch");
     if (lds > 64 * 1024) {                                    // both forms, whenever an instantiation asks for more than before
-        static std::atomic<size_t> granted{0};
-        if (lds > granted.load(std::memory_order_relaxed)) {
-            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qil_k1<F, A...>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-            QIL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qil_kn<F, A...>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-            granted.store(lds, std::memory_order_relaxed);
-        }
+        static qil_lds_grant g1, gn;                              // per device (qil_internal.h)
+        QIL_HIP(g1.ensure(ctx->device, reinterpret_cast<const void*>(&qil_k1<F, A...>), lds));
+        QIL_HIP(gn.ensure(ctx->device, reinterpret_cast<const void*>(&qil_kn<F, A...>), lds));
     }
     qil_lockstep* ls = ctx->lockstep;
     if (!ls) {

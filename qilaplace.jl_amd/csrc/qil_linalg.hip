@@ -2417,6 +2417,7 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
         if (ctx->rinv) qil_ctx_free(ctx, ctx->rinv);
         ctx->rinv = nullptr;
         QIL_TRY(qil_ctx_alloc(ctx, nn, &ctx->rinv));
+        ctx->rinv_serial = ctx->alloc_serial;                    // (the block just allocated)
         QIL_TRY(gemm_dispatch<T>(ctx, 0, 0, n, n, n, X1, n, X2, n, static_cast<T*>(ctx->rinv), n));
         ctx->rinv_for = R;
     }
