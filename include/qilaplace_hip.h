@@ -303,6 +303,29 @@ int qil_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n
 /* Thin QR with non-negative real diagonal (qr(...; positive=true), rsvd.jl:83,90,94) of a host operand
  * A (m x n, m >= n, column-major): Q (m x n), R (n x n).  Utility / test hook.                       */
 int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, const void* A, void* Q, void* R);
+/* ------------------------------------------------------------------ multi-GPU: the batched gather */
+/* Independent (signal, damping value) items are dealt round-robin to one process per GPU (item i belongs to rank
+ * i mod world); nothing is exchanged until the end, when every rank needs all coefficient batches: ONE RCCL all-gather
+ * over xGMI.  The reference's callers loop serially over the damping values (docs/src/tutorials/zt.jl:300-348,
+ * scripts/benchmark/zt_full_runtime.jl:151-221); this is the verb a Julia host uses in place of torch.distributed.
+ * RCCL is loaded at run time by qil_comm_unique_id / qil_comm_create (QIL_RCCL_LIB, else the librccl.so next to the
+ * process's libamdhip64, else the loader path): libqilhip.so itself links the HIP runtime only.
+ *
+ * Rendezvous: rank 0 calls qil_comm_unique_id and ships the QIL_COMM_ID_BYTES bytes to the other ranks over any host
+ * channel (a file, Distributed.jl, MPI); then EVERY rank calls qil_comm_create (collective: returns when all have).   */
+#define QIL_COMM_ID_BYTES 128
+typedef struct qil_comm qil_comm;
+int qil_comm_unique_id(void* id_out);
+int qil_comm_create(qil_context* ctx, int rank, int world, const void* id, qil_comm** out);
+int qil_comm_destroy(qil_comm* comm);
+int qil_comm_info(const qil_comm* comm, int* rank, int* world);
+/* local: this rank's items in its own order (item rank, rank + world, ...), each `width` complex values (interleaved
+ * doubles), host memory.  out: n_items x width complex values in ITEM order, host memory, on every rank.  Collective. */
+int qil_gather_coefficients(qil_comm* comm, int64_t n_items, int64_t width, const double* local, double* out);
+/* The layout rule of that gather as a host function (no GPU, no RCCL): `gathered` = world blocks of
+ * ceil(n_items / world) x width complex values in rank order -> `out` in item order.                                 */
+int qil_sweep_unshuffle(int world, int64_t n_items, int64_t width, const double* gathered, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,8 @@ using ..Mpo: SingleSiteMPO, PairedSiteMPO
 using ..ApplyMPO: _as_single_site_mpo
 
 export DeviceMPS, DeviceMPO, to_device, to_host, signal_mps_device, marginal, mps_block, apply_compress,
-    compress_mpo!, build_dt_mpo_batch, build_qft_mpo_device, build_zt_qft_chain_device, apply_coefficient_sweep, apply!, rsvd_device, svd_device
+    compress_mpo!, build_dt_mpo_batch, build_qft_mpo_device, build_zt_qft_chain_device, apply_coefficient_sweep, apply!, rsvd_device, svd_device,
+    Comm, comm_unique_id, gather_coefficients, damping_sweep, shard_items
 
 const LIB = get(ENV, "QILHIP_LIB", "libqilhip.so")
 
@@ -482,6 +483,57 @@ function build_zt_qft_chain_device(psi::DeviceMPS; cutoff::Float64=1e-14, maxdim
                 ctx().h, n, cutoff, maxdim, _site_ids(psi.sites), h, fb))
     fb[] != 0 && error("build_zt_qft_chain_device: a bond exceeded the in-LDS capacity of the persistent builder")
     return finalizer(_free!, DeviceMPO(h[], copy(psi.sites), true))
+end
+
+# ---- multi-GPU: the batched gather of a sweep (SURVEY 8e).  One Julia process per GPU (Distributed.jl workers, MPI ranks or a
+# plain launcher that sets RANK / WORLD_SIZE); items are dealt round-robin (item i -> rank i mod world, `shard_items`), nothing is
+# exchanged until every rank needs all coefficient batches: ONE ncclAllGather over xGMI inside qil_gather_coefficients.
+# Replaces the serial loops over the damping values of docs/src/tutorials/zt.jl:300-348 / scripts/benchmark/zt_full_runtime.jl:151-221.
+mutable struct Comm
+    h::Ptr{Cvoid}
+    rank::Int
+    world::Int
+end
+const COMM_ID_BYTES = 128
+# rank 0 creates the id and ships it to the other ranks over any host channel (Distributed.remotecall, a file, MPI.Bcast)
+function comm_unique_id()
+    id = Vector{UInt8}(undef, COMM_ID_BYTES)
+    check(ccall((:qil_comm_unique_id, LIB), Cint, (Ptr{Cvoid},), id))
+    return id
+end
+# collective: every rank calls it with the same id
+function Comm(rank::Integer, world::Integer, id::Vector{UInt8})
+    length(id) == COMM_ID_BYTES || throw(ArgumentError("Comm: the unique id must be $COMM_ID_BYTES bytes"))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:qil_comm_create, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx().h, rank, world, id, h))
+    return finalizer(c -> (ccall((:qil_comm_destroy, LIB), Cint, (Ptr{Cvoid},), c.h); c.h = C_NULL), Comm(h[], rank, world))
+end
+shard_items(n_items::Integer, world::Integer, rank::Integer) = collect(rank:world:(n_items - 1))      # zero-based item indices
+# `local_batches`: this rank's coefficient batches in its own order (items rank, rank + world, ...), each of length `width`;
+# returns the (n_items, width) matrix in item order on every rank
+function gather_coefficients(comm::Comm, local_batches::Vector{Vector{ComplexF64}}, n_items::Integer, width::Integer)
+    mine = length(shard_items(n_items, comm.world, comm.rank))
+    length(local_batches) == mine || throw(ArgumentError("gather_coefficients: rank $(comm.rank) owns $mine items, got $(length(local_batches))"))
+    loc = Matrix{ComplexF64}(undef, width, max(mine, 1))             # column = one item: item-major in memory
+    for (s, v) in enumerate(local_batches)
+        length(v) == width || throw(ArgumentError("gather_coefficients: batch $s has length $(length(v)), expected $width"))
+        loc[:, s] = v
+    end
+    out = Matrix{ComplexF64}(undef, width, n_items)
+    check(ccall((:qil_gather_coefficients, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}),
+                comm.h, n_items, width, loc, out))
+    return permutedims(out)
+end
+# the whole damping sweep of BASELINE configs[3] on this rank's share + the gather (qilaplace.jl_amd/sweep.py: damping_sweep)
+function damping_sweep(comm::Comm, psi::DeviceMPS, wrs::AbstractVector{<:Real}, bits::AbstractMatrix{<:Integer}; cutoff::Float64=1e-14, maxdim::Int=1000)
+    mine = shard_items(length(wrs), comm.world, comm.rank) .+ 1
+    batches = Vector{ComplexF64}[]
+    if !isempty(mine)
+        Ws = build_dt_mpo_batch(psi, wrs[mine]; cutoff=cutoff, maxdim=maxdim)
+        res = apply_coefficient_sweep(Ws, psi, bits)                 # (operator, query)
+        batches = [Vector{ComplexF64}(res[k, :]) for k in 1:length(mine)]
+    end
+    return gather_coefficients(comm, batches, length(wrs), size(bits, 1))
 end
 
 end # module

@@ -23,7 +23,7 @@ from .builders import (build_qft_mpo, build_dt_mpo, build_zt_mpo, qft_mpo_tensor
                        dt_mpo_tensors, zt_mpo_tensors, dt_mpo_tensors_many, build_dt_mpo_batch,
                        build_zt_mpo_batch, zt_qft_chain_tensors, qft_mpo_device, zt_qft_chain_device)
 from .interchange import save, load  # noqa: F401
-from .sweep import shard_items, sweep, damping_sweep, gather_results, damping_sample_bits  # noqa: F401
+from .sweep import shard_items, sweep, damping_sweep, gather_results, damping_sample_bits, Comm, unshuffle  # noqa: F401
 
 __all__ = [
     "Context", "default_context", "set_default_context", "device_count", "host_cpu_budget",
@@ -33,6 +33,6 @@ __all__ = [
     "build_qft_mpo", "build_dt_mpo", "build_zt_mpo", "qft_mpo_tensors", "dt_mpo_tensors", "zt_mpo_tensors",
     "dt_mpo_tensors_many", "build_dt_mpo_batch", "build_zt_mpo_batch", "zt_qft_chain_tensors", "qft_mpo_device", "zt_qft_chain_device", "mpo_compress", "compress_batch", "mpo_compress_batch", "mps_block",
     "save", "load",
-    "shard_items", "sweep", "damping_sweep", "gather_results", "damping_sample_bits",
+    "shard_items", "sweep", "damping_sweep", "gather_results", "damping_sample_bits", "Comm", "unshuffle",
     "QilError", "QilDomainError",
 ]

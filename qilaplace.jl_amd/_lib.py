@@ -136,6 +136,12 @@ PROTOTYPES = {
     "qil_qr_positive": [_vp, _int, _i64, _i64, _vp, _vp, _vp],
     "qil_gemm_device_time": [_vp, _int, _int, _int, _i64, _i64, _i64, _int, _pdbl],
     "qil_svd_trunc": [_vp, _vp, _i64, _i64, _int, _dbl, _i64, _i64, _pi64, _vp, _pdbl, _vp],
+    "qil_comm_unique_id": [_vp],
+    "qil_comm_create": [_vp, _int, _int, _vp, _pvp],
+    "qil_comm_destroy": [_vp],
+    "qil_comm_info": [_vp, _pint, _pint],
+    "qil_gather_coefficients": [_vp, _i64, _i64, _pdbl, _pdbl],
+    "qil_sweep_unshuffle": [_int, _i64, _i64, _pdbl, _pdbl],
 }
 _RET = {"qil_last_error": C.c_char_p, "qil_version": C.c_char_p}
 

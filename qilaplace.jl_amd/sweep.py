@@ -9,7 +9,100 @@ gloo in the CPU tests).
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import time
+
 import numpy as np
+
+from . import _lib as L
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """RCCL communicator of the C ABI (qil_comm_*): the sweep's gather without torch.distributed -- what a Julia host calls.
+
+    ``Comm(ctx, rank, world, uid)`` is collective (every rank, same 128-byte ``uid`` from ``Comm.unique_id()`` on rank 0).
+    ``Comm.from_env(ctx)`` reads RANK / WORLD_SIZE and passes the id through a file: rank 0 writes
+    ``$QIL_COMM_FILE`` (default ``/tmp/qil_comm_<MASTER_PORT>_<launcher pid>.id``) atomically, the others wait for it --
+    one node, one shared /tmp: the scope of SURVEY.md 8(e)."""
+
+    def __init__(self, ctx, rank: int, world: int, uid: bytes):
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError(f"Comm: unique id must be {COMM_ID_BYTES} bytes, got {len(uid)}")
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(uid, COMM_ID_BYTES)
+        L.check(L.lib.qil_comm_create(ctx.handle, self.rank, self.world, C.cast(buf, C.c_void_p), C.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        L.check(L.lib.qil_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    @classmethod
+    def from_env(cls, ctx, timeout_s: float = 120.0):
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if world == 1:
+            return cls(ctx, 0, 1, cls.unique_id())
+        path = os.environ.get("QIL_COMM_FILE") or os.path.join(
+            "/tmp", f"qil_comm_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('QIL_COMM_TAG', os.getppid())}.id")
+        if rank == 0:
+            uid = cls.unique_id()
+            with open(path + ".tmp", "wb") as f:
+                f.write(uid)
+            os.replace(path + ".tmp", path)
+        else:
+            t0 = time.monotonic()
+            while not (os.path.exists(path) and os.path.getsize(path) == COMM_ID_BYTES):
+                if time.monotonic() - t0 > timeout_s:
+                    raise TimeoutError(f"Comm.from_env: rank 0 never wrote {path}")
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                uid = f.read()
+        comm = cls(ctx, rank, world, uid)              # collective: every rank has read the file when this returns
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return comm
+
+    def gather_coefficients(self, local: dict, n_items: int, width: int):
+        """{item index -> complex vector (width,)} of THIS rank's items -> (n_items, width) in item order on every rank:
+        one ncclAllGather (qil_gather_coefficients)."""
+        mine = shard_items(n_items, self.world, self.rank)
+        loc = np.zeros((max(len(mine), 1), width), dtype=np.complex128)
+        for slot, i in enumerate(mine):
+            loc[slot] = local[i]
+        out = np.zeros((n_items, width), dtype=np.complex128)
+        L.check(L.lib.qil_gather_coefficients(self.handle, int(n_items), int(width),
+                                              loc.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            L.lib.qil_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                              # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def unshuffle(world: int, n_items: int, width: int, gathered):
+    """The gather's layout rule (qil_sweep_unshuffle, host only): world blocks of ceil(n_items / world) x width complex values
+    in rank order -> (n_items, width) in item order."""
+    g = np.ascontiguousarray(gathered, dtype=np.complex128)
+    out = np.zeros((n_items, width), dtype=np.complex128)
+    L.check(L.lib.qil_sweep_unshuffle(int(world), int(n_items), int(width), g.ctypes.data_as(C.POINTER(C.c_double)),
+                                      out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
 
 
 def shard_items(n_items: int, world: int, rank: int):
@@ -19,10 +112,23 @@ def shard_items(n_items: int, world: int, rank: int):
     return list(range(rank, n_items, world))
 
 
+def _world_rank(dist):
+    if isinstance(dist, Comm):
+        return dist.world, dist.rank
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    return world, (dist.get_rank() if world > 1 else 0)
+
+
 def gather_results(local: dict, n_items: int, width: int, dist=None, device=None, always_gather=False):
-    """All ranks contribute {item index -> complex vector of length `width`}; returns the
+    """`dist`: a torch.distributed module with an initialised process group, or a `Comm` (RCCL through the C ABI), or None.
+    All ranks contribute {item index -> complex vector of length `width`}; returns the
     (n_items, width) complex array in item order on every rank.  `always_gather`: run the collective even in a world of
     one rank (exercises the RCCL path on a 1-GPU box: bench.py with QIL_BENCH_FORCE_DIST=1)."""
+    if isinstance(dist, Comm):                     # the C ABI's RCCL gather (no torch): qil_gather_coefficients
+        if dist.world == 1 and not always_gather:
+            dist = None
+        else:
+            return dist.gather_coefficients(local, n_items, width)
     if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always_gather):
         out = np.zeros((n_items, width), dtype=np.complex128)
         for i, v in local.items():
@@ -51,8 +157,7 @@ def gather_results(local: dict, n_items: int, width: int, dist=None, device=None
 def sweep(items, work_fn, width: int, dist=None, device=None, always_gather=False):
     """Run ``work_fn(item) -> complex vector (width,)`` on this rank's share of ``items`` and
     gather all results in item order."""
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    world, rank = _world_rank(dist)
     local = {i: work_fn(items[i]) for i in shard_items(len(items), world, rank)}
     return gather_results(local, len(items), width, dist if (world > 1 or always_gather) else None, device, always_gather)
 
@@ -103,8 +208,7 @@ def damping_sweep(psi, sigmas, bits, build_mpo=None, dist=None, device=None, cut
 
         return sweep(sigmas, work, bits.shape[0], dist, device, always_gather)
     from .builders import build_dt_mpo_batch
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    world, rank = _world_rank(dist)
     mine = shard_items(len(sigmas), world, rank)
     local = {}
     if mine:

@@ -479,6 +479,36 @@ def _config4_signal(n):
     return sum(ak[k] * np.sin(wk[k] * j) * np.exp(lk[k] * j) for k in range(10))
 
 
+def test_cabi_rccl_gather_world_of_one(qil):
+    """SURVEY.md 8(e) through the C ABI (qil_comm_* / qil_gather_coefficients, RCCL loaded at run time, no torch): the
+    communicator of a world of one rank -- all a 1-GPU box can hold -- created from a unique id, the damping sweep's gather run
+    through ncclAllGather, equal to the plain result; ragged shares and the layout rule are covered on CPU
+    (tests/test_sweep_gloo.py::test_cabi_gather_layout_equals_the_gloo_gather)."""
+    ctx = qil.default_context()
+    comm = qil.Comm(ctx, 0, 1, qil.Comm.unique_id())
+    assert (comm.rank, comm.world) == (0, 1)
+    n = 5
+    N = 2 ** n
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    psi = qil.signal_ztmps(x, cutoff=1e-14)
+    sig = np.linspace(0.25, 4.0, 6)
+    bits, _, _ = qil.damping_sample_bits(n, 64, seed=3, kmax=N)
+    plain = qil.damping_sweep(psi, sig, bits)
+    through = qil.damping_sweep(psi, sig, bits, dist=comm, always_gather=True)
+    assert np.array_equal(plain, through)
+    # the verb itself on arbitrary data, twice (buffers return to the pool in between)
+    rng = np.random.default_rng(0)
+    for width in (1, 1024):
+        items = rng.standard_normal((7, width)) + 1j * rng.standard_normal((7, width))
+        got = comm.gather_coefficients({i: items[i] for i in range(7)}, 7, width)
+        assert np.array_equal(got, items)
+    comm.close()
+    # from_env in a world of one (no RANK / WORLD_SIZE set: rank 0 of 1)
+    c2 = qil.Comm.from_env(ctx)
+    assert c2.world == 1
+    c2.close()
+
+
 def test_config4_damping_sweep_full_size(qil):
     """BASELINE.json configs[3] at full size on one GPU: n = 24, 64 damping values through `damping_sweep` with the
     batched device builder, 1024 sampled coefficients per value, checked where the output is NOT negligible

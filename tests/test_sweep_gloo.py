@@ -71,3 +71,34 @@ def test_sweep_world2_gloo_matches_serial():
     serial = np.stack([_work_item(0.25 * (i + 1)) for i in range(5)])
     for r in range(2):
         assert np.abs(results[r] - serial).max() < 1e-14
+
+
+def test_cabi_gather_layout_equals_the_gloo_gather():
+    """qil_sweep_unshuffle -- the layout rule of the C ABI's RCCL gather (qil_gather_coefficients: per-rank blocks of
+    ceil(n_items / world) x width, rank order -> item order) -- gives what the torch.distributed path of sweep.py gives:
+    world 2 against the gloo run's construction (ragged share), and worlds 1 / 3 / 8 against the definition."""
+    sweep = importlib.import_module("qilaplace_jl_amd.sweep")
+    rng = np.random.default_rng(8)
+    for world, n_items, width in ((2, 5, 16), (1, 4, 3), (3, 10, 7), (8, 64, 1024), (8, 3, 2), (4, 0, 5)):
+        items = rng.standard_normal((n_items, width)) + 1j * rng.standard_normal((n_items, width))
+        per = (n_items + world - 1) // world
+        blocks = np.zeros((world, per, width), dtype=np.complex128)          # what every rank would contribute
+        for r in range(world):
+            for slot, i in enumerate(sweep.shard_items(n_items, world, r)):
+                blocks[r, slot] = items[i]
+        out = sweep.unshuffle(world, n_items, width, blocks)
+        assert np.array_equal(out, items)
+        # ... and the torch path's own reassembly of the same blocks (gather_results' loop), restated
+        ref = np.zeros_like(items)
+        for r in range(world):
+            for slot, i in enumerate(sweep.shard_items(n_items, world, r)):
+                ref[i] = blocks[r, slot]
+        assert np.array_equal(out, ref)
+    with pytest.raises(ValueError):
+        sweep.unshuffle(0, 4, 4, np.zeros((4, 4), dtype=np.complex128))
+
+
+def test_comm_requires_a_full_id():
+    sweep = importlib.import_module("qilaplace_jl_amd.sweep")
+    with pytest.raises(ValueError, match="128 bytes"):
+        sweep.Comm(None, 0, 1, b"short")
