@@ -467,7 +467,8 @@ def spawn_ranks(n):
 class Ranks:
     """RANK / WORLD_SIZE from the launcher's environment; torch.distributed over RCCL when there is more than one.
     QIL_BENCH_FORCE_DIST=1 exercises the collective code path at N=1; QIL_BENCH_BACKEND=gloo (+ every rank on device 0)
-    lets a 1-GPU box run the N-rank logic end to end."""
+    lets a 1-GPU box run the N-rank logic end to end; QIL_BENCH_BACKEND=cabi runs barrier, max-over-ranks and the gather through the
+    library's own RCCL communicator (qil_comm_* / qil_gather_coefficients: what a Julia host uses) with no torch in the process."""
 
     def __init__(self, gpus):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -475,9 +476,11 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.backend = os.environ.get("QIL_BENCH_BACKEND", "nccl")
+        self.comm = None                 # QIL_BENCH_BACKEND=cabi: the C ABI's own RCCL communicator (qil_comm_*), no torch at all
+        self.want_comm = self.backend == "cabi" and (self.world > 1 or os.environ.get("QIL_BENCH_FORCE_DIST") == "1")
         if self.backend == "gloo":
             self.local_rank = 0
-        if self.world > 1 or os.environ.get("QIL_BENCH_FORCE_DIST") == "1":
+        if self.backend != "cabi" and (self.world > 1 or os.environ.get("QIL_BENCH_FORCE_DIST") == "1"):
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -493,9 +496,24 @@ class Ranks:
         if self.world != gpus and os.environ.get("QIL_BENCH_FORCE_DIST") != "1":
             sys.exit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={self.world} ranks")
 
+    def attach(self, qil, ctx):
+        """QIL_BENCH_BACKEND=cabi: create the library's communicator on the rank's context (collective; file rendezvous keyed by
+        MASTER_PORT and the launcher's pid, sweep.Comm.from_env)."""
+        if self.want_comm and self.comm is None:
+            self.comm = qil.Comm.from_env(ctx)
+            self.world = self.comm.world
+
+    def _gather_scalars(self, values):
+        n = len(values)
+        out = self.comm.gather_coefficients({self.rank: np.asarray(values, dtype=np.complex128)}, self.world, n)
+        return out.real                                  # (world, n)
+
     @property
     def backend_used(self):
-        """"nccl" (= RCCL on ROCm) / "gloo" when a process group is up, None for a bare single process."""
+        """"nccl" (= RCCL on ROCm via torch.distributed) / "gloo" when a process group is up, "rccl-cabi" for the library's own
+        communicator, None for a bare single process."""
+        if self.comm is not None:
+            return "rccl-cabi"
         return self.backend if self.dist is not None else None
 
     @property
@@ -504,6 +522,8 @@ class Ranks:
 
     def barrier(self, ctx):
         ctx.synchronize()
+        if self.comm is not None:
+            self._gather_scalars([0.0])                  # an all-gather of one value per rank is a barrier
         if self.dist is not None:
             import torch
             self.dist.barrier()
@@ -511,6 +531,8 @@ class Ranks:
                 torch.cuda.synchronize()
 
     def max_over_ranks(self, values):
+        if self.comm is not None:
+            return [float(v) for v in self._gather_scalars(values).max(axis=0)]
         if self.dist is None:
             return list(values)
         import torch
@@ -519,6 +541,8 @@ class Ranks:
         return [float(v) for v in t]
 
     def finish(self):
+        if self.comm is not None:
+            self.comm.close()
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
@@ -538,6 +562,7 @@ def run_apply(args, rk):
     import qilaplace_jl_amd as qil
     ctx = qil.Context(rk.local_rank)
     qil.set_default_context(ctx)
+    rk.attach(qil, ctx)
     rank, world = rk.rank, rk.world
     L, paired, chi, D, desc = WORKLOADS[args.workload]
     cb, db = profiles(L, chi, D)
@@ -589,6 +614,8 @@ def run_apply(args, rk):
         ph = O.SignalMPS(psi.to_host(), amplitude=psi.amplitude)
         c_ref = O.lazy_coefficient_batch(Wh, ph, bits)
         err_oracle = float(np.abs(c_mat - c_ref).max() / max(np.abs(c_ref).max(), 1e-300))
+    if rk.comm is not None:                               # the one data collective, through the C ABI (qil_gather_coefficients)
+        rk.comm.gather_coefficients({rank: c_mat}, world, len(c_mat))
     if rk.dist is not None:
         import torch
         mine = torch.tensor(np.stack([c_mat.real, c_mat.imag], -1), device=rk.device)
@@ -665,9 +692,10 @@ def run_sweep(args, rk):
     # small k, log-uniform j: the closed form x_j exp(-sigma k j / N) is NOT negligible on >= 64 % of the samples of every
     # damping value (uniformly random bits make all of them underflow to 0.0 at n = 24)
     bits, kk, jj = qil.damping_sample_bits(n, nsamp, seed=7)
-    forced = rk.dist is not None and rk.world == 1              # QIL_BENCH_FORCE_DIST=1: the collective path in a world of one
-    dist = rk.dist if (rk.world > 1 or forced) else None
-    dev = rk.device if dist is not None and rk.backend == "nccl" else None
+    rk.attach(qil, ctx)
+    forced = (rk.dist is not None or rk.comm is not None) and rk.world == 1      # QIL_BENCH_FORCE_DIST=1: the collective path in a world of one
+    dist = (rk.comm or rk.dist) if (rk.world > 1 or forced) else None
+    dev = rk.device if rk.dist is not None and dist is rk.dist and rk.backend == "nccl" else None
     res = None
     for _ in range(args.warmup):
         res = qil.damping_sweep(psi, sig, bits, dist=dist, device=dev, always_gather=forced)
