@@ -305,6 +305,7 @@ struct gemm_batch {
     const uint8_t* b_sel = nullptr;
     long long b_sel_step = 0, b_sel_stride = 0;
     int subtract = 0;                   // 1: C <- C - op(A) op(B)  (the projection step of the blocked QR, no temporary)
+    int skinny_m = 0;                   // 1: the caller knows op(A) has <= 32 rows and a long n: 32 x 128 output tiles
 };
 
 template <class T, int BM, int BN, int WM, int WN, bool PIPE, int GKT = GK>
@@ -388,6 +389,9 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
     // idle is bound by the K loop of ONE tile on its CU (32 MFMAs per wave and 32-deep K step at 64 x 64, 8 at 32 x 32)
     // (measured, up to 0 / 16 / 32 / 64 tiles of 64 x 64 as 32 x 32 tiles: compress! chi 256 f64 49.5 / 46.2 / 45.6 / 46.1 ms, c64 66.2 /
     // 61.5 / 59.6 / 61.0, chi 512 f64 122.3 / 118.0 / 115.7 / 114.5, c64 165.9 / 151.8 / 148.1 / 142.6, fused apply-and-truncate 147 / 131 / 128 / 129)
+    // skinny op(A) (the halves of a bit-sorted coefficient read-out: ~32 queries x 8192 columns x 8192 deep): same MFMA count
+    // per wave and K tile as the 64 x 64 tile (1 x 4 instead of 2 x 2 fragments), half the padded rows
+    if (batch.skinny_m && m <= 32 && n >= 128) return gemm_launch<T, 32, 128, 16, 64, true>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch);
     constexpr long long small_tiles = 64;
     // (K step of the small tiles 16 / 32 / 64: compress! chi 256 46.5 / 45.3 / 45.2 ms, chi 512 115.1 / 111.7 / 112.1, exact route 300 / 293 / 294)
     if (((m + 63) / 64) * ((n + 63) / 64) * batch.count <= small_tiles && m >= 32 && n >= 32)
@@ -2728,6 +2732,48 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
     return QIL_OK;
 }
 
+// ------------------------------------------------------------------ all sweeps of a mid-size SVD in ONE launch (r05 experiment)
+// the chains wait on ~1 500 (chi 256) to ~10 000 (exact route) back-to-back round launches of 9-16 us.  The
+// persistent form runs every round of every sweep of one SVD inside one launch of nblk / 2 (<= 32) co-resident workgroups with a
+// device-scope barrier between rounds, and takes the convergence decision on the device (no read-back per sweep).  The round
+// bodies are the per-round kernels' own device functions: same arithmetic, same order.  Used only outside lock-step batches
+// (a table launch of 16 operands x 20 workgroups could exceed the CUs, and a spinning grid that is not fully resident never
+// finishes).
+__device__ __forceinline__ void qil_grid_barrier(unsigned* bar, unsigned nwg) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_thread_fence(__ATOMIC_RELEASE);                          // this workgroup's stores, device-wide
+        if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+}
+
+template <class T, int BB, int KM, int G>
+__global__ __launch_bounds__(BB* G) void nov_sweeps_persistent(T* A, long long lda, int m, int n, int nb, double tol, int* dflag,
+                                                               const double* negligible, int max_sweeps, unsigned* bar, int* done) {
+    const uint3 b{blockIdx.x, 0, 0}, g{gridDim.x, 1, 1};
+    int sw = 0;
+    for (; sw < max_sweeps; ++sw) {
+        for (int round = 0; round < nb - 1; ++round) {
+            if (round == 0) jacobi_block_round_nov_body<T, BB, KM, G, true>(b, g, A, lda, m, n, nb, round, tol, dflag + 2 * sw, negligible);
+            else jacobi_block_round_nov_body<T, BB, KM, G, false>(b, g, A, lda, m, n, nb, round, tol, dflag + 2 * sw, negligible);
+            qil_grid_barrier(bar, gridDim.x);
+        }
+        if (!__hip_atomic_load(&dflag[2 * sw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            ++sw;
+            break;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *done = sw;
+}
+
 // ------------------------------------------------------------------ Gram-matrix block round on the matrix cores
 // One outer round of the same block tournament, but a block pair is orthogonalised through its Gram matrix instead of column by
 // column (the rotation work of the truncate half on v_mfma_f64_16x16x4_f64):
@@ -3138,6 +3184,26 @@ int launch_gram_round(qil_context* ctx, T* X, long long ldx, int k, int nblk, in
     return qil_klaunch<gram_block_round_k<T, BB, false>>(ctx, dim3(nblk / 2), dim3(512), lds, a);
 }
 
+template <class T, int BB>
+__global__ __launch_bounds__(512) void gram_sweeps_persistent(gram_round_args<T> a, int* dflag, int max_sweeps, unsigned* bar, int* done) {
+    int sw = 0;
+    for (; sw < max_sweeps; ++sw) {
+        a.flag = dflag + 2 * sw;
+        a.prev = nullptr;
+        for (int round = 0; round < a.nb - 1; ++round) {
+            a.round = round;
+            if (round == 0) gram_block_round_body<T, BB, true>(a, blockIdx.x);
+            else gram_block_round_body<T, BB, false>(a, blockIdx.x);
+            qil_grid_barrier(bar, gridDim.x);
+        }
+        if (!__hip_atomic_load(&dflag[2 * sw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            ++sw;
+            break;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *done = sw;
+}
+
 // B (p x q, ldb; destroyed) = Uiso diag(S) V^H:  Uiso (p x k, k = min(p, q)) orthonormal columns sorted by descending
 // singular value, S on the host, SVh (k x q) = diag(S) V^H.  Serves 97 <= k < 640 (and smaller k whose general path would not be LDS-resident) with the columns in LDS;
 // *handled = 0 (nothing touched beyond B's contents being intact) sends the caller to the general svd_impl.
@@ -3539,7 +3605,68 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         return QIL_OK;
     };
     bool gram_done = false;
-    if constexpr (sizeof(T) == 8) if (gbb) {                     // (no complex instantiation of the Gram-round kernels: r05)
+    // r05 experiment (stop rule): every round of every sweep in ONE launch, device-scope barrier between rounds
+    static const bool persist = getenv("QIL_SVD_PERSIST") && atoi(getenv("QIL_SVD_PERSIST")) != 0;
+    if (persist && !ctx->lockstep && nblk / 2 <= 32 && nblk >= 2) {
+        constexpr int MAXS = 40;
+        int* dflag = static_cast<int*>(flag);                    // [MAXS][2] flags, 2 barrier words, sweeps done
+        QIL_TRY(qil_dev_zero(ctx, dflag, 512));
+        unsigned* bar = reinterpret_cast<unsigned*>(dflag + 2 * MAXS);
+        int* done = dflag + 2 * MAXS + 2;
+        bool launched = false;
+        if constexpr (sizeof(T) == 8) {
+            if (gbb) {
+                gram_round_args<T> a{X, k, (int)k, (int)k, nblk, 0, tol, dflag, nullptr, (const double*)negl, nullptr};
+                if (gbb == 16) {
+                    static qil_lds_grant grant;
+                    const size_t lds = gram_round_lds<T, 16>((int)k);
+                    QIL_HIP(grant.ensure(ctx->device, reinterpret_cast<const void*>(&gram_sweeps_persistent<T, 16>), lds));
+                    hipLaunchKernelGGL((gram_sweeps_persistent<T, 16>), dim3(nblk / 2), dim3(512), lds, qil_stream(ctx), a, dflag, MAXS, bar, done);
+                } else {
+                    static qil_lds_grant grant;
+                    const size_t lds = gram_round_lds<T, 8>((int)k);
+                    QIL_HIP(grant.ensure(ctx->device, reinterpret_cast<const void*>(&gram_sweeps_persistent<T, 8>), lds));
+                    hipLaunchKernelGGL((gram_sweeps_persistent<T, 8>), dim3(nblk / 2), dim3(512), lds, qil_stream(ctx), a, dflag, MAXS, bar, done);
+                }
+                launched = true;
+            }
+        }
+        if (!launched) {
+#define QIL_NOVP(KMv)                                                                                                                 \
+    {                                                                                                                                 \
+        static qil_lds_grant grant;                                                                                                   \
+        constexpr size_t lds = block_round_nov_lds<T, 8, KMv, 64>();                                                                  \
+        QIL_HIP(grant.ensure(ctx->device, reinterpret_cast<const void*>(&nov_sweeps_persistent<T, 8, KMv, 64>), lds));               \
+        hipLaunchKernelGGL((nov_sweeps_persistent<T, 8, KMv, 64>), dim3(nblk / 2), dim3(8 * 64), lds, qil_stream(ctx), X, k, (int)k, \
+                           (int)k, nblk, tol, dflag, (const double*)negl, MAXS, bar, done);                                           \
+        launched = true;                                                                                                              \
+    }
+            switch (km) {
+                case 1: QIL_NOVP(1) break;
+                case 2: QIL_NOVP(2) break;
+                case 3: QIL_NOVP(3) break;
+                case 4: QIL_NOVP(4) break;
+                case 5: QIL_NOVP(5) break;
+                case 6: QIL_NOVP(6) break;
+                case 7: QIL_NOVP(7) break;
+                case 8: QIL_NOVP(8) break;
+                case 9: QIL_NOVP(9) break;
+                default:
+                    if constexpr (sizeof(T) == 8) QIL_NOVP(10)
+                    break;
+            }
+#undef QIL_NOVP
+        }
+        if (launched) {
+            QIL_HIP(hipGetLastError());
+            int hdone = 0;
+            QIL_TRY(qil_read_back(ctx, &hdone, done, sizeof(int)));
+            sweeps = hdone;
+            if (dbg) fprintf(stderr, "[svd-left] persistent sweeps (%lld cols, blocks of %d, %d workgroups): %d sweeps\n", k, bb, nblk / 2, sweeps);
+            gram_done = true;                                    // (skips both per-round loops below)
+        }
+    }
+    if constexpr (sizeof(T) == 8) if (gbb && !gram_done) {        // (no complex instantiation of the Gram-round kernels: r05)
         gram_done = true;
         // Gram-matrix block rounds on the matrix cores.  The host stays ONE SWEEP AHEAD of its read-backs: sweep s + 1 is
         // enqueued before the flags of sweep s have come back, each of its launches first looks at those flags on the device
@@ -4333,6 +4460,17 @@ int qil_dev_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64
     static const int real_op[4] = {0, 1, 1, 0};
     return gemm_dispatch<double>(ctx, real_op[opA & 3], real_op[opB & 3], m, n, k, (const double*)A, lda,
                                  (const double*)B, ldb, (double*)C, ldc);
+}
+
+int qil_dev_gemm_skinny(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+                        const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc) {
+    gemm_batch bt;
+    bt.skinny_m = 1;
+    if (dtype == QIL_C64)
+        return gemm_dispatch<c64>(ctx, opA, opB, m, n, k, (const c64*)A, lda, (const c64*)B, ldb, (c64*)C, ldc, bt);
+    static const int real_op[4] = {0, 1, 1, 0};
+    return gemm_dispatch<double>(ctx, real_op[opA & 3], real_op[opB & 3], m, n, k, (const double*)A, lda,
+                                 (const double*)B, ldb, (double*)C, ldc, bt);
 }
 
 // C = opA(A) * opB(B) on host operands (column-major): utility / test hook for the MFMA GEMM

@@ -209,6 +209,25 @@ struct select_slice_k {
         select_slice_body<T>(b, g, a...);
     }
 };
+// Bit-sorted read-out: rows of Tm are in site i's order (queries with bit 0 first), the next site wants its own order:
+// Vn[r + nb * beta] = Tm[map[r] + nb * beta]
+template <class T>
+__device__ __forceinline__ void gather_rows_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ Tm, long long nb, int cr,
+                                                 const int* __restrict__ map, T* __restrict__ Vn) {
+    const long long total = nb * cr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long r = t % nb, beta = t / nb;
+        Vn[t] = Tm[map[r] + nb * beta];
+    }
+}
+template <class T>
+struct gather_rows_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        gather_rows_body<T>(b, g, a...);
+    }
+};
 template <class T>
 __device__ __forceinline__ void fill_ones_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ v, long long n) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) v[t] = one_t(T{});
@@ -432,7 +451,59 @@ extern "C" int qil_coefficient_marginal_batch(const qil_mps* psi, int64_t nb, co
 
 // Enqueue the read-out of nb configurations (device bits) of psi into dout (nb complex, device); no
 // synchronisation, every temporary goes back to the pool in stream order.
-static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* dbits, void* dout) {
+// Plan of the bit-sorted GEMM read-out (built on the host from the caller's bits, shared by every chain read at the same
+// configurations): before site i the query vectors are stored in order_i = queries with bit_i = 0 first (stable), so the site
+// costs two products with ONE slice each -- n0[i] x chi_l by chi_l x chi_r and (nb - n0[i]) x chi_l by chi_l x chi_r -- instead
+// of one nb x chi_l by chi_l x 2 chi_r product that computes both slices for every query and throws half away.  map[i][r] = row
+// of site i's result that becomes row r of site i + 1's operand (the last map restores the caller's order).
+struct SortPlan {
+    int* dmap = nullptr;                 // [n][nb], device
+    std::vector<int64_t> n0;             // per site: queries with bit 0
+};
+static int build_sort_plan(qil_context* ctx, int64_t nb, int64_t n, const uint8_t* bits, SortPlan* plan) {
+    std::vector<int> map((size_t)(n * nb)), order((size_t)nb), next((size_t)nb), pos((size_t)nb);
+    plan->n0.assign((size_t)n, 0);
+    auto order_of = [&](int64_t site, std::vector<int>& o) -> int64_t {
+        int64_t z = 0;
+        if (site >= n) {
+            for (int64_t q = 0; q < nb; ++q) o[(size_t)q] = (int)q;
+            return nb;
+        }
+        for (int64_t q = 0; q < nb; ++q)
+            if (bits[q * n + site] == 0) o[(size_t)z++] = (int)q;
+        int64_t w = z;
+        for (int64_t q = 0; q < nb; ++q)
+            if (bits[q * n + site] != 0) o[(size_t)w++] = (int)q;
+        return z;
+    };
+    plan->n0[0] = order_of(0, order);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int64_t r = 0; r < nb; ++r) pos[(size_t)order[(size_t)r]] = (int)r;
+        const int64_t z = order_of(i + 1, next);
+        if (i + 1 < n) plan->n0[(size_t)i + 1] = z;
+        for (int64_t r = 0; r < nb; ++r) map[(size_t)(i * nb + r)] = pos[(size_t)next[(size_t)r]];
+        order.swap(next);
+    }
+    void* p = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, map.size() * sizeof(int), &p));
+    hipError_t e = hipMemcpyAsync(p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice, qil_stream(ctx));
+    if (e == hipSuccess) e = qil_stream_sync(ctx);         // `map` is a local
+    if (e != hipSuccess) {
+        qil_ctx_free(ctx, p);
+        return qil_fail(QIL_EHIP, "read-out plan upload failed: %s", hipGetErrorString(e));
+    }
+    plan->dmap = static_cast<int*>(p);
+    return QIL_OK;
+}
+// queries x bonds from which the sorted GEMM form is taken (same crossover as the GEMM form itself)
+static bool wants_sort_plan(const qil_mps* psi, int64_t nb, int max_bit) {
+    if (max_bit > 1 || nb < 4) return false;                 // a marginal (bit 2) needs both slices of its site
+    long long maxchi = 1;
+    for (int64_t i = 0; i < psi->n(); ++i) maxchi = std::max<long long>(maxchi, psi->dims[(size_t)i + 1]);
+    return maxchi >= 128 || (nb >= 1024 && maxchi >= 16);
+}
+
+static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* dbits, void* dout, const SortPlan* plan = nullptr) {
     qil_context* ctx = psi->ctx;
     const int64_t n = psi->n();
     std::vector<ChainSite> tab((size_t)n);
@@ -463,8 +534,27 @@ static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* db
         else QIL_TRY((qil_klaunch<fill_ones_k<double>>(ctx, dim3(g1), dim3(256), 0, (double*)V, (long long)nb)));
         for (int64_t i = 0; i < n; ++i) {
             const int64_t cl = psi->dims[(size_t)i], cr = psi->dims[(size_t)i + 1];
-            QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 0, 0, nb, 2 * cr, cl, V, nb, psi->site[(size_t)i], cl, Tm, nb));
             const unsigned g = (unsigned)std::min<long long>((nb * cr + 255) / 256, 65536);
+            if (plan && plan->dmap) {
+                // bit-sorted: rows [0, n0) take slice 0, rows [n0, nb) slice 1 (slice s of A[alpha, s, beta]: offset s chi_l, ld 2 chi_l)
+                const int64_t z = plan->n0[(size_t)i];
+                const char* site = static_cast<const char*>(psi->site[(size_t)i]);
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int64_t r0 = sl ? z : 0, rows = sl ? nb - z : z;
+                    if (rows == 0) continue;
+                    const void* Vs = static_cast<const char*>(V) + (size_t)r0 * esz;
+                    void* Ts = static_cast<char*>(Tm) + (size_t)r0 * esz;
+                    const void* As = site + (size_t)(sl * cl) * esz;
+                    if (rows <= 32) QIL_TRY(qil_dev_gemm_skinny(ctx, psi->dtype, 0, 0, rows, cr, cl, Vs, nb, As, 2 * cl, Ts, nb));
+                    else QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 0, 0, rows, cr, cl, Vs, nb, As, 2 * cl, Ts, nb));
+                }
+                const int* map = plan->dmap + (size_t)(i * nb);
+                if (cx) QIL_TRY((qil_klaunch<gather_rows_k<c64>>(ctx, dim3(g), dim3(256), 0, (const c64*)Tm, (long long)nb, (int)cr, map, (c64*)Vn)));
+                else QIL_TRY((qil_klaunch<gather_rows_k<double>>(ctx, dim3(g), dim3(256), 0, (const double*)Tm, (long long)nb, (int)cr, map, (double*)Vn)));
+                std::swap(V, Vn);
+                continue;
+            }
+            QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 0, 0, nb, 2 * cr, cl, V, nb, psi->site[(size_t)i], cl, Tm, nb));
             if (cx)
                 QIL_TRY((qil_klaunch<select_slice_k<c64>>(ctx, dim3(g), dim3(256), 0, (const c64*)Tm, (long long)nb, (int)cr,
                                                           (const uint8_t*)dbits, (int)n, (int)i, (c64*)Vn)));
@@ -508,9 +598,12 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
     qil_call_scope call_scope(ctx);
     uint8_t* dbits = nullptr;
     QIL_TRY(upload_bits(ctx, nb, psi->n(), bits, &dbits, max_bit));
+    SortPlan plan;
+    if (wants_sort_plan(psi, nb, max_bit)) QIL_TRY(build_sort_plan(ctx, nb, psi->n(), bits, &plan));
     void* dout = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)nb * 16, &dout));
-    QIL_TRY(coefficient_enqueue(psi, nb, dbits, dout));
+    QIL_TRY(coefficient_enqueue(psi, nb, dbits, dout, &plan));
+    if (plan.dmap) qil_ctx_free(ctx, plan.dmap);
     QIL_HIP(hipMemcpyAsync(out, dout, (size_t)nb * 16, hipMemcpyDeviceToHost, qil_stream(ctx)));
     QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, dout);
@@ -532,6 +625,8 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
     qil_call_scope call_scope(ctx);
     uint8_t* dbits = nullptr;
     QIL_TRY(upload_bits(ctx, nb, psi->n(), bits, &dbits, 1));
+    SortPlan plan;                                        // one plan for every operator's read-out (same configurations)
+    if (nb >= 4) QIL_TRY(build_sort_plan(ctx, nb, psi->n(), bits, &plan));
     void* dout = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nw * nb) * 16, &dout));
     bool distinct = true;                                 // operators change context for the batch: each must be its own handle
@@ -546,7 +641,7 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
     auto one = [&](const qil_mpo* W, const qil_mps* state, int64_t j) {
         qil_mps* prod = nullptr;
         QIL_TRY(qil_apply_shared_state(W, state, &prod));
-        const int st = coefficient_enqueue(prod, nb, dbits, static_cast<char*>(dout) + (size_t)(j * nb) * 16);
+        const int st = coefficient_enqueue(prod, nb, dbits, static_cast<char*>(dout) + (size_t)(j * nb) * 16, &plan);
         qil_mps_destroy(prod);
         return st;
     };
@@ -566,6 +661,7 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
     QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, dout);
     qil_ctx_free(ctx, dbits);
+    if (plan.dmap) qil_ctx_free(ctx, plan.dmap);
     return QIL_OK;
 }
 
