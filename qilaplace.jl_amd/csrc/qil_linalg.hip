@@ -2732,48 +2732,6 @@ int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nbl
     return QIL_OK;
 }
 
-// ------------------------------------------------------------------ all sweeps of a mid-size SVD in ONE launch (r05 experiment)
-// the chains wait on ~1 500 (chi 256) to ~10 000 (exact route) back-to-back round launches of 9-16 us.  The
-// persistent form runs every round of every sweep of one SVD inside one launch of nblk / 2 (<= 32) co-resident workgroups with a
-// device-scope barrier between rounds, and takes the convergence decision on the device (no read-back per sweep).  The round
-// bodies are the per-round kernels' own device functions: same arithmetic, same order.  Used only outside lock-step batches
-// (a table launch of 16 operands x 20 workgroups could exceed the CUs, and a spinning grid that is not fully resident never
-// finishes).
-__device__ __forceinline__ void qil_grid_barrier(unsigned* bar, unsigned nwg) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __atomic_thread_fence(__ATOMIC_RELEASE);                          // this workgroup's stores, device-wide
-        if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
-            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
-    __syncthreads();
-}
-
-template <class T, int BB, int KM, int G>
-__global__ __launch_bounds__(BB* G) void nov_sweeps_persistent(T* A, long long lda, int m, int n, int nb, double tol, int* dflag,
-                                                               const double* negligible, int max_sweeps, unsigned* bar, int* done) {
-    const uint3 b{blockIdx.x, 0, 0}, g{gridDim.x, 1, 1};
-    int sw = 0;
-    for (; sw < max_sweeps; ++sw) {
-        for (int round = 0; round < nb - 1; ++round) {
-            if (round == 0) jacobi_block_round_nov_body<T, BB, KM, G, true>(b, g, A, lda, m, n, nb, round, tol, dflag + 2 * sw, negligible);
-            else jacobi_block_round_nov_body<T, BB, KM, G, false>(b, g, A, lda, m, n, nb, round, tol, dflag + 2 * sw, negligible);
-            qil_grid_barrier(bar, gridDim.x);
-        }
-        if (!__hip_atomic_load(&dflag[2 * sw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            ++sw;
-            break;
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *done = sw;
-}
-
 // ------------------------------------------------------------------ Gram-matrix block round on the matrix cores
 // One outer round of the same block tournament, but a block pair is orthogonalised through its Gram matrix instead of column by
 // column (the rotation work of the truncate half on v_mfma_f64_16x16x4_f64):
@@ -3184,25 +3142,6 @@ int launch_gram_round(qil_context* ctx, T* X, long long ldx, int k, int nblk, in
     return qil_klaunch<gram_block_round_k<T, BB, false>>(ctx, dim3(nblk / 2), dim3(512), lds, a);
 }
 
-template <class T, int BB>
-__global__ __launch_bounds__(512) void gram_sweeps_persistent(gram_round_args<T> a, int* dflag, int max_sweeps, unsigned* bar, int* done) {
-    int sw = 0;
-    for (; sw < max_sweeps; ++sw) {
-        a.flag = dflag + 2 * sw;
-        a.prev = nullptr;
-        for (int round = 0; round < a.nb - 1; ++round) {
-            a.round = round;
-            if (round == 0) gram_block_round_body<T, BB, true>(a, blockIdx.x);
-            else gram_block_round_body<T, BB, false>(a, blockIdx.x);
-            qil_grid_barrier(bar, gridDim.x);
-        }
-        if (!__hip_atomic_load(&dflag[2 * sw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            ++sw;
-            break;
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *done = sw;
-}
 
 // B (p x q, ldb; destroyed) = Uiso diag(S) V^H:  Uiso (p x k, k = min(p, q)) orthonormal columns sorted by descending
 // singular value, S on the host, SVh (k x q) = diag(S) V^H.  Serves 97 <= k < 640 (and smaller k whose general path would not be LDS-resident) with the columns in LDS;
@@ -3605,68 +3544,12 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         return QIL_OK;
     };
     bool gram_done = false;
-    // r05 experiment (stop rule): every round of every sweep in ONE launch, device-scope barrier between rounds
-    static const bool persist = getenv("QIL_SVD_PERSIST") && atoi(getenv("QIL_SVD_PERSIST")) != 0;
-    if (persist && !ctx->lockstep && nblk / 2 <= 32 && nblk >= 2) {
-        constexpr int MAXS = 40;
-        int* dflag = static_cast<int*>(flag);                    // [MAXS][2] flags, 2 barrier words, sweeps done
-        QIL_TRY(qil_dev_zero(ctx, dflag, 512));
-        unsigned* bar = reinterpret_cast<unsigned*>(dflag + 2 * MAXS);
-        int* done = dflag + 2 * MAXS + 2;
-        bool launched = false;
-        if constexpr (sizeof(T) == 8) {
-            if (gbb) {
-                gram_round_args<T> a{X, k, (int)k, (int)k, nblk, 0, tol, dflag, nullptr, (const double*)negl, nullptr};
-                if (gbb == 16) {
-                    static qil_lds_grant grant;
-                    const size_t lds = gram_round_lds<T, 16>((int)k);
-                    QIL_HIP(grant.ensure(ctx->device, reinterpret_cast<const void*>(&gram_sweeps_persistent<T, 16>), lds));
-                    hipLaunchKernelGGL((gram_sweeps_persistent<T, 16>), dim3(nblk / 2), dim3(512), lds, qil_stream(ctx), a, dflag, MAXS, bar, done);
-                } else {
-                    static qil_lds_grant grant;
-                    const size_t lds = gram_round_lds<T, 8>((int)k);
-                    QIL_HIP(grant.ensure(ctx->device, reinterpret_cast<const void*>(&gram_sweeps_persistent<T, 8>), lds));
-                    hipLaunchKernelGGL((gram_sweeps_persistent<T, 8>), dim3(nblk / 2), dim3(512), lds, qil_stream(ctx), a, dflag, MAXS, bar, done);
-                }
-                launched = true;
-            }
-        }
-        if (!launched) {
-#define QIL_NOVP(KMv)                                                                                                                 \
-    {                                                                                                                                 \
-        static qil_lds_grant grant;                                                                                                   \
-        constexpr size_t lds = block_round_nov_lds<T, 8, KMv, 64>();                                                                  \
-        QIL_HIP(grant.ensure(ctx->device, reinterpret_cast<const void*>(&nov_sweeps_persistent<T, 8, KMv, 64>), lds));               \
-        hipLaunchKernelGGL((nov_sweeps_persistent<T, 8, KMv, 64>), dim3(nblk / 2), dim3(8 * 64), lds, qil_stream(ctx), X, k, (int)k, \
-                           (int)k, nblk, tol, dflag, (const double*)negl, MAXS, bar, done);                                           \
-        launched = true;                                                                                                              \
-    }
-            switch (km) {
-                case 1: QIL_NOVP(1) break;
-                case 2: QIL_NOVP(2) break;
-                case 3: QIL_NOVP(3) break;
-                case 4: QIL_NOVP(4) break;
-                case 5: QIL_NOVP(5) break;
-                case 6: QIL_NOVP(6) break;
-                case 7: QIL_NOVP(7) break;
-                case 8: QIL_NOVP(8) break;
-                case 9: QIL_NOVP(9) break;
-                default:
-                    if constexpr (sizeof(T) == 8) QIL_NOVP(10)
-                    break;
-            }
-#undef QIL_NOVP
-        }
-        if (launched) {
-            QIL_HIP(hipGetLastError());
-            int hdone = 0;
-            QIL_TRY(qil_read_back(ctx, &hdone, done, sizeof(int)));
-            sweeps = hdone;
-            if (dbg) fprintf(stderr, "[svd-left] persistent sweeps (%lld cols, blocks of %d, %d workgroups): %d sweeps\n", k, bb, nblk / 2, sweeps);
-            gram_done = true;                                    // (skips both per-round loops below)
-        }
-    }
-    if constexpr (sizeof(T) == 8) if (gbb && !gram_done) {        // (no complex instantiation of the Gram-round kernels: r05)
+    // (r05 built the persistent form -- every round of every sweep of one SVD in ONE launch of nblk / 2 co-resident workgroups, a
+    // device-scope barrier between rounds, the convergence decision on the device -- and measured it against these per-round
+    // launches: chi 256 -> 128 45.0 -> 43.6 ms, chi 512 -> 256 110.7 -> 119.1 ms, exact compress!(apply) 281 -> 272 ms with the kernel
+    // time of its complex rounds UP 19 %: a barrier through L2 costs what a dispatch costs.  Removed again, VERDICT r04 item 3's
+    // stop rule; code in commit 674496a, evidence profiles/r05_persist_{compare,trace}.txt.)
+    if constexpr (sizeof(T) == 8) if (gbb) {                     // (no complex instantiation of the Gram-round kernels: r05)
         gram_done = true;
         // Gram-matrix block rounds on the matrix cores.  The host stays ONE SWEEP AHEAD of its read-backs: sweep s + 1 is
         // enqueued before the flags of sweep s have come back, each of its launches first looks at those flags on the device
