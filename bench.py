@@ -729,6 +729,7 @@ def run_sweep(args, rk):
         tb.append(time.perf_counter() - t0)
         del Wb
     t_build = min(tb)
+    by_values = bench_configs.builder_launch_by_values(qil, ctx, psi, (8, nsig, 4 * nsig)) if rk.world == 1 else None
     cpu = None
     if rk.world == 1 and not args.no_cpu_baseline:
         # the reference-shaped CPU path beside the figure -- build_dt_mpo (numpy restatement of
@@ -779,7 +780,9 @@ def run_sweep(args, rk):
         "bound_by": {"kernel": "dt_build_persistent (one launch per sweep, one workgroup per damping value)",
                      "ms": t_build * 1e3, "frac_of_step": t_build / (elapsed / args.steps),
                      "kind": "latency chain: zip QR + gauge QR + truncating Jacobi SVD per site and layer, all in LDS",
-                     "workgroups": len(share), "cu_share": len(share) / 256.0},
+                     "workgroups": len(share), "cu_share": len(share) / 256.0,
+                     # one launch of 8 / 64 / 256 values -- the launch is as long as its slowest chain up to one value per CU
+                     "builder_launch_ms_by_values": by_values},
         "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<double,double> (the sweep's apply launches; the step is "
                      "dominated by the latency-bound dt_build_persistent chain, see bound_by and DESIGN.md 3.6)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

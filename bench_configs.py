@@ -171,6 +171,24 @@ def cfg4_errors(res, x, sig, kk, jj, n):
     return err, shares, peak
 
 
+def builder_launch_by_values(qil, ctx, psi, counts, lo=0.25, hi=16.0):
+    """Wall ms (synchronised, min of 2) of ONE build_dt_mpo_batch of `c` damping values in linspace(lo, hi, c), per count."""
+    out = {}
+    for c in counts:
+        sig = np.linspace(lo, hi, int(c))
+        best = None
+        for _ in range(2):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            Wb = qil.build_dt_mpo_batch(psi, sig)
+            ctx.synchronize()
+            dt_ = time.perf_counter() - t0
+            del Wb
+            best = dt_ if best is None else min(best, dt_)
+        out[str(int(c))] = best * 1e3
+    return out
+
+
 def cfg4_entry(qil, ctx, n=24, nsig=64, nsamp=1024, steps=3):
     x = cfg4_signal(n)
     psi = qil.signal_ztmps(x, method="rsvd", k=15, p=5, q=2, cutoff=1e-12)
@@ -193,11 +211,15 @@ def cfg4_entry(qil, ctx, n=24, nsig=64, nsamp=1024, steps=3):
         mpo_bond = int(max(max(W.bond_dims) for W in Wb))
         del Wb
     err, shares, _ = cfg4_errors(res, x, sig, kk, jj, n)
+    by_values = builder_launch_by_values(qil, ctx, psi, (8, nsig, 4 * nsig))
     return {"workload": f"dt_sweep_n{n}_s{nsig}", "damping_values": nsig, "samples_per_value": nsamp, "steps": steps,
             "ms_per_sweep": wall * 1e3, "site_contractions_per_s": nsig * 2 * n / wall, "mps_bonds_max": int(max(psi.bond_dims)),
             "mpo_bonds_max": mpo_bond,
             "bound_by": {"kernel": "DT builder launch (latency chain of in-LDS factorisations per damping value)",
-                         "ms": min(tb) * 1e3, "frac_of_step": min(tb) / wall},
+                         "ms": min(tb) * 1e3, "frac_of_step": min(tb) / wall,
+                         "builder_launch_ms_by_values": by_values,
+                         "note": "one workgroup per damping value: the launch is as long as its slowest chain whatever the count up to one "
+                                 "value per CU (256), so 4x the values per launch cost the same time -- the unit that scales with GPUs is the value"},
             "max_coeff_err": err, "coeff_err_kind": "vs x_j exp(-sigma k j / N) / sqrt(N), relative to the signal peak, all values x samples",
             "reference_samples_above_1e-6_peak": shares}
 

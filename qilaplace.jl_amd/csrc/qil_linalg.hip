@@ -2507,7 +2507,11 @@ template <class T, int BB, int KM, int G, bool AP, bool PROF = false>
 __device__ __forceinline__ void jacobi_block_round_nov_body(const uint3 blockIdx, const uint3 gridDim, T* __restrict__ A, long long lda, int m, int n, int nb,
                                                                  int round, double tol, int* __restrict__ rotated,
                                                                  const double* __restrict__ negligible,
-                                                                 long long* __restrict__ prof = nullptr) {
+                                                                 long long* __restrict__ prof = nullptr,
+                                                                 const int* __restrict__ prev = nullptr) {
+    // prev: the flags of the PREVIOUS sweep; when that sweep met nothing above the quadratic level the iteration had converged
+    // and this launch (issued speculatively by a host that is one sweep ahead of its read-backs) does nothing
+    if (prev && !prev[1]) return;
     // PROF (tools/micro/jacobi_round_cost.hip only): shader-clock stamps start / staged / rotated / stored + the 100 MHz clock
     long long st[5];
     if (PROF) {
@@ -2722,13 +2726,13 @@ constexpr size_t block_round_nov_lds() {
 
 template <class T, int BB, int KM, int G>
 int launch_block_round_nov(qil_context* ctx, T* X, long long ldx, int k, int nblk, int round, double tol, int* flag,
-                           const double* negl) {
+                           const double* negl, const int* prev) {
     constexpr size_t lds = block_round_nov_lds<T, BB, KM, G>();
     static_assert(lds <= 156 * 1024, "column blocks must fit the LDS");
     if (round == 0)
-        QIL_TRY((qil_klaunch<jacobi_block_round_nov_k<T, BB, KM, G, true>>(ctx, dim3(nblk / 2), dim3(BB * G), lds, X, ldx, k, k, nblk, round, tol, flag, negl)));
+        QIL_TRY((qil_klaunch<jacobi_block_round_nov_k<T, BB, KM, G, true>>(ctx, dim3(nblk / 2), dim3(BB * G), lds, X, ldx, k, k, nblk, round, tol, flag, negl, (long long*)nullptr, prev)));
     else
-        QIL_TRY((qil_klaunch<jacobi_block_round_nov_k<T, BB, KM, G, false>>(ctx, dim3(nblk / 2), dim3(BB * G), lds, X, ldx, k, k, nblk, round, tol, flag, negl)));
+        QIL_TRY((qil_klaunch<jacobi_block_round_nov_k<T, BB, KM, G, false>>(ctx, dim3(nblk / 2), dim3(BB * G), lds, X, ldx, k, k, nblk, round, tol, flag, negl, (long long*)nullptr, prev)));
     return QIL_OK;
 }
 
@@ -3520,9 +3524,9 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
     const int nblk = (int)(((k + bb - 1) / bb + 1) / 2 * 2);
     int sweeps = 0;
     // the rounds of one sweep
-    auto launch_rounds = [&]() -> int {
+    auto launch_rounds = [&](int* fl, const int* prev) -> int {
         for (int round = 0; round < nblk - 1; ++round) {
-#define QIL_NOV(BBv, KMv, Gv) QIL_TRY((launch_block_round_nov<T, BBv, KMv, Gv>(ctx, X, k, (int)k, nblk, round, tol, (int*)flag, (const double*)negl)))
+#define QIL_NOV(BBv, KMv, Gv) QIL_TRY((launch_block_round_nov<T, BBv, KMv, Gv>(ctx, X, k, (int)k, nblk, round, tol, fl, (const double*)negl, prev)))
             {
                 switch (km) {
                     case 1: QIL_NOV(8, 1, 64); break;
@@ -3580,14 +3584,29 @@ int svd_left_mid(qil_context* ctx, long long p, long long q, T* B, long long ldb
         }
         QIL_TRY(st);
     }
-    if (!gram_done)
-    for (; sweeps < 40; ++sweeps) {
-        QIL_TRY(qil_dev_zero(ctx, flag, 2 * sizeof(int)));
-        QIL_TRY(launch_rounds());
-        int hv[2] = {0, 0};
-        QIL_TRY(qil_read_back(ctx, hv, flag, 2 * sizeof(int)));
-        if (dbg) fprintf(stderr, "[svd-left] sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[0], hv[1]);
-        if (!hv[1]) break;
+    if (!gram_done) {
+        // vector rounds (complex operands, f64 ones too tall for the Gram workspace): the host stays one sweep ahead of its
+        // read-backs here too (r05: until then every sweep ended in a host round trip, ~8 per SVD -- the persistent-kernel
+        // experiment's only gain on the exact route was their absence)
+        constexpr int MAXS = 40;
+        int* dflag = static_cast<int*>(flag);                    // [MAXS][2]
+        QIL_TRY(qil_dev_zero(ctx, dflag, (size_t)2 * MAXS * sizeof(int)));
+        uint64_t ticket[2] = {0, 0};
+        auto enqueue = [&](int sw) -> int {
+            QIL_TRY(launch_rounds(dflag + 2 * sw, sw > 0 ? dflag + 2 * (sw - 1) : nullptr));
+            return qil_read_back_post(ctx, dflag + 2 * sw, 2 * sizeof(int), &ticket[sw & 1]);
+        };
+        int st = enqueue(0);
+        for (; st == QIL_OK && sweeps < MAXS; ++sweeps) {
+            if (sweeps + 1 < MAXS) st = enqueue(sweeps + 1);
+            if (st != QIL_OK) break;
+            int hv[2] = {0, 0};
+            st = qil_read_back_wait(ctx, ticket[sweeps & 1], hv, sizeof(hv));
+            if (st != QIL_OK) break;
+            if (dbg) fprintf(stderr, "[svd-left] sweep %d (%lld cols, blocks of %d): rotated=%d above-quadratic=%d\n", sweeps, k, bb, hv[0], hv[1]);
+            if (!hv[1]) break;
+        }
+        QIL_TRY(st);
     }
     lap("sweeps");
     qil_progress_phase(ctx, 5);
