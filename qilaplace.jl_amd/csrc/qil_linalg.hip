@@ -4069,7 +4069,9 @@ int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     // Cholesky QR first where it pays (from a few panels on) and while it keeps succeeding on this context: a numerically
     // rank-deficient operand (product bonds, deficient sketches) costs the attempt a Gram product, a partial factorisation and
     // one synchronisation, so after a refusal the next attempts are skipped
-    if (n >= 64 && n <= 1024 && m >= n && m * n <= (1LL << 22)) {
+    // (r05: skinny tall panels up to 2^24 entries too -- the 32768 x 133 sketch bases of the n = 30 encoder's root split sat just
+    // above 2^22 and took the Householder tree at 2.2 ms each, five per split)
+    if (n >= 64 && n <= 1024 && m >= n && (m * n <= (1LL << 22) || (n <= 256 && m * n <= (1LL << 24)))) {
         if (ctx->cholqr_skip > 0) {
             --ctx->cholqr_skip;
         } else {
