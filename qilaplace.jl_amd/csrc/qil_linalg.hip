@@ -392,6 +392,8 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
     // skinny op(A) (the halves of a bit-sorted coefficient read-out: ~32 queries x 8192 columns x 8192 deep): same MFMA count
     // per wave and K tile as the 64 x 64 tile (1 x 4 instead of 2 x 2 fragments), half the padded rows
     if (batch.skinny_m && m <= 32 && n >= 128) return gemm_launch<T, 32, 128, 16, 64, true>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch);
+    // ... and 33-48 rows (the larger half of 64 sorted queries is typically 33-40 rows): 48 x 128 tiles, 3 x 2 fragments per wave
+    if (batch.skinny_m && m <= 48 && n >= 128) return gemm_launch<T, 48, 128, 48, 32, true>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch);
     constexpr long long small_tiles = 64;
     // (K step of the small tiles 16 / 32 / 64: compress! chi 256 46.5 / 45.3 / 45.2 ms, chi 512 115.1 / 111.7 / 112.1, exact route 300 / 293 / 294)
     if (((m + 63) / 64) * ((n + 63) / 64) * batch.count <= small_tiles && m >= 32 && n >= 32)

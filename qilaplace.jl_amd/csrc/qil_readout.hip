@@ -545,7 +545,7 @@ static int coefficient_enqueue(const qil_mps* psi, int64_t nb, const uint8_t* db
                     const void* Vs = static_cast<const char*>(V) + (size_t)r0 * esz;
                     void* Ts = static_cast<char*>(Tm) + (size_t)r0 * esz;
                     const void* As = site + (size_t)(sl * cl) * esz;
-                    if (rows <= 32) QIL_TRY(qil_dev_gemm_skinny(ctx, psi->dtype, 0, 0, rows, cr, cl, Vs, nb, As, 2 * cl, Ts, nb));
+                    if (rows <= 48) QIL_TRY(qil_dev_gemm_skinny(ctx, psi->dtype, 0, 0, rows, cr, cl, Vs, nb, As, 2 * cl, Ts, nb));
                     else QIL_TRY(qil_dev_gemm(ctx, psi->dtype, 0, 0, rows, cr, cl, Vs, nb, As, 2 * cl, Ts, nb));
                 }
                 const int* map = plan->dmap + (size_t)(i * nb);
