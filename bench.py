@@ -87,20 +87,9 @@ def pmc_traffic(workload):
 
 
 def pmc_truncate():
-    """Matrix-core counters of the truncate half (tools/collect_pmc_truncate.py: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 = f64 MFMA flops and
-    SQ_VALU_MFMA_BUSY_CYCLES per repetition of the exact compress!(apply) and of compress! chi 256 -> 128), for THIS build of the
-    library only."""
-    import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_truncate.json")))
-    if not paths:
-        return None, None
-    try:
-        rec = json.load(open(paths[-1]))
-        if rec.get("lib_sha16") != lib_sha16():
-            return None, f"{os.path.basename(paths[-1])} was collected with another build of libqilhip.so"
-        return rec, os.path.basename(paths[-1])
-    except Exception:
-        return None, None
+    """Matrix-core counters of the truncate half (tools/collect_pmc_truncate.py), for THIS build of the library only."""
+    import bench_configs
+    return bench_configs.pmc_record()
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline

@@ -32,6 +32,40 @@ CONFIGS_BLOCK_KEYS = {
 }
 
 
+def pmc_record():
+    """The newest profiles/r0*_pmc_truncate.json (tools/collect_pmc_truncate.py: counted f64 MFMA instructions per repetition of the
+    truncate-half workloads, the 64-query read-out and the n = 30 encode) IF it was collected with the library binary that is
+    running now (sha256 beside it); else (None, reason)."""
+    import glob, hashlib, json, os
+    root = os.path.dirname(os.path.abspath(__file__))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r0*_pmc_truncate.json")))
+    if not paths:
+        return None, None
+    try:
+        import qilaplace_jl_amd as qil
+        sha = hashlib.sha256(open(qil.LIB_PATH, "rb").read()).hexdigest()[:16]
+        rec = json.load(open(paths[-1]))
+        if rec.get("lib_sha16") != sha:
+            return None, f"{os.path.basename(paths[-1])} was collected with another build of libqilhip.so"
+        return rec, os.path.basename(paths[-1])
+    except Exception:                                        # noqa: BLE001
+        return None, None
+
+
+def counted_mfma(key, ms):
+    """{"mfma_f64_flops", "achieved", "frac", "source"} from the PMC record of this build for workload `key`, over the time measured here."""
+    rec, src = pmc_record()
+    if not rec or key not in rec:
+        return {"mfma_f64_flops": None, "achieved": None, "frac": None, "source": src}
+    fl = rec[key]["mfma_f64_flops"]
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"mfma_f64_flops": fl, "achieved": ach, "unit": "TFLOP/s", "frac": ach / F64_MFMA_PEAK_TFLOPS, "source": src,
+            "dispatches": rec[key].get("dispatches"),
+            "mfma_busy_share_of_simd_cycles": rec[key]["mfma_busy_cycles"] / (ms * 1e-3 * 2.4e9 * 1024.0),
+            "model": "counted: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 per repetition (3-repetition minus 1-repetition rocprofv3 --pmc run of "
+                     "this build) over the time measured here"}
+
+
 def saturated(L, cap, base=2):
     return [int(min(base ** (i + 1), base ** (L - 1 - i), cap)) for i in range(L - 1)]
 
@@ -67,7 +101,7 @@ def readout_roofline(bond_dims, nb, ms, elem_bytes=16, complex_sites=True):
             "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_h, "algorithmic_bytes": bytes_},
             "mfma": {"achieved": mfma, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_m, "algorithmic_flops": flops},
             "model": "bytes = every site tensor read once per batch; flops = one slice per site and query (8 flop per complex "
-                     "multiply-add); time = HIP events around the whole read-out (one GEMM + one slice selection per site)",
+                     "multiply-add); time = HIP events around the whole read-out (bit-sorted: two one-slice GEMMs + one row gather per site)",
             "traffic": None}
 
 
@@ -77,9 +111,12 @@ def coefficient_batch_entry(qil, ctx, out, nb=64, reps=3):
     bits = np.random.default_rng(64).integers(0, 2, size=(nb, L)).astype(np.uint8)
     mean, best = timed(ctx, lambda: qil.coefficient_batch(out, bits), reps=reps)
     cx = np.dtype(out.dtype) == np.complex128
+    roof = readout_roofline(out.bond_dims, nb, mean, 16 if cx else 8, cx)
+    if nb == 64 and max(out.bond_dims) == 8192:
+        roof["mfma_counted"] = counted_mfma("coefficient_batch_64_cfg3", mean)      # executed (incl. tile padding), not algorithmic
     return {"workload": "coefficient_batch on the materialised cfg3 product (zt_n24_chi64_D128, 80 GB)", "queries": nb,
             "ms": mean, "ms_min": best, "repetitions": reps, "product_bond_max": int(max(out.bond_dims)),
-            "roofline": readout_roofline(out.bond_dims, nb, mean, 16 if cx else 8, cx)}
+            "roofline": roof}
 
 
 # ---------------------------------------------------------------------------------------------- cfg2
@@ -350,6 +387,7 @@ def cfg5_entry(qil, ctx, n=30, k=128, p=5, q=2, reps=2):
         "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes": bytes_},
         "mfma": {"achieved": mf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf / F64_MFMA_PEAK_TFLOPS, "algorithmic_flops": flops},
         "frac": max(mf / F64_MFMA_PEAK_TFLOPS, hbm / HBM_PEAK_GBS),
+        "mfma_counted": counted_mfma("encode_n30_random_k128", r_mean) if (n, k, p, q) == (30, 128, 5, 2) else None,
         "model": f"root split {2 ** (n // 2)} x {2 ** (n - n // 2)}: (2 + 2q) = {2 + 2 * q} sketch products with l = k + p = {k + p} columns, "
                  "2 m n l flops and 8 m n bytes each; time = the WHOLE encode (root + 2 n - 2 smaller splits + normalisation), HIP events"}
     del psi_r, xr

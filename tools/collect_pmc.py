@@ -2,7 +2,7 @@
 """HBM traffic of the dominant kernel from rocprofv3 PMC passes (MI355X_MICROARCH.md, HBM / rocprofv3 section):
 WRITE_SIZE and FETCH_SIZE are collected in SEPARATE passes (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2), both in
 KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, so it is doubled.  Writes
-profiles/r04_pmc_traffic.json = {workload: bytes per launch, lib_sha16: ...}; bench.py reports `roofline.traffic` from it
+profiles/<round>_pmc_traffic.json (QIL_ROUND, default r05) = {workload: bytes per launch, lib_sha16: ...}; bench.py reports `roofline.traffic` from it
 only while the sha matches the library it runs.
 
 Run on the GPU box from the repo root (each pass is its own rocprofv3 process; the profiled program is python itself):
@@ -18,6 +18,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("QIL_ROUND", "r05")
 WORKLOAD = "zt_n24_chi64_D128"
 KERNEL = "site_apply_grouped"
 
@@ -27,7 +28,7 @@ def one_pass(counter, outdir):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "-d", outdir, "--output-format", "csv", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-           "--no-truncate", "--workload", WORKLOAD]
+           "--no-truncate", "--no-configs", "--workload", WORKLOAD]
     subprocess.run(cmd, check=True, env=env, cwd="/tmp", stdout=subprocess.DEVNULL)
     vals = collections.defaultdict(list)
     rows_out = []
@@ -54,13 +55,13 @@ def main():
                     "correction, MI355X_MICROARCH.md HBM section), separate --pmc passes, mean over the profiled launches",
            "_write_size_kb": w_kb, "_fetch_size_kb": f_kb, "_launches": [nw, nf]}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    for name, rows in (("r04_pmc_write_site_apply.csv", wrows), ("r04_pmc_fetch_site_apply.csv", frows)):
+    for name, rows in ((ROUND + "_pmc_write_site_apply.csv", wrows), (ROUND + "_pmc_fetch_site_apply.csv", frows)):
         with open(os.path.join(ROOT, "gpurun_out", name), "w", newline="") as fh:
             wr = csv.writer(fh)
             wr.writerow(["Kernel_Name", "Counter_Name", "Counter_Value_KB", "Grid_Size", "Workgroup_Size", "LDS_Block_Size",
                          "VGPR_Count", "SGPR_Count"])
             wr.writerows(rows)
-    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r04_pmc_traffic.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", ROUND + "_pmc_traffic.json"), "w"), indent=1)
     import shutil
     shutil.rmtree(out, ignore_errors=True)
     print(json.dumps(rec))

@@ -5,8 +5,10 @@ f64 MFMA flops), SQ_VALU_MFMA_BUSY_CYCLES and SQ_INSTS_VALU summed over every di
     (tools/_exact_compress_time.py), and
   * compress! chi 256 -> 128 on 24 sites (tools/_compress_one.py 256 f64), and
   * (r04) ONE qil_apply_compress_batch of the 64 (zT operator, signal) pairs of a damping sweep (tools/_apply_compress_batch64.py),
+and (r05, the two other rooflines of SURVEY.md 8d) the 64-query coefficient_batch on an 80 GB cfg3-shaped product
+(tools/_coeff_cfg3.py) and signal_ztmps(:rsvd, k=128) of 2^30 i.i.d. samples (tools/_prof_encode30.py),
 each as the DIFFERENCE of a 3-repetition and a 1-repetition run (the set-up -- encode, MPO build, warm-up -- cancels), per
-repetition.  Writes gpurun_out/r04_pmc_truncate.json keyed to the library's sha256 (copy it to profiles/): bench.py reports
+repetition.  Writes gpurun_out/<round>_pmc_truncate.json (round tag: QIL_ROUND, default r05) keyed to the library's sha256 (copy it to profiles/): bench.py reports
 `truncate.roofline` from it only while the sha matches the library it runs.  PMC passes serialise the kernels, so times come
 from the un-profiled bench run, never from here.
 
@@ -24,6 +26,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("QIL_ROUND", "r05")
 COUNTERS = ["SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA"]
 
 
@@ -78,9 +81,12 @@ def main():
            "compress_chi256_24_sites": workload("chi256", "_compress_one.py", lambda r: ["256", "f64", str(r)]),
            # the batch as the operating point of the truncate half: 64 (zT operator, signal) pairs of a damping sweep through
            # ONE qil_apply_compress_batch (tools/_apply_compress_batch64.py 64 zt <repetitions>)
-           "apply_compress_batch64_zt": workload("batch64", "_apply_compress_batch64.py", lambda r: ["64", "zt", str(r)])}
+           "apply_compress_batch64_zt": workload("batch64", "_apply_compress_batch64.py", lambda r: ["64", "zt", str(r)]),
+           # the read-out and the RSVD encode, counted
+           "coefficient_batch_64_cfg3": workload("coeff64", "_coeff_cfg3.py", lambda r: [str(r)]),
+           "encode_n30_random_k128": workload("encode30", "_prof_encode30.py", lambda r: [str(r)])}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r04_pmc_truncate.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", ROUND + "_pmc_truncate.json"), "w"), indent=1)
     print(json.dumps(rec))
 
 
