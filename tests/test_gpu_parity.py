@@ -859,6 +859,39 @@ def test_coefficient_batched_gemm_path(qil, dt):
     assert rel(qil.coefficient_batch(psi, bits[:3]), ref[:3]) < 1e-12        # nb < 4: chain kernel
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+def test_coefficient_bit_sorted_readout_edge_cases(qil, dt):
+    """r05: the GEMM read-out sorts the queries by their bit at every site and multiplies each half with ONE slice (32 / 48 / 64-row
+    tiles by the size of the half).  Every split the plan can produce -- empty halves (all queries share the bit), halves of 1, 16,
+    32, 33, 48, 49 rows, many queries, queries that are all equal -- against the oracle, for real and complex sites (the real ones
+    run the f64 instantiations of the skinny tiles)."""
+    rng = np.random.default_rng(77)
+    bonds = [2, 4, 8, 160, 300, 130, 8, 4, 2]
+    a = random_mps_data(bonds, rng, dt)
+    L = len(a)
+    psi, ref_psi = qil.SignalMPS(a, amplitude=1.7), O.SignalMPS(a, amplitude=1.7)
+
+    def check(bits):
+        got = qil.coefficient_batch(psi, bits)
+        ref = O.coefficient_batch(ref_psi, bits)
+        assert rel(got, ref) < 1e-12, bits.shape
+
+    for nb in (4, 5, 33, 49, 64, 97, 130, 700):
+        check(rng.integers(0, 2, size=(nb, L)))
+    check(np.zeros((40, L), dtype=np.int64))                                   # every site: the whole batch takes slice 0
+    check(np.ones((40, L), dtype=np.int64))                                    # ... slice 1
+    for n1 in (1, 16, 32, 33, 48, 49):                                         # exact half sizes around the tile boundaries
+        b = np.zeros((80, L), dtype=np.int64)
+        b[:n1] = 1
+        rng.shuffle(b, axis=0)
+        check(b)
+    alt = (np.arange(64)[:, None] + np.arange(L)[None, :]) % 2                 # the halves swap at every site
+    check(alt)
+    same = np.tile(rng.integers(0, 2, size=(1, L)), (50, 1))                   # 50 copies of one query
+    got = qil.coefficient_batch(psi, same)
+    assert np.all(got == got[0]) and rel(got[:1], O.coefficient_batch(ref_psi, same[:1])) < 1e-12
+
+
 # ---------------------------------------------------------------- marginals / scans (SURVEY 8f-3)
 @pytest.mark.parametrize("big", [False, True])
 def test_marginal_batch_and_scans(qil, big):
