@@ -1052,6 +1052,34 @@ def test_apply_compress_random_products_against_oracle(qil, case):
     assert abs(qil.norm(fused) - 1.0) < 1e-10                     # compress! post-condition (mps.jl:967-971)
 
 
+@pytest.mark.parametrize("decay", [0.0, 0.5])
+def test_apply_compress_large_maxdim_slow_decay(qil, decay):
+    """the zip-up's intermediate cap is maxdim + 16 up to maxdim 128 (fuzzed on flat spectra) and keeps a relative floor
+    of 1.125 maxdim beyond; this is the case at maxdim 256 that evidence was missing for -- a bond-512 product whose Schmidt
+    spectrum is flat (decay 0) or decays slowly (bond index beta scaled by (1 + beta)^-0.5) -- against the oracle's
+    compress!(apply(W, psi)): bonds never larger, state error at most twice the oracle's own truncation error."""
+    rng = np.random.default_rng(256)
+    L, chi, D, maxdim, tol = 20, 64, 8, 256, 1e-10
+    a = random_mps_data(saturated_profile(L, chi), rng, dtype=np.float64)
+    if decay:
+        for i in range(L - 1):
+            b = a[i].shape[2]
+            a[i] = a[i] * ((1.0 + np.arange(b)) ** -decay)[None, None, :]
+    w = random_mpo_data(saturated_profile(L, D, base=4), rng, dtype=np.complex128)
+    ref = O.apply(O.SingleSiteMPO(w), O.SignalMPS([t.copy() for t in a], amplitude=1.0))
+    assert max(ref.bond_dims) == 512
+    exact = dense_mps(ref.data)
+    O.compress(ref, maxdim=maxdim, tol=tol)
+    want = ref.amplitude * dense_mps(ref.data)
+    fused = qil.apply_compress(qil.SingleSiteMPO(w), qil.SignalMPS(a, amplitude=1.0), maxdim=maxdim, tol=tol)
+    got = fused.amplitude * dense_mps(fused.to_host())
+    nrm = np.linalg.norm(exact)
+    e_trunc = np.linalg.norm(want - exact) / nrm
+    e_fused = np.linalg.norm(got - exact) / nrm
+    assert max(fused.bond_dims) == maxdim and all(f <= o for f, o in zip(fused.bond_dims, ref.bond_dims)), (fused.bond_dims, ref.bond_dims)
+    assert e_fused <= 2 * e_trunc + 1e-9, (decay, e_fused, e_trunc)
+
+
 @pytest.mark.parametrize("n,maxdim,tol", [(8, 12, 1e-4), (10, 16, 1e-4), (10, 8, 1e-3), (10, 16, 1e-6), (10, 24, 1e-10)])
 def test_apply_compress_zt_pipeline_against_oracle(qil, n, maxdim, tol):
     """The genuine pipeline: zT MPO applied to an encoded signal and truncated, fused route vs the oracle's
