@@ -36,7 +36,7 @@ using namespace qil_dev;
 //     the fragment reads at <= 2-way bank conflicts);
 //   * the MFMA is issued as (B^T tile) x (A^T tile) = (AB)^T tile: the D fragment then has the C ROW
 //     index on lane&15, so every 16 lanes store 128 B (f64) / 256 B (c64) contiguous in column-major C;
-//   * complex product = 4 real MFMAs into 3 accumulators (rr, ii, ri): C = (rr - ii) + i ri;
+//   * complex product = 3 real MFMAs (Gauss, r05) into 3 accumulators (rr = k1, ii = k3, ri = k2): C = (rr - ii) + i (rr + ri);
 //   * operands are addressed through (row stride, k stride, conj) so N/T/H/conj need no extra kernels;
 //     the global->register mapping follows whichever index is contiguous (coalesced either way);
 //   * gridDim.z > 1 = split-K into a workspace + fixed-order reduction (deterministic).
@@ -225,17 +225,35 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                 bre[t] = b0[(kk + l4) * LB + wc + 16 * t + l15];
                 if (CX) bim[t] = b0[GKT * LB + (kk + l4) * LB + wc + 16 * t + l15];
             }
+            if constexpr (CX) {
+                // complex product by Gauss's three multiplications (r05): with k1 = br (ar + ai), k2 = ar (bi - br),
+                // k3 = ai (br + bi):  re = k1 - k3,  im = k1 + k2.  Three MFMAs per complex multiply-add instead of four -- the
+                // matrix pipe is what a complex product is bound by (64 cycles per v_mfma_f64_16x16x4) --, the three operand sums
+                // are VALU adds on the fragments just read (TM + 2 TN per K step of 3 TM TN MFMAs).  Normwise as accurate as the
+                // four-multiplication form (error ~ u |a| |b|); accumulators: rr = sum k1, ii = sum k3, ri = sum k2.
+                double asum[TM], bsum[TN], bdif[TN];
 #pragma unroll
-            for (int ti = 0; ti < TM; ++ti)
+                for (int t = 0; t < TM; ++t) asum[t] = are[t] + aim[t];
 #pragma unroll
-                for (int tj = 0; tj < TN; ++tj) {
-                    rr[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], are[ti], rr[ti][tj], 0, 0, 0);
-                    if (CX) {
-                        ii[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bim[tj], aim[ti], ii[ti][tj], 0, 0, 0);
-                        ri[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bim[tj], are[ti], ri[ti][tj], 0, 0, 0);
-                        ri[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], aim[ti], ri[ti][tj], 0, 0, 0);
-                    }
+                for (int t = 0; t < TN; ++t) {
+                    bsum[t] = bre[t] + bim[t];
+                    bdif[t] = bim[t] - bre[t];
                 }
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TN; ++tj) {
+                        rr[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], asum[ti], rr[ti][tj], 0, 0, 0);
+                        ii[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bsum[tj], aim[ti], ii[ti][tj], 0, 0, 0);
+                        ri[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bdif[tj], are[ti], ri[ti][tj], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TN; ++tj)
+                        rr[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], are[ti], rr[ti][tj], 0, 0, 0);
+            }
         }
         if (PIPE) buf ^= 1;
     }
@@ -254,13 +272,13 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                     if (subtract) {
                         if (CX) {
                             cp[0] -= rr[ti][tj][r] - ii[ti][tj][r];
-                            cp[1] -= ri[ti][tj][r];
+                            cp[1] -= rr[ti][tj][r] + ri[ti][tj][r];
                         } else {
                             cp[0] -= rr[ti][tj][r];
                         }
                     } else if (CX) {
-                        cp[0] = rr[ti][tj][r] - ii[ti][tj][r];
-                        cp[1] = ri[ti][tj][r];
+                        cp[0] = rr[ti][tj][r] - ii[ti][tj][r];                   // re = k1 - k3
+                        cp[1] = rr[ti][tj][r] + ri[ti][tj][r];                   // im = k1 + k2
                     } else {
                         cp[0] = rr[ti][tj][r];
                     }
