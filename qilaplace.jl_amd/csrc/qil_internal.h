@@ -262,7 +262,8 @@ struct qil_call_scope {
 int qil_dev_gemm(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
                  const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc);
 // The same product for a SKINNY op(A) (m <= 48 rows against thousands of columns: the bit-sorted coefficient read-out):
-// 32 x 128 / 48 x 128 output tiles instead of 64 x 64, so that a 30-row operand does not pay for 64 rows of matrix-core work.
+// 32 x 64 / 48 x 64 output tiles with two K tiles in flight instead of 64 x 64 with one, so that a 30-row operand does not pay
+// for 64 rows of matrix-core work and the long operand streams at more than one tile's latency allows.
 int qil_dev_gemm_skinny(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
                         const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc);
 // Strided batch of the same product (grid y = batch): operand/result b lives at base + b * stride elements;

@@ -60,7 +60,7 @@ __device__ __forceinline__ c64 maybe_conj(c64 v, int cj) { return cj ? c64{v.re,
 
 // ARC / BKC: op(A)'s row index / op(B)'s k index is the contiguous one in memory (compile time, so that the staging
 // pattern -- which element of the tile a thread loads and where it lands in LDS -- folds into constants).
-template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC, int GKT = GK>
+template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC, int GKT = GK, int DEEP = 0>
 __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3 gridDim, long long m, long long n, long long k_total,
                                                  const T* __restrict__ A, long long a_rs, long long a_ks, int conjA,
                                                  const T* __restrict__ B, long long b_ks, long long b_cs, int conjB,
@@ -164,7 +164,7 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
     // tiles -- all but possibly the last -- run plain loads and plain stores to LDS, the last one selects a valid
     // address per lane and zeroes the k-invalid elements when the tile is staged.  Nothing touches a loaded value
     // before store_tile, so the loads stay in flight across the MFMAs of the current tile.
-    auto load_tile = [&](long long k0) {
+    auto load_tile_into = [&](T(&ra)[EA], T(&rb)[EB], long long k0) {
         if (k0 + GKT <= kend) {
 #pragma unroll
             for (int e = 0; e < EA; ++e) {
@@ -183,7 +183,8 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
             for (int e = 0; e < EB; ++e) rb[e] = *((k0 + kb[e] < kend) ? pb[e] : B);
         }
     };
-    auto store_tile = [&](int buf, long long k0) {     // k0 = first k of the tile held in ra / rb
+    auto load_tile = [&](long long k0) { load_tile_into(ra, rb, k0); };
+    auto store_tile_from = [&](const T(&ra)[EA], const T(&rb)[EB], int buf, long long k0) {     // k0 = first k of the tile held in ra / rb
         double* a0 = As + (buf * NP) * GKT * LA;
         double* b0 = Bs + (buf * NP) * GKT * LB;
         if (k0 + GKT <= kend) {
@@ -200,16 +201,8 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                 put_plane(b0, b0 + GKT * LB, sb[e], (k0 + kb[e] < kend) ? maybe_conj(rb[e], conjB) : T{});
         }
     };
-    int buf = 0;
-    if (PIPE && kbeg < kend) load_tile(kbeg);
-    for (long long k0 = kbeg; k0 < kend; k0 += GKT) {
-        if (!PIPE) {
-            if (k0 > kbeg) __syncthreads();         // everyone is done reading the single buffer
-            load_tile(k0);
-        }
-        store_tile(buf, k0);
-        __syncthreads();
-        if (PIPE && k0 + GKT < kend) load_tile(k0 + GKT);     // in flight during the MFMAs below
+    auto store_tile = [&](int buf, long long k0) { store_tile_from(ra, rb, buf, k0); };
+    auto mfma_tile = [&](int buf) {
         const double* a0 = As + (buf * NP) * GKT * LA;
         const double* b0 = Bs + (buf * NP) * GKT * LB;
 #pragma unroll
@@ -255,7 +248,40 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                         rr[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], are[ti], rr[ti][tj], 0, 0, 0);
             }
         }
-        if (PIPE) buf ^= 1;
+    };
+    if constexpr (PIPE && DEEP) {
+        // TWO K tiles in flight (r05): a skinny product streams its long operand once, one row of tiles per workgroup, and
+        // with one tile ahead the global-load latency under a full HBM pipe (~3 us) exceeded the MFMA phase it hides behind
+        // (~1 us): 32 / 48 / 64 rows x 8192 x 8192 all took 0.47 ms = 2.3 TB/s.  Two register sets alternate; each load has
+        // two MFMA phases to land.
+        T ra1[EA], rb1[EB];
+        if (kbeg < kend) load_tile_into(ra, rb, kbeg);
+        if (kbeg + GKT < kend) load_tile_into(ra1, rb1, kbeg + GKT);
+        for (long long k0 = kbeg; k0 < kend; k0 += 2 * GKT) {
+            store_tile_from(ra, rb, 0, k0);
+            __syncthreads();
+            if (k0 + 2 * GKT < kend) load_tile_into(ra, rb, k0 + 2 * GKT);
+            mfma_tile(0);
+            if (k0 + GKT >= kend) break;
+            store_tile_from(ra1, rb1, 1, k0 + GKT);
+            __syncthreads();
+            if (k0 + 3 * GKT < kend) load_tile_into(ra1, rb1, k0 + 3 * GKT);
+            mfma_tile(1);
+        }
+    } else {
+        int buf = 0;
+        if (PIPE && kbeg < kend) load_tile(kbeg);
+        for (long long k0 = kbeg; k0 < kend; k0 += GKT) {
+            if (!PIPE) {
+                if (k0 > kbeg) __syncthreads();         // everyone is done reading the single buffer
+                load_tile(k0);
+            }
+            store_tile(buf, k0);
+            __syncthreads();
+            if (PIPE && k0 + GKT < kend) load_tile(k0 + GKT);     // in flight during the MFMAs below
+            mfma_tile(buf);
+            if (PIPE) buf ^= 1;
+        }
     }
     // D fragment of (AB)^T: D'[j][i], i = lane & 15, j = (lane >> 4) + 4 * reg
 #pragma unroll
@@ -285,12 +311,12 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                 }
             }
 }
-template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC, int GKT = GK>
+template <class T, int BM, int BN, int WM, int WN, bool PIPE, bool ARC, bool BKC, int GKT = GK, int DEEP = 0>
 struct gemm_mfma_k {
-    static constexpr int NT = 256, MINW = (BM * BN <= 128 * 128 ? 2 : 1);
+    static constexpr int NT = 256, MINW = (DEEP ? 1 : (BM * BN <= 128 * 128 ? 2 : 1));   // (DEEP: two register sets of staged tiles, no spills)
     template <class... QA>
     static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
-        gemm_mfma_body<T, BM, BN, WM, WN, PIPE, ARC, BKC, GKT>(b, g, a...);
+        gemm_mfma_body<T, BM, BN, WM, WN, PIPE, ARC, BKC, GKT, DEEP>(b, g, a...);
     }
 };
 
@@ -326,7 +352,7 @@ struct gemm_batch {
     int skinny_m = 0;                   // 1: the caller knows op(A) has <= 32 rows and a long n: 32 x 128 output tiles
 };
 
-template <class T, int BM, int BN, int WM, int WN, bool PIPE, int GKT = GK>
+template <class T, int BM, int BN, int WM, int WN, bool PIPE, int GKT = GK, int DEEP = 0>
 int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T* A, long long a_rs,
                 long long a_ks, int conjA, const T* B, long long b_ks, long long b_cs, int conjB, T* C,
                 long long ldc, const gemm_batch& bt) {
@@ -371,7 +397,7 @@ int gemm_launch(qil_context* ctx, long long m, long long n, long long k, const T
     static const bool xcd_order = true;
     const int col_fastest = (tiles_n <= 8 ? 1 : 0) | (xcd_order ? 0 : 2);
 #define QIL_GEMM_K(ARCv, BKCv)                                                                                               \
-    QIL_TRY((qil_klaunch<gemm_mfma_k<T, BM, BN, WM, WN, PIPE, ARCv, BKCv, GKT>>(                                                      \
+    QIL_TRY((qil_klaunch<gemm_mfma_k<T, BM, BN, WM, WN, PIPE, ARCv, BKCv, GKT, DEEP>>(                                                      \
         ctx, dim3((unsigned)tiles, (unsigned)bt.count, (unsigned)splits), dim3(256), lds, m, n, k, A, a_rs, a_ks, conjA, B, b_ks, \
         b_cs, conjB, Cout, ldo, kchunk, cstride, (int)tiles_m, (int)tiles_n, col_fastest, bt.a_bs, bt.b_bs, c_bs, bt.cmap,        \
         bt.cmap_blk, bt.b_sel, bt.b_sel_step, bt.b_sel_stride, splits > 1 ? 0 : bt.subtract)))
@@ -407,11 +433,15 @@ int gemm_dispatch(qil_context* ctx, int opA, int opB, long long m, long long n, 
     // idle is bound by the K loop of ONE tile on its CU (32 MFMAs per wave and 32-deep K step at 64 x 64, 8 at 32 x 32)
     // (measured, up to 0 / 16 / 32 / 64 tiles of 64 x 64 as 32 x 32 tiles: compress! chi 256 f64 49.5 / 46.2 / 45.6 / 46.1 ms, c64 66.2 /
     // 61.5 / 59.6 / 61.0, chi 512 f64 122.3 / 118.0 / 115.7 / 114.5, c64 165.9 / 151.8 / 148.1 / 142.6, fused apply-and-truncate 147 / 131 / 128 / 129)
-    // skinny op(A) (the halves of a bit-sorted coefficient read-out: ~32 queries x 8192 columns x 8192 deep): same MFMA count
-    // per wave and K tile as the 64 x 64 tile (1 x 4 instead of 2 x 2 fragments), half the padded rows
-    if (batch.skinny_m && m <= 32 && n >= 128) return gemm_launch<T, 32, 128, 16, 64, true>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch);
-    // ... and 33-48 rows (the larger half of 64 sorted queries is typically 33-40 rows): 48 x 128 tiles, 3 x 2 fragments per wave
-    if (batch.skinny_m && m <= 48 && n >= 128) return gemm_launch<T, 48, 128, 48, 32, true>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch);
+    // skinny op(A) (the halves of a bit-sorted coefficient read-out: ~32 queries x 8192 columns x 8192 deep): the product streams
+    // its long operand ONCE, one row of tiles.  32 x 64 / 48 x 64 tiles (no rows of padding work; 51 / 59 KB of LDS: 3 / 2
+    // workgroups per CU) with TWO K tiles in flight (DEEP).  Measured per 8192 x 8192 complex slice: 64 x 64 tile, one tile ahead
+    // 0.47 ms whatever the rows (latency-bound, 2.3 TB/s); 32 x 128 / 48 x 128 one tile ahead the same; 32 x 64 DEEP 0.30 ms
+    // (3.5 TB/s), 48 x 64 DEEP 0.43-0.47 ms, 64 x 64 DEEP 0.58 ms -- now proportional to the padded rows (~42 TFLOP/s of real
+    // MFMA work, 0.54 of the matrix peak) and independent of the grid size (512 ... 1536 workgroups: equal)
+    if (batch.skinny_m && m <= 32 && n >= 128) return gemm_launch<T, 32, 64, 16, 32, true, GK, 1>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch);
+    // ... and 33-48 rows (the larger half of 64 sorted queries is typically 33-40 rows)
+    if (batch.skinny_m && m <= 48 && n >= 128) return gemm_launch<T, 48, 64, 48, 16, true, GK, 1>(ctx, m, n, k, A, a_rs, a_ks, cA, B, b_ks, b_cs, cB, C, ldc, batch);
     constexpr long long small_tiles = 64;
     // (K step of the small tiles 16 / 32 / 64: compress! chi 256 46.5 / 45.3 / 45.2 ms, chi 512 115.1 / 111.7 / 112.1, exact route 300 / 293 / 294)
     if (((m + 63) / 64) * ((n + 63) / 64) * batch.count <= small_tiles && m >= 32 && n >= 32)
