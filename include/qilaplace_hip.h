@@ -317,7 +317,7 @@ int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, const voi
 typedef struct qil_comm qil_comm;
 int qil_comm_unique_id(void* id_out);
 int qil_comm_create(qil_context* ctx, int rank, int world, const void* id, qil_comm** out);
-int qil_comm_destroy(qil_comm* comm);
+int qil_comm_destroy(qil_comm* comm);            /* before the context it was created on is destroyed */
 int qil_comm_info(const qil_comm* comm, int* rank, int* world);
 /* local: this rank's items in its own order (item rank, rank + world, ...), each `width` complex values (interleaved
  * doubles), host memory.  out: n_items x width complex values in ITEM order, host memory, on every rank.  Collective. */
