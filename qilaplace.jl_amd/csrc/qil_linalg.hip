@@ -41,6 +41,9 @@ using namespace qil_dev;
 //     the global->register mapping follows whichever index is contiguous (coalesced either way);
 //   * gridDim.z > 1 = split-K into a workspace + fixed-order reduction (deterministic).
 constexpr int GK = 16;
+#ifndef QIL_GEMM_GAUSS
+#define QIL_GEMM_GAUSS 1          // complex products by three real multiplications (0: four; A/B builds)
+#endif
 #ifndef QIL_GEMM_PAD
 #define QIL_GEMM_PAD 2
 #endif
@@ -218,7 +221,7 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                 bre[t] = b0[(kk + l4) * LB + wc + 16 * t + l15];
                 if (CX) bim[t] = b0[GKT * LB + (kk + l4) * LB + wc + 16 * t + l15];
             }
-            if constexpr (CX) {
+            if constexpr (CX && QIL_GEMM_GAUSS) {
                 // complex product by Gauss's three multiplications (r05): with k1 = br (ar + ai), k2 = ar (bi - br),
                 // k3 = ai (br + bi):  re = k1 - k3,  im = k1 + k2.  Three MFMAs per complex multiply-add instead of four -- the
                 // matrix pipe is what a complex product is bound by (64 cycles per v_mfma_f64_16x16x4) --, the three operand sums
@@ -244,8 +247,14 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
 #pragma unroll
                 for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-                    for (int tj = 0; tj < TN; ++tj)
+                    for (int tj = 0; tj < TN; ++tj) {
                         rr[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], are[ti], rr[ti][tj], 0, 0, 0);
+                        if constexpr (CX) {                                      // (QIL_GEMM_GAUSS = 0: the four-multiplication form, A/B builds only)
+                            ii[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bim[tj], aim[ti], ii[ti][tj], 0, 0, 0);
+                            ri[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bim[tj], are[ti], ri[ti][tj], 0, 0, 0);
+                            ri[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bre[tj], aim[ti], ri[ti][tj], 0, 0, 0);
+                        }
+                    }
             }
         }
     };
@@ -298,13 +307,13 @@ __device__ __forceinline__ void gemm_mfma_body(const uint3 blockIdx, const uint3
                     if (subtract) {
                         if (CX) {
                             cp[0] -= rr[ti][tj][r] - ii[ti][tj][r];
-                            cp[1] -= rr[ti][tj][r] + ri[ti][tj][r];
+                            cp[1] -= QIL_GEMM_GAUSS ? rr[ti][tj][r] + ri[ti][tj][r] : ri[ti][tj][r];
                         } else {
                             cp[0] -= rr[ti][tj][r];
                         }
                     } else if (CX) {
                         cp[0] = rr[ti][tj][r] - ii[ti][tj][r];                   // re = k1 - k3
-                        cp[1] = rr[ti][tj][r] + ri[ti][tj][r];                   // im = k1 + k2
+                        cp[1] = QIL_GEMM_GAUSS ? rr[ti][tj][r] + ri[ti][tj][r] : ri[ti][tj][r];   // im = k1 + k2
                     } else {
                         cp[0] = rr[ti][tj][r];
                     }
