@@ -25,7 +25,7 @@ class Comm:
 
     ``Comm(ctx, rank, world, uid)`` is collective (every rank, same 128-byte ``uid`` from ``Comm.unique_id()`` on rank 0).
     ``Comm.from_env(ctx)`` reads RANK / WORLD_SIZE and passes the id through a file: rank 0 writes
-    ``$QIL_COMM_FILE`` (default ``/tmp/qil_comm_<MASTER_PORT>_<launcher pid>.id``) atomically, the others wait for it --
+    ``$QIL_COMM_FILE`` (default ``<tmpdir>/qil_comm_<uid>_<MASTER_PORT>_<launcher pid>.id``, mode 0600) atomically, the others wait for it --
     one node, one shared /tmp: the scope of SURVEY.md 8(e)."""
 
     def __init__(self, ctx, rank: int, world: int, uid: bytes):
@@ -48,13 +48,16 @@ class Comm:
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         if world == 1:
             return cls(ctx, 0, 1, cls.unique_id())
+        import tempfile
         path = os.environ.get("QIL_COMM_FILE") or os.path.join(
-            "/tmp", f"qil_comm_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('QIL_COMM_TAG', os.getppid())}.id")
+            tempfile.gettempdir(), f"qil_comm_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('QIL_COMM_TAG', os.getppid())}.id")
         if rank == 0:
             uid = cls.unique_id()
-            with open(path + ".tmp", "wb") as f:
+            tmp = f"{path}.{os.getpid()}.tmp"
+            fd = os.open(tmp, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)      # never through somebody else's file or link
+            with os.fdopen(fd, "wb") as f:
                 f.write(uid)
-            os.replace(path + ".tmp", path)
+            os.replace(tmp, path)
         else:
             t0 = time.monotonic()
             while not (os.path.exists(path) and os.path.getsize(path) == COMM_ID_BYTES):
