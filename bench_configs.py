@@ -6,7 +6,7 @@ configuration and for the two other rooflines of SURVEY.md 8(d) (VERDICT r04 ite
                      closed form is NOT negligible (share printed)
   cfg5               n=30 signal generated in HBM: signal_ztmps(:rsvd, k=128, p=5, q=2) encode with the bytes / flops model of
                      its root split against the HBM and f64-MFMA peaks, zT MPO build, lazy read-out, materialised apply of the
-                     structured signal, error against the closed form
+                     structured signal and of the saturated chi_s = 128 state (62 GB, HBM-resident), error against the closed form
   coefficient_batch  64 coefficients of the 80 GB cfg3 product: ms, site bytes against the HBM spec and slice flops against the
                      f64 matrix peak (measured by bench.py on the product of its own timed region, passed in)
 
@@ -392,8 +392,48 @@ def cfg5_entry(qil, ctx, n=30, k=128, p=5, q=2, reps=2):
         "mfma_counted": counted_mfma("encode_n30_random_k128", r_mean) if (n, k, p, q) == (30, 128, 5, 2) else None,
         "model": f"root split {2 ** (n // 2)} x {2 ** (n - n // 2)}: (2 + 2q) = {2 + 2 * q} sketch products with l = k + p = {k + p} columns, "
                  "2 m n l flops and 8 m n bytes each; time = the WHOLE encode (root + 2 n - 2 smaller splits + normalisation), HIP events"}
-    del psi_r, xr
+    del xr
     torch.cuda.empty_cache()
+    ctx.trim()
+    # ... and the apply at the configuration's NOMINAL chi_s: zT MPO (natural bonds) x the saturated state, materialised in HBM
+    # (201 GB at D ~ 90; it must not be padded to 128 -- 406 GB > 288 GB).  Only when the device has the room.
+    try:
+        Wr = qil.build_zt_mpo_batch(psi_r, [wr], cutoff=1e-14)[0]
+        pbr = [c * d for c, d in zip(psi_r.bond_dims, Wr.bond_dims)]
+        ob = sum(16 * a * 2 * b for a, b in zip([1] + pbr, pbr + [1]))
+        free = ctx.mem_info()["device_free"]
+        sat = {"output_bytes": ob, "device_free_bytes": int(free), "mps_bonds_max": int(max(psi_r.bond_dims)), "mpo_bonds_max": int(max(Wr.bond_dims)),
+               "product_bond_max": int(max(pbr))}
+        if ob < 0.8 * free:
+            ab = algorithmic_bytes(psi_r.bond_dims, Wr.bond_dims)
+            outr = qil.apply(Wr, psi_r)                                   # warm-up: the pool takes the blocks from the driver
+            ctx.synchronize()
+            ctx.profile_enable(True)
+            ctx.profile_read(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                del outr
+                outr = qil.apply(Wr, psi_r)
+            ctx.synchronize()
+            wall = (time.perf_counter() - t0) / 2
+            ctx.profile_enable(False)
+            nl, kms = ctx.profile_read(reset=True)
+            k_ms = kms / max(nl, 1)
+            bq = kl_bits(n, rng.integers(0, min(64, N), size=16), rng.integers(0, min(1 << 20, N), size=16))
+            mat = qil.coefficient_batch(outr, bq)
+            lz = qil.apply_coefficient_batch(Wr, psi_r, bq)
+            sat.update({"apply_ms": wall * 1e3, "kernel_ms": k_ms, "site_contractions_per_s": 2 * n / wall, "algorithmic_bytes": ab,
+                        "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<c64,double>", "achieved": ab / (k_ms * 1e-3) / 1e9,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "materialised_vs_lazy_rel": float(np.abs(mat - lz).max() / np.abs(lz).max())})
+            del outr
+        else:
+            sat["skipped"] = "the materialised product does not fit beside what the device holds"
+        res["apply_saturated"] = sat
+        del Wr
+    except Exception as e:                                                 # noqa: BLE001
+        res["apply_saturated"] = {"error": f"{type(e).__name__}: {e}"}
+    del psi_r
     ctx.trim()
     return res
 

@@ -1189,6 +1189,8 @@ def test_bench_configs_block_small(qil):
     assert blk["cfg2"]["max_coeff_err"] < 1e-9 and 0 < blk["cfg2"]["roofline"]["frac"] < 1.2
     assert blk["cfg4"]["max_coeff_err"] < 1e-5 and blk["cfg4"]["reference_samples_above_1e-6_peak"]["count"] > 0
     assert blk["cfg5"]["max_coeff_err"] < 2e-7 and blk["cfg5"]["lazy_vs_materialised_rel"] < 1e-11
+    sat = blk["cfg5"]["apply_saturated"]                               # the apply at the nominal chi_s, materialised
+    assert "error" not in sat and sat["materialised_vs_lazy_rel"] < 1e-11 and sat["mps_bonds_max"] == 24
     assert blk["cfg5"]["encode_roofline"]["mfma"]["algorithmic_flops"] == 6 * 2 * 2 ** 16 * 29
     # the read-out entry on a small materialised product (the bench passes the 80 GB one)
     rng = np.random.default_rng(9)
