@@ -191,7 +191,9 @@ def truncate_roofline(t_exact, t_one, f_exact_model, f_fused_model, t_fused):
                                     "mfma_busy_share_of_simd_cycles": c2["mfma_busy_cycles"] / simd_cycles(t_one)},
                 "model": "counted: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 and SQ_VALU_MFMA_BUSY_CYCLES per repetition (separate rocprofv3 "
                          "--pmc passes of this build, tools/collect_pmc_truncate.py) over the times measured here; the chains are "
-                         "latency-bound sequences of small factorisations, so this fraction is the honest distance to the matrix peak"}
+                         "latency-bound sequences of small factorisations, so this fraction is the honest distance to the matrix peak.  "
+                         "(Since r05 complex products issue THREE real MFMA multiplications instead of four -- Gauss's trick, DESIGN.md 3.4 --, "
+                         "so the same complex work counts 25 % fewer MFMA flops than in the r04 records at equal time.)"}
     return {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS, "source": src,
             "achieved": f_exact_model / t_exact / 1e12, "frac": f_exact_model / t_exact / 1e12 / F64_MFMA_PEAK_TFLOPS,
             "achieved_fused": f_fused_model / t_fused / 1e12,
@@ -252,7 +254,8 @@ def truncate_roofline_batch64(t_batch):
             "achieved": b["mfma_f64_flops"] / t_batch / 1e12, "frac": b["mfma_f64_flops"] / t_batch / 1e12 / F64_MFMA_PEAK_TFLOPS,
             "mfma_f64_flops_per_batch": b["mfma_f64_flops"], "dispatches_per_batch": b["dispatches"],
             "mfma_busy_share_of_simd_cycles": b["mfma_busy_cycles"] / (t_batch * 2.4e9 * 1024.0),
-            "model": "counted: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 per batch (3-repetition minus 1-repetition PMC run) over the batch time measured here"}
+            "model": "counted: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 per batch (3-repetition minus 1-repetition PMC run) over the batch time measured here "
+                     "(complex products count three real multiplications since r05, four in the r04 records)"}
 
 
 def truncate_block(qil, ctx, reps=3, cpu=True):
