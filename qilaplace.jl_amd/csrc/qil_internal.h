@@ -277,6 +277,8 @@ struct qil_gemm_batch {
 int qil_dev_gemm_batched(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
                          const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          const qil_gemm_batch* batch);
+// |r_jj|^2 (j < n <= 1024) of a triangular factor on the device, to the host
+int qil_dev_diag_abs2(qil_context* ctx, int dtype, const void* R, int64_t ldr, int64_t n, double* host_out);
 // At (n x m, ldt) = A^T (conj = 0) or A^H (conj = 1)
 int qil_dev_transpose(qil_context* ctx, int dtype, int conj, int64_t m, int64_t n, const void* A, int64_t lda,
                       void* At, int64_t ldt);

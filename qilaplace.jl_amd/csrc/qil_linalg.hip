@@ -4613,6 +4613,30 @@ int qil_dev_qr_certified(qil_context* ctx, int dtype, int64_t m, int64_t n, cons
                                   static_cast<double*>(Rout), certified);
 }
 
+// |r_jj|^2 of an n x n triangular factor on the device -> host (n <= 1024): what tells a deficient sketch's noise columns apart
+template <class T>
+__device__ __forceinline__ void diag_abs2_body(const uint3 blockIdx, const uint3 gridDim, const T* __restrict__ R, long long ldr, int n, double* __restrict__ out) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) out[j] = abs2_t(R[j + ldr * j]);
+}
+template <class T>
+struct diag_abs2_k {
+    static constexpr int NT = 256, MINW = 1;
+    template <class... QA>
+    static __device__ __forceinline__ void run(const uint3 b, const uint3 g, QA... a) {
+        diag_abs2_body<T>(b, g, a...);
+    }
+};
+int qil_dev_diag_abs2(qil_context* ctx, int dtype, const void* R, int64_t ldr, int64_t n, double* host_out) {
+    QIL_REQUIRE(n >= 1 && n <= 1024, QIL_EINVAL_ARG, "diag: n = %lld", (long long)n);
+    void* d = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * sizeof(double), &d));
+    if (dtype == QIL_C64) QIL_TRY((qil_klaunch<diag_abs2_k<c64>>(ctx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const c64*)R, (long long)ldr, (int)n, (double*)d)));
+    else QIL_TRY((qil_klaunch<diag_abs2_k<double>>(ctx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const double*)R, (long long)ldr, (int)n, (double*)d)));
+    QIL_TRY(qil_read_back(ctx, host_out, d, (size_t)n * sizeof(double)));
+    qil_ctx_free(ctx, d);
+    return QIL_OK;
+}
+
 int qil_dev_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, void* A, int64_t lda, void* R,
                         int64_t ldr, bool orthonormal) {
     QIL_REQUIRE(m >= n, QIL_EINVAL_ARG, "qr: needs m >= n (got %lld x %lld)", (long long)m, (long long)n);

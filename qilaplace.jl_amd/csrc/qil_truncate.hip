@@ -498,8 +498,8 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
                   void** right, std::vector<double>* S_out) {
     QIL_REQUIRE(m >= 1 && n >= 1, QIL_EEMPTY, "In `rsvd`, left or right index set is empty.");
     const size_t e = qil_elem_size(dt);
-    const int64_t l = std::min(std::min(k + p, m), n);  // rsvd.jl:72
-    if (l == std::min(m, n)) {
+    const int64_t l0 = std::min(std::min(k + p, m), n);  // rsvd.jl:72
+    if (l0 == std::min(m, n)) {
         // The sketch is as wide as the short side: Q spans the whole range of M and the procedure returns the exact
         // truncated SVD (up to rounding) after 2 + 2q products and 1 + 2q QRs of matrices no larger than M itself.
         // Take the SVD directly: Z = M^T = Uz Sz Vz^h  =>  U_M^T = Vz^h,  (S V_M^h)^T = Uz Sz.  Every deep split of
@@ -523,20 +523,51 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
         if (!dbg) return;
         (void)qil_stream_sync(ctx);
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[rsvd] %lld x %lld, l = %lld: %s %.2f ms\n", (long long)m, (long long)n, (long long)l, what,
+        fprintf(stderr, "[rsvd] %lld x %lld, l = %lld: %s %.2f ms\n", (long long)m, (long long)n, (long long)l0, what,
                 std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Om));
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * l) * e, &Y));
-    QIL_TRY(qil_dev_fill_normal(ctx, dt, Om, n * l, seed, 1.0));                        // rsvd.jl:74-76
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l0) * e, &Om));
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(m * l0) * e, &Y));
+    QIL_TRY(qil_dev_fill_normal(ctx, dt, Om, n * l0, seed, 1.0));                        // rsvd.jl:74-76
     lap("omega");
-    QIL_TRY(qil_dev_gemm(ctx, dt, 1, 0, m, l, n, Z, n, Om, n, Y, m));                   // Y = M Omega (:79)
+    QIL_TRY(qil_dev_gemm(ctx, dt, 1, 0, m, l0, n, Z, n, Om, n, Y, m));                   // Y = M Omega (:79)
     lap("Y = M Omega");
     // the basis that B = Q^H M and U = Q Uhat are built from (the last QR) must be orthonormal even when the sketch is
     // wider than the rank of M; the power iteration's intermediate bases only stabilise it
-    QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l, Y, m, nullptr, 0, q == 0));              // Q (:83)
-    lap("qr(Y)");
+    // Deflation of a sketch wider than the operand's numerical rank (r05).  The signals this library is for compress to bonds of
+    // 4 ... 20 while the sketch has k + p = 25 ... 133 columns: Y = M Omega then has numerical rank r << l, the columns of Q
+    // beyond a basis of range(Y) are orthonormalised rounding noise -- orthogonal to range(M), so their rows of B = Q^H M
+    // vanish to rounding and no cutoff >= 1e-24 keeps them -- and every later product and QR carried them at full price (n = 30,
+    // rank-4 signal: 6 products of 32768 x 32768 x 133 where 32768 x 32768 x 8 do).  Columns j with |r_jj| <= 1e-13 max |r_ii|
+    // leave the basis (R's diagonal is read back: one small transfer); the kept ones are a basis of range(Y) because QR without
+    // pivoting gives r_jj = 0 exactly for a column that lies in the span of its predecessors.
+    int64_t l = l0;
+    {
+        void* Rq = nullptr;
+        QIL_TRY(qil_ctx_alloc(ctx, (size_t)(l0 * l0) * e, &Rq));
+        QIL_TRY(qil_dev_qr_positive(ctx, dt, m, l0, Y, m, Rq, l0, q == 0));             // Q (:83)
+        lap("qr(Y)");
+        if (l0 <= 1024 && l0 >= 8) {
+            std::vector<double> d2((size_t)l0);
+            QIL_TRY(qil_dev_diag_abs2(ctx, dt, Rq, l0, l0, d2.data()));
+            double dmax = 0;
+            for (double v : d2) dmax = std::max(dmax, v);
+            std::vector<int64_t> keep;
+            for (int64_t j = 0; j < l0; ++j)
+                if (d2[(size_t)j] > 1e-26 * dmax && d2[(size_t)j] > 0.0) keep.push_back(j);
+            if (keep.empty()) keep.push_back(0);
+            if ((int64_t)keep.size() < l0) {
+                for (size_t t = 0; t < keep.size(); ++t)                                 // compact the kept columns to the front (usually a prefix already)
+                    if (keep[t] != (int64_t)t)
+                        QIL_TRY(qil_dev_copy(ctx, static_cast<char*>(Y) + (size_t)t * (size_t)m * e,
+                                             static_cast<const char*>(Y) + (size_t)keep[t] * (size_t)m * e, (size_t)m * e));
+                l = (int64_t)keep.size();
+                if (dbg) fprintf(stderr, "[rsvd] %lld x %lld: sketch of %lld columns has numerical rank %lld: deflated\n", (long long)m, (long long)n, (long long)l0, (long long)l);
+            }
+        }
+        qil_ctx_free(ctx, Rq);
+    }
     if (q > 0) QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * l) * e, &Zq));
     for (int it = 0; it < q; ++it) {                                                    // :86-95
         QIL_TRY(qil_dev_gemm(ctx, dt, 3, 0, n, l, m, Z, n, Y, m, Zq, n));               // M^H Q = conj(Z) Q
