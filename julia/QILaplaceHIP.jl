@@ -520,7 +520,8 @@ function gather_coefficients(comm::Comm, local_batches::Vector{Vector{ComplexF64
         loc[:, s] = v
     end
     out = Matrix{ComplexF64}(undef, width, n_items)
-    check(ccall((:qil_gather_coefficients, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}),
+    # (interleaved doubles on the C side; Ptr{Cvoid} because a Matrix{ComplexF64} does not convert to Ptr{Cdouble})
+    check(ccall((:qil_gather_coefficients, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
                 comm.h, n_items, width, loc, out))
     return permutedims(out)
 end
