@@ -94,6 +94,23 @@ def _build_c_client(tmp_path):
     return exe
 
 
+def test_host_only_c99_client_runs_without_a_gpu(tmp_path):
+    """The host-only entries of the boundary from plain C, RUN here: the layout rule of the multi-GPU gather,
+    the CPU budget, the version string and the error convention (tests/cabi_host_client.c)."""
+    import shutil
+    import subprocess
+    lib = os.path.join(ROOT, "qilaplace.jl_amd", "lib")
+    exe = os.path.join(str(tmp_path), "cabi_host_client")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cabi_host_client.c"), "-L", lib, "-lqilhip", f"-Wl,-rpath,{lib}",
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.returncode, r.stdout, r.stderr)
+
+
 def test_plain_c99_client_compiles_and_links(tmp_path):
     """The header is C (not C++): a C99 translation unit using the boundary compiles warning-free and links against
     libqilhip.so.  (It is RUN by the GPU suite.)"""
