@@ -16,22 +16,22 @@ extern "C" {
 
 /* Testing aid: the n-th pool allocation from now (0 = the next one) fails with QIL_ENOMEM; n < 0 switches the
  * injection off.  Used to check that a failing call leaves no device memory behind and its operands intact. */
-int qil_context_fail_alloc_after(qil_context* ctx, int64_t n);
+QIL_API int qil_context_fail_alloc_after(qil_context* ctx, int64_t n);
 /* Testing aid: pool bytes in use that no MPS/MPO handle owns.  Zero between calls -- every temporary is back in
  * the pool whether the last call succeeded or failed.                                                        */
-int qil_context_unowned_bytes(qil_context* ctx, int64_t* out);
+QIL_API int qil_context_unowned_bytes(qil_context* ctx, int64_t* out);
 
 /* HIP-event timing on the context's stream (hipEventRecord / hipEventElapsedTime). */
-int qil_timer_start(qil_context* ctx);
-int qil_timer_stop(qil_context* ctx, double* elapsed_ms);   /* synchronises the stop event */
+QIL_API int qil_timer_start(qil_context* ctx);
+QIL_API int qil_timer_stop(qil_context* ctx, double* elapsed_ms);   /* synchronises the stop event */
 /* Per-kernel profile: when enabled every launch of the site-contraction kernel is
  * bracketed by its own event pair; read returns launches and summed device ms since
  * the last reset (synchronises).                                                   */
-int qil_profile_enable(qil_context* ctx, int on);
-int qil_profile_read(qil_context* ctx, int64_t* n_launches, double* total_ms, int reset);
+QIL_API int qil_profile_enable(qil_context* ctx, int on);
+QIL_API int qil_profile_read(qil_context* ctx, int64_t* n_launches, double* total_ms, int reset);
 
 /* Diagnostic: device-resident time of the same GEMM (operands generated in HBM, HIP events). */
-int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
+QIL_API int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
                          int reps, double* ms_per_call);
 
 #ifdef __cplusplus

@@ -45,6 +45,17 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in the header but not exported: {missing}"
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """built with -fvisibility=hidden + a linker version script, the dynamic symbol table of the drop-in
+    library is the C ABI and nothing else -- no mangled C++ internals, no weak STL instantiations, no HIP unit ids."""
+    import subprocess
+    import qilaplace_jl_amd as qil
+    out = subprocess.run(["nm", "-D", "--defined-only", qil.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {l.split()[-1].split("@")[0] for l in out.splitlines() if l.strip()}
+    assert not [s for s in exported if s.startswith("_Z")], "mangled C++ symbols exported"
+    assert exported == set(_declared_symbols()), exported ^ set(_declared_symbols())
+
+
 def test_python_prototypes_cover_the_header():
     import importlib
     L = importlib.import_module("qilaplace_jl_amd._lib")
