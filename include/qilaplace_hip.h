@@ -300,6 +300,17 @@ QIL_API int qil_build_qft_mpo(qil_context* ctx, int64_t n, double cutoff, int64_
 QIL_API int qil_build_zt_qft_chain(qil_context* ctx, int64_t n, double cutoff, int64_t maxdim, const int64_t* site_ids,
                            qil_mpo** out, int* fallback);
 
+/* build_zt_mpo(n, wr, sites_main, sites_copy; cutoff=1e-14, maxdim=1000) src/transforms/zt_transformer.jl:41-112 for a BATCH
+ * of damping values wr[0..nb), every step on the device: the DT halves (:74, one launch, one workgroup per value) and the
+ * paired-register QFT chain (:78-99, one launch of one workgroup, built once for the whole batch) run CONCURRENTLY on two
+ * streams of the context, then per value the MPO x MPO product apply(W_dt, mpo_qft) (:103) and zip_to_compress_mpo "down"
+ * (:104; the nb compressions run as one batch).  out[nb] receives PairedSiteMPO handles (complex, 2n tensors) with the bond
+ * dimensions of a single build_zt_mpo call each.  site_ids: the 2n labels main_1, copy_1, ... of the operand (build_zt_mpo(
+ * psi::ZTMPS, wr), :107-111); NULL => 1..2n.  maxdim <= 0: no cap.  n == 1 returns the bare product (:66-70).
+ * QIL_EINVAL_ARG for n < 1 (the reference's ArgumentError, :49).                                                        */
+QIL_API int qil_build_zt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff,
+                           int64_t maxdim, const int64_t* site_ids, qil_mpo** out);
+
 /* C (m x n) = opA(A) * opB(B) on host operands, column-major; op: 0 = N, 1 = T, 2 = H, 3 = conj.
  * The f64-MFMA GEMM every contraction of the truncation/encode path goes through (the `*` of
  * mps.jl:930,947; rsvd.jl:79,89,93,98,114); exported as a utility and test hook.                */

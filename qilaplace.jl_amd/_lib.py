@@ -130,6 +130,7 @@ PROTOTYPES = {
     "qil_signal_ztmps_batch": [_vp, _pvp, _i64, _i64, _int, _int, _dbl, _i64, _i64, _i64, _int, _u64, _i64, _pvp],
     "qil_rsvd": [_vp, _vp, _i64, _i64, _int, _i64, _i64, _int, _u64, _dbl, _i64, _i64, _pi64, _vp, _pdbl, _vp],
     "qil_build_dt_mpo_batch": [_vp, _i64, _i64, _pdbl, _dbl, _i64, _pi64, _pvp],
+    "qil_build_zt_mpo_batch": [_vp, _i64, _i64, _pdbl, _dbl, _i64, _pi64, _pvp],
     "qil_build_qft_mpo": [_vp, _i64, _dbl, _i64, _pi64, _pvp, _pint],
     "qil_build_zt_qft_chain": [_vp, _i64, _dbl, _i64, _pi64, _pvp, _pint],
     "qil_gemm": [_vp, _int, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64],

@@ -285,15 +285,13 @@ def build_qft_mpo(n_or_psi, sites=None, cutoff=1e-14, maxdim=1000, ctx=None, dev
     return SingleSiteMPO(qft_mpo_tensors(n, cutoff, maxdim), sites=sites, ctx=ctx)
 
 
-_DEVICE_BUILD_MIN_N = 8      # from here on the device-assisted builders are faster than the host chain
-
-
 def build_dt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None, device=None):
-    """build_dt_mpo(n, wr, ...; cutoff, maxdim) / build_dt_mpo(psi::ZTMPS, wr; ...).  `device`: build on the GPU
-    (qil_build_dt_mpo_batch with one value; default from n = 8) or with the host chain (`dt_mpo_tensors`)."""
+    """build_dt_mpo(n, wr, ...; cutoff, maxdim) / build_dt_mpo(psi::ZTMPS, wr; ...).  Default (`device` None / True), for every n:
+    on the GPU (qil_build_dt_mpo_batch with one value); `device=False`: the host chain (`dt_mpo_tensors`, numpy) -- the
+    independent restatement the device builder is tested against."""
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
     n = _n_of(n_or_psi)
-    if device or (device is None and n >= _DEVICE_BUILD_MIN_N):
+    if device is None or device:
         return build_dt_mpo_batch(n_or_psi, [wr], cutoff, maxdim, ctx)[0]
     sites = psi.site_ids if psi is not None else None
     return PairedSiteMPO(dt_mpo_tensors(n, wr, cutoff, maxdim), sites=sites,
@@ -301,12 +299,13 @@ def build_dt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None, device=None)
 
 
 def build_zt_mpo(n_or_psi, wr, cutoff=1e-14, maxdim=1000, ctx=None, device=None):
-    """build_zt_mpo(n, wr, ...; cutoff, maxdim) / build_zt_mpo(psi::ZTMPS, wr; ...).  `device`: DT half, MPO x MPO
-    product and final compression on the GPU (build_zt_mpo_batch with one value; default from n = 8: 0.55 s instead
-    of 2.6 s at n = 24) or everything with the host chain (`zt_mpo_tensors`)."""
+    """build_zt_mpo(n, wr, ...; cutoff, maxdim) / build_zt_mpo(psi::ZTMPS, wr; ...) (zt_transformer.jl:41-112).  Default
+    (`device` None / True), for every n: ONE C verb, every step on the GPU (qil_build_zt_mpo_batch with one value: DT half and
+    paired QFT chain concurrently on two streams, MPO x MPO product, compression); `device=False`: everything with the host
+    chain (`zt_mpo_tensors`, numpy) -- the independent restatement."""
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
     n = _n_of(n_or_psi)
-    if device or (device is None and n >= _DEVICE_BUILD_MIN_N):
+    if device is None or device:
         return build_zt_mpo_batch(n_or_psi, [wr], cutoff, maxdim, ctx)[0]
     sites = psi.site_ids if psi is not None else None
     return PairedSiteMPO(zt_mpo_tensors(n, wr, cutoff, maxdim), sites=sites,
@@ -436,21 +435,42 @@ def zt_qft_chain_device(n, sites=None, cutoff=1e-14, maxdim=1000, ctx=None, pers
     return Q
 
 
-def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, workers=None, qft="host"):
-    """z-transform MPOs for a sweep of damping values with the heavy steps on the GPU: the DT halves are built
-    together (qil_build_dt_mpo_batch), the QFT half once on the host (it does not depend on the damping), and
-    per value the MPO x MPO product (zt_transformer.jl:103 -> qil_apply_mpo_mpo) and its compression
-    (zt_transformer.jl:104 -> qil_mpo_compress) run on the device -- on the host that last step alone is the
-    largest part of a build (1.4 s of 2.6 s at n = 24).  With more than one value the per-value compression chains run
-    concurrently (qil_mpo_compress_batch).  `qft="device"`: the QFT half is assembled on the GPU too
-    (`zt_qft_chain_device`; nothing but 2 x 2 gate blocks comes from the host), `"host"` (default): numpy, cached per n,
-    overlapping the device DT build."""
-    from .ops import apply, mpo_compress_batch
-    import threading
+def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, workers=None, qft="device"):
+    """z-transform MPOs for a sweep of damping values (zt_transformer.jl:41-112 per value).  Default `qft="device"`: the C verb
+    qil_build_zt_mpo_batch -- the DT halves (one launch, one workgroup per value) and the paired QFT chain (one launch, built
+    once: it does not depend on the damping) run concurrently on two streams of the context, then per value the MPO x MPO
+    product (:103) and its compression (:104; the per-value chains run as one batch).  No host linear algebra anywhere.
+    `qft="parts"`: the same steps composed from their own C entries (qil_build_dt_mpo_batch, qil_build_zt_qft_chain,
+    qil_apply_mpo_mpo, qil_mpo_compress_batch) one after another -- the cross-check of the verb; `qft="host"`: the QFT chain from
+    the numpy restatement (`zt_qft_chain_tensors`, cached per n) on a host thread next to the device DT build -- the r02-r05
+    default, kept as a comparison route.  `workers` is ignored (callers of the earliest host-thread route)."""
+    import ctypes as C
+    from . import _lib as L
+    from .containers import default_context
     psi = n_or_psi if hasattr(n_or_psi, "handle") else None
     n = _n_of(n_or_psi)
     if n < 1:
         raise ValueError(f"build_zt_mpo: n must be >= 1. Found n={n}")
+    if qft not in ("host", "device", "parts"):
+        raise ValueError(f"build_zt_mpo_batch: qft must be 'device', 'parts' or 'host', got {qft!r}")
+    if qft != "device":
+        return _build_zt_mpo_batch_parts(n_or_psi, wrs, cutoff, maxdim, ctx, qft)
+    ctx = ctx or (psi.ctx if psi is not None else default_context())
+    w = np.ascontiguousarray(np.asarray(list(wrs), dtype=np.float64))
+    outs = (C.c_void_p * len(w))()
+    ids = None
+    if psi is not None:                      # build_zt_mpo(psi::ZTMPS, ...) builds on psi's own sites (:107-111)
+        ids = (C.c_int64 * (2 * n))(*[int(i) for i in psi.site_ids])
+    L.check(L.lib.qil_build_zt_mpo_batch(ctx.handle, int(n), len(w), w.ctypes.data_as(C.POINTER(C.c_double)),
+                                         float(cutoff), -1 if maxdim is None else int(maxdim), ids, outs))
+    return [PairedSiteMPO(ctx=ctx, _handle=C.c_void_p(h)) for h in outs]
+
+
+def _build_zt_mpo_batch_parts(n_or_psi, wrs, cutoff, maxdim, ctx, qft):
+    """The steps of qil_build_zt_mpo_batch from their own entry points (see build_zt_mpo_batch)."""
+    from .ops import apply, mpo_compress_batch
+    import threading
+    n = _n_of(n_or_psi)
     # the host-side QFT half (numpy, GIL released inside LAPACK) is built while the GPU builds the DT halves
     box = {}
 
@@ -460,8 +480,6 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, worke
         except Exception as e:                      # noqa: BLE001  (re-raised on the calling thread)
             box["err"] = e
 
-    if qft not in ("host", "device"):
-        raise ValueError(f"build_zt_mpo_batch: qft must be 'host' or 'device', got {qft!r}")
     th = threading.Thread(target=_host_half)
     if qft == "host":
         th.start()
@@ -474,12 +492,9 @@ def build_zt_mpo_batch(n_or_psi, wrs, cutoff=1e-14, maxdim=1000, ctx=None, worke
         raise box["err"]
     home = dts[0].ctx
     ids = dts[0].site_ids
-    Q = (zt_qft_chain_device(n, ids, cutoff, maxdim, home) if qft == "device"
+    Q = (zt_qft_chain_device(n, ids, cutoff, maxdim, home) if qft == "parts"
          else PairedSiteMPO(box["Q"], sites=ids, ctx=home))
     prods = [apply(W_dt, Q) for W_dt in dts]
     if n == 1:
         return prods
-    # The compression of a product is a chain of ~100 small dependent factorisations: latency-bound on one stream, the GPU
-    # mostly idle.  The values are independent, so the chains run concurrently on the context's worker streams
-    # (qil_mpo_compress_batch; `workers` is kept for callers of the earlier host-thread route and ignored).
     return mpo_compress_batch(prods, "down", cutoff, maxdim)

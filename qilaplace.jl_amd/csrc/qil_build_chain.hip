@@ -690,6 +690,42 @@ int qil_build_chain_persistent(qil_context* ctx, int kind, int64_t n, double cut
     return QIL_OK;
 }
 
+// The paired QFT chain by the GENERIC device route (layers of qil_apply_mpo_mpo + qil_mpo_compress "down"): what the persistent
+// kernel's callers take when a bond exceeds its in-LDS capacity (cutoffs far below the reference's default, chains longer than
+// CB_MAXL).  zt_transformer.jl:78-99: block k acts on sites 1..2k, the chain is extended by an identity pair first -- the window
+// product of apply(W1, W2) pads the shorter operand exactly like that (apply.jl:141-147).
+int qil_build_zt_qft_chain_generic(qil_context* ctx, int64_t n, double cutoff, int64_t maxdim, const int64_t* site_ids, qil_mpo** out) {
+    std::vector<int64_t> ids((size_t)(2 * n));
+    for (int64_t i = 0; i < 2 * n; ++i) ids[(size_t)i] = site_ids ? site_ids[i] : i + 1;
+    auto upload = [&](const std::vector<Blk>& b, qil_mpo** W) {
+        const int64_t L = (int64_t)b.size();
+        std::vector<int64_t> bonds((size_t)std::max<int64_t>(L - 1, 1), 1);
+        std::vector<const void*> ptrs((size_t)L);
+        for (int64_t i = 0; i < L; ++i) {
+            if (i + 1 < L) bonds[(size_t)i] = b[(size_t)i].dr;
+            ptrs[(size_t)i] = b[(size_t)i].w;                      // Blk::w is the stored layout W[a + dl (io + 4 b)], packed
+        }
+        return qil_mpo_create(ctx, L, QIL_C64, 1, bonds.data(), ids.data(), ptrs.data(), W);
+    };
+    qil_mpo* Q = nullptr;
+    QIL_TRY(upload(zt_block(1), &Q));
+    for (int k = 2; k <= n; ++k) {
+        qil_mpo *B = nullptr, *P = nullptr;
+        int st = upload(zt_block(k), &B);
+        if (st == QIL_OK) st = qil_apply_mpo_mpo(Q, B, &P);
+        if (B) qil_mpo_destroy(B);
+        qil_mpo_destroy(Q);
+        Q = P;
+        if (st == QIL_OK) st = qil_mpo_compress(Q, 0, cutoff, maxdim);
+        if (st != QIL_OK) {
+            if (Q) qil_mpo_destroy(Q);
+            return st;
+        }
+    }
+    *out = Q;
+    return QIL_OK;
+}
+
 // build_qft_mpo(n, sites; cutoff, maxdim) on the device (qft_transformer.jl:121-165)
 extern "C" int qil_build_qft_mpo(qil_context* ctx, int64_t n, double cutoff, int64_t maxdim, const int64_t* site_ids, qil_mpo** out,
                                  int* fallback) {

@@ -25,8 +25,9 @@ class Comm:
 
     ``Comm(ctx, rank, world, uid)`` is collective (every rank, same 128-byte ``uid`` from ``Comm.unique_id()`` on rank 0).
     ``Comm.from_env(ctx)`` reads RANK / WORLD_SIZE and passes the id through a file: rank 0 writes
-    ``$QIL_COMM_FILE`` (default ``<tmpdir>/qil_comm_<uid>_<MASTER_PORT>_<launcher pid>.id``, mode 0600) atomically, the others wait for it --
-    one node, one shared /tmp: the scope of SURVEY.md 8(e)."""
+    ``$QIL_COMM_FILE`` (default ``<tmpdir>/qil_comm_<uid>_<MASTER_PORT>_<QIL_COMM_TAG or launcher pid>.id``, mode 0600) atomically --
+    the id plus its own pid and start time -- and the others wait for a record whose writer is alive (a stale file of a crashed
+    job is never accepted).  One node, one shared /tmp and /proc: the scope of SURVEY.md 8(e)."""
 
     def __init__(self, ctx, rank: int, world: int, uid: bytes):
         if len(uid) != COMM_ID_BYTES:
@@ -43,29 +44,72 @@ class Comm:
         L.check(L.lib.qil_comm_unique_id(C.cast(buf, C.c_void_p)))
         return buf.raw
 
+    @staticmethod
+    def _proc_start_ticks(pid: int):
+        """Start time of a live process in clock ticks since boot (/proc/<pid>/stat field 22), None if it is gone / no procfs."""
+        try:
+            with open(f"/proc/{int(pid)}/stat", "rb") as f:
+                return int(f.read().rsplit(b")", 1)[1].split()[19])
+        except (OSError, ValueError, IndexError):
+            return None
+
+    @classmethod
+    def _rendezvous_path(cls):
+        import tempfile
+        return os.environ.get("QIL_COMM_FILE") or os.path.join(
+            tempfile.gettempdir(), f"qil_comm_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('QIL_COMM_TAG', os.getppid())}.id")
+
+    @classmethod
+    def _read_rendezvous(cls, path):
+        """The id rank 0 published at `path`, or None while there is nothing TRUSTWORTHY there.  The record is the 128-byte id
+        followed by the writer's pid and process start time; a record is accepted only if it is ours (st_uid), complete, and its
+        writer is still alive with that start time -- a file left behind by a crashed earlier job under the same key (same uid,
+        MASTER_PORT and launcher pid: ADVICE r05) names a dead process and is ignored until rank 0 replaces it."""
+        import struct
+        try:
+            st = os.stat(path)
+            if st.st_uid != os.getuid() or st.st_size != COMM_ID_BYTES + 16:
+                return None
+            with open(path, "rb") as f:
+                rec = f.read()
+        except OSError:
+            return None
+        if len(rec) != COMM_ID_BYTES + 16:
+            return None
+        pid, ticks = struct.unpack("<qq", rec[COMM_ID_BYTES:])
+        alive = cls._proc_start_ticks(pid)
+        if os.path.isdir("/proc/self") and alive != ticks:
+            return None
+        return rec[:COMM_ID_BYTES]
+
     @classmethod
     def from_env(cls, ctx, timeout_s: float = 120.0):
+        """Every rank calls this (RANK / WORLD_SIZE from the launcher).  Rank 0 creates the id and publishes it in a file keyed by
+        (uid, MASTER_PORT, QIL_COMM_TAG or the launcher's pid); two jobs that run at the same time under one launcher shell with
+        the same MASTER_PORT need distinct QIL_COMM_TAG values (bench.py's spawner sets one per job)."""
+        import struct
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         if world == 1:
             return cls(ctx, 0, 1, cls.unique_id())
-        import tempfile
-        path = os.environ.get("QIL_COMM_FILE") or os.path.join(
-            tempfile.gettempdir(), f"qil_comm_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('QIL_COMM_TAG', os.getppid())}.id")
+        path = cls._rendezvous_path()
         if rank == 0:
             uid = cls.unique_id()
-            tmp = f"{path}.{os.getpid()}.tmp"
+            me = os.getpid()
+            rec = uid + struct.pack("<qq", me, cls._proc_start_ticks(me) or 0)
+            tmp = f"{path}.{me}.tmp"
             fd = os.open(tmp, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)      # never through somebody else's file or link
             with os.fdopen(fd, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, path)
+                f.write(rec)
+            os.replace(tmp, path)                                              # atomically over whatever was there
         else:
             t0 = time.monotonic()
-            while not (os.path.exists(path) and os.path.getsize(path) == COMM_ID_BYTES):
+            while True:
+                uid = cls._read_rendezvous(path)
+                if uid is not None:
+                    break
                 if time.monotonic() - t0 > timeout_s:
-                    raise TimeoutError(f"Comm.from_env: rank 0 never wrote {path}")
+                    raise TimeoutError(f"Comm.from_env: rank 0 never published a live id at {path}")
                 time.sleep(0.01)
-            with open(path, "rb") as f:
-                uid = f.read()
         comm = cls(ctx, rank, world, uid)              # collective: every rank has read the file when this returns
         if rank == 0:
             try:

@@ -1704,6 +1704,65 @@ def test_persistent_qft_builders(qil, pins):
     assert qil.default_context().unowned_bytes() == 0
 
 
+def test_build_zt_mpo_one_verb_all_device(qil, pins):
+    """build_zt_mpo (zt_transformer.jl:41-112) behind ONE C verb with every step on the device
+    (qil_build_zt_mpo_batch: DT half and paired QFT chain concurrently on two streams, product, compression) is the DEFAULT of
+    build_zt_mpo / build_zt_mpo_batch for every n.  Against the ORACLE's builder: dense operator for n <= 6 (1e-12) with equal
+    bond dimensions, sampled coefficients of W psi at n = 12 (1e-9); the three routes (verb / its parts from their own entries /
+    numpy QFT half) give the same bonds; the chain's generic fallback (bond beyond the in-LDS capacity at cutoff 1e-30); batches
+    of 2 (streams) and 6 (lock-step) values equal the single builds bit for bit; labels; argument errors."""
+    from helpers import dense_mpo
+    import inspect
+    assert inspect.signature(qil.build_zt_mpo_batch).parameters["qft"].default == "device"
+    for n in (1, 2, 3, 4, 5, 6):
+        for wr in (2 * np.pi, 0.4):
+            W = qil.build_zt_mpo(n, wr)                                    # default route = the verb
+            ref = O.build_zt_mpo(n, wr)
+            assert W.paired and len(W.to_host()) == 2 * n and W.bond_dims == ref.bond_dims, (n, wr, W.bond_dims, ref.bond_dims)
+            assert np.abs(dense_mpo(W.to_host()) - dense_mpo(ref.data)).max() < 1e-12, (n, wr)
+    series = pins["mpo_maxbond_n2_30"]["zt"]
+    for n in (2, 3, 4, 5, 6, 7, 8):
+        W = qil.build_zt_mpo(n, 2 * np.pi, cutoff=1e-15, maxdim=None)       # the artifact's settings
+        assert max(W.bond_dims) == series[n - 2], (n, W.bond_dims)
+    # n = 12: sampled coefficients of W psi against the oracle's operator on the same state, and the three routes' bonds
+    n = 12
+    rng = np.random.default_rng(1206)
+    a = random_mps_data(saturated_profile(2 * n, 8), rng)
+    ids = [100 + 3 * i for i in range(2 * n)]
+    psi = qil.ZTMPS(a, sites=ids)
+    bits = rng.integers(0, 2, size=(256, 2 * n))
+    for wr in (2 * np.pi, 0.7):
+        W = qil.build_zt_mpo(psi, wr)
+        assert W.site_ids == ids and W.ctx is psi.ctx
+        Wo = O.build_zt_mpo(n, wr)
+        assert W.bond_dims == Wo.bond_dims
+        want = O.coefficient_batch(O.apply(Wo, O.ZTMPS(a)), bits)
+        assert rel(qil.coefficient_batch(W * psi, bits), want) < 1e-9
+        for route in ("parts", "host"):
+            assert qil.build_zt_mpo_batch(psi, [wr], qft=route)[0].bond_dims == W.bond_dims, route
+    # a cap that binds, like the reference's maxdim
+    Wc = qil.build_zt_mpo(8, 2 * np.pi, maxdim=12)
+    assert max(Wc.bond_dims) <= 12 and Wc.bond_dims == [t.shape[3] for t in qil.zt_mpo_tensors(8, 2 * np.pi, 1e-14, 12)[:-1]]
+    # the paired chain's generic route inside the verb (nothing is dropped at cutoff 1e-30: bonds exceed the kernel's capacity)
+    n = 5
+    Wg = qil.build_zt_mpo(n, 1.3, cutoff=1e-30, maxdim=None)
+    Wh = qil.zt_mpo_tensors(n, 1.3, 1e-30, None)
+    assert np.abs(dense_mpo(Wg.to_host()) - dense_mpo(Wh)).max() < 1e-12
+    # batches: one QFT chain shared by every value; 2 values (streams) and 6 (lock-step groups) equal the single builds
+    for wrs in ([0.5, 7.0], [0.25, 1.0, 2 * np.pi, 9.0, 12.0, 15.5]):
+        Ws = qil.build_zt_mpo_batch(6, wrs)
+        for W, wr in zip(Ws, wrs):
+            one = qil.build_zt_mpo(6, wr)
+            assert W.bond_dims == one.bond_dims
+            for tb, t1 in zip(W.to_host(), one.to_host()):
+                assert np.array_equal(tb, t1)
+    with pytest.raises(ValueError, match="n must be >= 1"):
+        qil.build_zt_mpo(0, 1.0)
+    with pytest.raises(ValueError, match="qft must be"):
+        qil.build_zt_mpo_batch(3, [1.0], qft="gpu")
+    assert qil.default_context().unowned_bytes() == 0
+
+
 def test_failed_calls_leave_no_device_memory_behind(qil):
     """Error-path reclamation: whichever allocation inside a call fails, the pool's in-use byte count returns to
     what the live handles account for, in-place operands stay usable, and the same call succeeds afterwards."""
@@ -1736,6 +1795,7 @@ def test_failed_calls_leave_no_device_memory_behind(qil):
             ("build_dt_mpo_batch", lambda: qil.build_dt_mpo_batch(4, [0.5, 1.5])),
             ("build_qft_mpo (persistent chain builder)", lambda: qil.build_qft_mpo(6)),
             ("zt_qft_chain_device (persistent chain builder)", lambda: qil.zt_qft_chain_device(4)),
+            ("build_zt_mpo_batch (one verb, two streams)", lambda: qil.build_zt_mpo_batch(3, [0.5, 1.5])),
         ]
 
     names = [n for n, _ in ops(None, None, None)]
