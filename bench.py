@@ -573,6 +573,9 @@ def run_apply(args, rk):
     else:
         W = mpo_cls.alloc(db, dtype=np.complex128, ctx=ctx).fill_random(777)
     abytes = algorithmic_bytes(cb, db)
+    # the box's own store-only ceiling (8 GiB x 5 by four writers, < 0.1 s, same process, before the timed region): fractions
+    # measured on different boxes of the pool become comparable
+    box_peak, box_writer = ctx.hbm_store_peak(8 << 30 if args.workload != "tiny" else 1 << 28, 5)
 
     out = None
     for _ in range(args.warmup):
@@ -646,6 +649,8 @@ def run_apply(args, rk):
         "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<c64,double>",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+                     "box_store_peak": box_peak, "box_store_peak_writer": box_writer,
+                     "frac_of_box_store_peak": achieved / box_peak if box_peak > 0 else None,
                      "traffic": traffic, "traffic_source": tsrc, "kernel_ms": k_ms, "launches_timed": n_launch,
                      "algorithmic_bytes_per_launch": abytes},
     }

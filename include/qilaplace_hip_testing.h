@@ -30,6 +30,12 @@ QIL_API int qil_timer_stop(qil_context* ctx, double* elapsed_ms);   /* synchroni
 QIL_API int qil_profile_enable(qil_context* ctx, int on);
 QIL_API int qil_profile_read(qil_context* ctx, int64_t* n_launches, double* total_ms, int reset);
 
+/* Diagnostic: the store-only HBM ceiling of THIS GPU -- `bytes` (>= 64 MiB) written `reps` times by each of four writers
+ * (hipMemsetAsync, 256 KiB span per workgroup with plain / non-temporal stores, grid-stride fill), HIP events; the best rate
+ * in GB/s and which writer reached it (0..3).  bench.py prints it beside the apply's roofline fraction so that lines measured
+ * on different boxes of a pool can be compared.                                                                         */
+QIL_API int qil_hbm_store_peak(qil_context* ctx, int64_t bytes, int reps, double* best_gbs, int* best_kind);
+
 /* Diagnostic: device-resident time of the same GEMM (operands generated in HBM, HIP events). */
 QIL_API int qil_gemm_device_time(qil_context* ctx, int dtype, int opA, int opB, int64_t m, int64_t n, int64_t k,
                          int reps, double* ms_per_call);

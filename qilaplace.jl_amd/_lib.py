@@ -136,6 +136,7 @@ PROTOTYPES = {
     "qil_gemm": [_vp, _int, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64],
     "qil_qr_positive": [_vp, _int, _i64, _i64, _vp, _vp, _vp],
     "qil_gemm_device_time": [_vp, _int, _int, _int, _i64, _i64, _i64, _int, _pdbl],
+    "qil_hbm_store_peak": [_vp, _i64, _int, _pdbl, _pint],
     "qil_svd_trunc": [_vp, _vp, _i64, _i64, _int, _dbl, _i64, _i64, _pi64, _vp, _pdbl, _vp],
     "qil_comm_unique_id": [_vp],
     "qil_comm_create": [_vp, _int, _int, _vp, _pvp],

@@ -44,6 +44,12 @@ class Context:
         L.check(L.lib.qil_context_unowned_bytes(self.handle, C.byref(v)))
         return v.value
 
+    def hbm_store_peak(self, nbytes=8 << 30, reps=5):
+        """Diagnostic (qil_hbm_store_peak): this GPU's store-only HBM ceiling in GB/s and the writer that reached it."""
+        g, k = C.c_double(), C.c_int()
+        L.check(L.lib.qil_hbm_store_peak(self.handle, int(nbytes), int(reps), C.byref(g), C.byref(k)))
+        return g.value, ("hipMemsetAsync", "span256KiB_plain", "span256KiB_nt", "grid_stride_plain")[k.value]
+
     def fail_alloc_after(self, n):
         """Testing aid: make the n-th pool allocation from now fail (None / negative: off)."""
         L.check(L.lib.qil_context_fail_alloc_after(self.handle, -1 if n is None else int(n)))

@@ -382,9 +382,19 @@ static int apply_new(const qil_mpo* W, const qil_mps* psi, qil_mps** out, bool s
     return QIL_OK;
 }
 
+static int apply_mpo_mpo_impl(const qil_mpo* W1, const qil_mpo* W2, qil_mpo** out, bool shared_second);
+
 extern "C" int qil_apply_mpo_mpo(const qil_mpo* W1, const qil_mpo* W2, qil_mpo** out) {
+    return apply_mpo_mpo_impl(W1, W2, out, false);
+}
+
+// the product in W1's context while W2 lives in another context of the same device, read-only for the duration of the call
+// (the items of a build_zt_mpo batch share ONE paired QFT chain; the batch's `ready` event orders the slots behind its producer)
+int qil_apply_mpo_mpo_shared(const qil_mpo* W1, const qil_mpo* W2, qil_mpo** out) { return apply_mpo_mpo_impl(W1, W2, out, true); }
+
+static int apply_mpo_mpo_impl(const qil_mpo* W1, const qil_mpo* W2, qil_mpo** out, bool shared_second) {
     QIL_REQUIRE(W1 && W2 && out, QIL_EINVAL_ARG, "apply: null handle");
-    QIL_REQUIRE(W1->ctx == W2->ctx, QIL_EINVAL_ARG, "apply: MPOs belong to different contexts");
+    QIL_REQUIRE(shared_second || W1->ctx == W2->ctx, QIL_EINVAL_ARG, "apply: MPOs belong to different contexts");
     QIL_REQUIRE(W1->paired == W2->paired, QIL_EINVAL_ARG, "apply: cannot mix paired and single-site MPOs");
     qil_context* ctx = W1->ctx;
     QIL_TRY(qil_ctx_activate(ctx));

@@ -18,6 +18,7 @@
 
 int qil_build_chain_persistent(qil_context* ctx, int kind, int64_t n, double cutoff, int64_t maxdim, const int64_t* site_ids,
                                qil_mpo** out, int* fallback);
+int qil_apply_mpo_mpo_shared(const qil_mpo* W1, const qil_mpo* W2, qil_mpo** out);
 int qil_build_zt_qft_chain_generic(qil_context* ctx, int64_t n, double cutoff, int64_t maxdim, const int64_t* site_ids, qil_mpo** out);
 
 extern "C" int qil_build_zt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff,
@@ -51,15 +52,26 @@ extern "C" int qil_build_zt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, c
         drop();
         return st;
     }
-    // :103 -- "W_dt first, then the QFT chain": W_dt's output leg feeds the chain's input leg (apply.jl:163-171)
-    for (int64_t b = 0; b < nb && st == QIL_OK; ++b) {
-        st = qil_apply_mpo_mpo(dts[(size_t)b], Q, &prods[(size_t)b]);
-        qil_mpo_destroy(dts[(size_t)b]);
-        dts[(size_t)b] = nullptr;
+    // :103 -- "W_dt first, then the QFT chain": W_dt's output leg feeds the chain's input leg (apply.jl:163-171) -- and :104
+    // (n == 1 returns the bare product, :66-70).  One value: on the context's stream.  Several: value b's product AND its
+    // compression form one chain of the batch, on the slot that owns W_dt[b]; the QFT chain stays in the home context and is
+    // read by every slot (64 values: the 64 x 48 product launches no longer queue up on one stream ahead of the batch).
+    auto finish = [&](int64_t b) -> int {
+        qil_mpo* P = nullptr;
+        QIL_TRY(qil_apply_mpo_mpo_shared(dts[(size_t)b], Q, &P));
+        prods[(size_t)b] = P;
+        if (n > 1) QIL_TRY(qil_mpo_compress(P, 0, cutoff, maxdim));
+        return QIL_OK;
+    };
+    if (nb == 1) {
+        st = finish(0);
+    } else {
+        st = qil_run_batch_on(
+            ctx, nb, [&](int64_t b, qil_context* slot) { qil_chain_rebind(dts[(size_t)b], slot); },
+            [&](int64_t b, qil_context*) { return finish(b); });
     }
-    // :104 (n == 1 returns the bare product, :66-70)
-    if (st == QIL_OK && n > 1)
-        st = nb == 1 ? qil_mpo_compress(prods[0], 0, cutoff, maxdim) : qil_mpo_compress_batch(prods.data(), nb, 0, cutoff, maxdim);
+    for (auto& W : dts)
+        if (W) qil_mpo_destroy(W), W = nullptr;
     if (st != QIL_OK) {
         drop();
         return st;

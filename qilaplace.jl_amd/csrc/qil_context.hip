@@ -367,6 +367,69 @@ extern "C" int qil_timer_stop(qil_context* ctx, double* ms) {
     return QIL_OK;
 }
 
+// ---- the box's own store-only ceiling: what a kernel that does nothing but write 16 B per lane reaches on
+// THIS GPU, so that a roofline fraction measured on one box of the pool can be compared with one measured on another (the
+// apply's figure moved 0.78 ... 0.85 of the 8 TB/s spec between boxes in r05).  Four writers, the best one is reported:
+// hipMemsetAsync, one contiguous 256 KiB span per workgroup with plain / non-temporal stores, a grid-stride fill.
+namespace {
+typedef double qil_fill_d2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__global__ __launch_bounds__(256) void hbm_fill_span(qil_fill_d2* __restrict__ p, long long span, double v) {
+    const qil_fill_d2 val{v, v + 1.0};
+    qil_fill_d2* q = p + blockIdx.x * span;
+    for (long long i = threadIdx.x; i < span; i += 256) {
+        if (NT) __builtin_nontemporal_store(val, q + i);
+        else q[i] = val;
+    }
+}
+__global__ __launch_bounds__(256) void hbm_fill_stride(qil_fill_d2* __restrict__ p, long long n, double v) {
+    const qil_fill_d2 val{v, v + 1.0};
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = val;
+}
+}  // namespace
+
+extern "C" int qil_hbm_store_peak(qil_context* ctx, int64_t bytes, int reps, double* best_gbs, int* best_kind) {
+    QIL_REQUIRE(ctx && best_gbs, QIL_EINVAL_ARG, "qil_hbm_store_peak: null argument");
+    QIL_REQUIRE(bytes >= (1 << 26) && reps >= 1 && reps <= 100, QIL_EINVAL_ARG, "qil_hbm_store_peak: bytes >= 64 MiB, 1 <= reps <= 100");
+    QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
+    const long long span = 256 * 1024 / 16;                           // 16-B elements per workgroup span
+    const long long n = bytes / 16 / span * span;
+    void* buf = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)n * 16, &buf));
+    qil_fill_d2* d = static_cast<qil_fill_d2*>(buf);
+    hipStream_t s = qil_stream(ctx);
+    auto launch = [&](int kind) {
+        switch (kind) {
+            case 0: (void)hipMemsetAsync(d, 0, (size_t)n * 16, s); break;
+            case 1: hipLaunchKernelGGL(hbm_fill_span<false>, dim3((unsigned)(n / span)), dim3(256), 0, s, d, span, 1.0); break;
+            case 2: hipLaunchKernelGGL(hbm_fill_span<true>, dim3((unsigned)(n / span)), dim3(256), 0, s, d, span, 1.0); break;
+            default: hipLaunchKernelGGL(hbm_fill_stride, dim3(32768), dim3(256), 0, s, d, n, 1.0); break;
+        }
+    };
+    double best = 0.0;
+    int which = 0;
+    for (int kind = 0; kind < 4; ++kind) {
+        launch(kind);                                                 // untimed first touch
+        QIL_HIP(hipEventRecord(ctx->t0, s));
+        for (int r = 0; r < reps; ++r) launch(kind);
+        QIL_HIP(hipEventRecord(ctx->t1, s));
+        QIL_HIP(hipEventSynchronize(ctx->t1));
+        QIL_HIP(hipGetLastError());
+        float ms = 0.f;
+        QIL_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+        const double gbs = ms > 0 ? (double)n * 16 * reps / (ms * 1e-3) / 1e9 : 0.0;
+        if (gbs > best) {
+            best = gbs;
+            which = kind;
+        }
+    }
+    qil_ctx_free(ctx, buf);
+    *best_gbs = best;
+    if (best_kind) *best_kind = which;
+    return QIL_OK;
+}
+
 extern "C" int qil_profile_enable(qil_context* ctx, int on) {
     QIL_REQUIRE(ctx, QIL_EINVAL_ARG, "null context");
     ctx->profile = on != 0;

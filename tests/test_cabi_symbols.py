@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 TESTING_HOOKS = {"qil_context_fail_alloc_after", "qil_context_unowned_bytes", "qil_timer_start", "qil_timer_stop",
-                 "qil_profile_enable", "qil_profile_read", "qil_gemm_device_time"}
+                 "qil_profile_enable", "qil_profile_read", "qil_gemm_device_time", "qil_hbm_store_peak"}
 
 
 def _symbols_of(header):
