@@ -11,6 +11,9 @@ RCCL is used only for the barrier, the max-over-ranks time and the final gather 
 `--workload dt_sweep_n24_s64` (BASELINE.json configs[3]): a step is one whole damping sweep -- 64 DT MPOs built
 by the persistent device builder, applied to one encoded n=24 signal and sampled at 1024 configurations each --
 with the 64 values dealt round-robin to the ranks (strong scaling) and one RCCL all_gather of the samples.
+`--workload dt_sweep_n24_weak`: the same sweep with 64 values PER RANK (64 N values in all, weak scaling): the builder launch
+is one chain's latency whatever the share (one workgroup per value, up to one per CU), so the strong-scaling form is expected
+to give ~1.05x at 8 GPUs (`expected_speedup_at_8` in its line) while this one scales with the number of values.
 
 `python bench.py --gpus N` without a launcher starts the N ranks itself (before anything touches the GPU).
 
@@ -49,6 +52,8 @@ WORKLOADS = {
     "tiny": (12, False, 16, 32, "debug size"),
     "dt_sweep_n24_s64": (48, True, 0, 0, "n=24 signal x 64 damping values: build_dt_mpo sweep, apply, 1024 samples each "
                                         "(configs[3]); values dealt round-robin to the ranks"),
+    "dt_sweep_n24_weak": (48, True, 0, 0, "n=24 signal x 64 damping values PER RANK (64 N values in linspace(0.25, 16) dealt round-robin): "
+                                         "the axis of configs[3] that scales -- one builder launch per rank whatever its share"),
 }
 
 
@@ -444,9 +449,10 @@ def spawn_ranks(n):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    tag = f"bench{os.getpid()}_{int(time.time() * 1e6) & 0xffffffff:08x}"     # per-job nonce of the C ABI's file rendezvous (sweep.Comm.from_env)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QIL_COMM_TAG=tag)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -466,6 +472,7 @@ class Ranks:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.world_hint = self.world     # known before any communicator exists (sizes the weak-scaling workload)
         self.dist = None
         self.backend = os.environ.get("QIL_BENCH_BACKEND", "nccl")
         self.comm = None                 # QIL_BENCH_BACKEND=cabi: the C ABI's own RCCL communicator (qil_comm_*), no torch at all
@@ -682,7 +689,9 @@ def run_sweep(args, rk):
     ctx = qil.Context(rk.local_rank)
     qil.set_default_context(ctx)
     import bench_configs
-    n, N, nsig, nsamp = 24, 2 ** 24, 64, 1024
+    weak = args.workload == "dt_sweep_n24_weak"
+    n, N, nsamp = 24, 2 ** 24, 1024
+    nsig = 64 * (rk.world_hint if weak else 1)       # weak: 64 values per rank
     x = bench_configs.cfg4_signal(n)                         # :multi_sin_exp-like structured signal (Signals.jl:64-85)
     psi = qil.signal_ztmps(x, method="rsvd", k=15, p=5, q=2, cutoff=1e-12)
     sig = np.linspace(0.25, 16.0, nsig)
@@ -716,6 +725,7 @@ def run_sweep(args, rk):
     achieved = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     # what bounds the step: the per-value builder chain (one launch of dt_build_persistent per sweep), timed here with
     # host clocks around a synchronised build of this rank's share (the kernel is >= 99 % of it, profiles/r03_kernel_stats_dt_sweep*)
+    xnorm = float(np.linalg.norm(x))
     share = [sig[i] for i in range(rk.rank, nsig, rk.world)]
     tb = []
     for _ in range(3):
@@ -759,20 +769,24 @@ def run_sweep(args, rk):
         "metric": "MPO×MPS site-contractions/sec + max |coeff err|, n=24 damping sweep (configs[3])",
         "value": nsig * 2 * n / (elapsed / args.steps), "unit": "site-contractions/s",
         "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "description": WORKLOADS[args.workload][4], "sites": 2 * n,
                    "damping_values": nsig, "samples_per_value": nsamp, "mps_bonds_max": max(psi.bond_dims),
                    "mpo_bonds_max": max(max(W.bond_dims) for W in Ws),
-                   "parallelism": f"64 damping values round-robin over {rk.world} rank(s), one all_gather",
+                   "parallelism": f"{nsig} damping values round-robin over {rk.world} rank(s), one all_gather",
                    "ranks_reported_by_collective_backend": rk.world, "collective_backend": rk.backend_used,
                    "values_per_rank": [len(range(r, nsig, rk.world)) for r in range(rk.world)],
                    "lib_sha16": lib_sha16()},
         # parity figure = HIP against the CPU restatement of the reference's algorithm on the same operands (when that leg ran);
         # the distance to the closed form is the ALGORITHM's own MPO-truncation error at the reference's default cutoff 1e-14
         # (3.5e-5 of the peak at sigma = 0.25, the numpy oracle shows the same value to five digits)
-        "max_coeff_err": cpu["hip_vs_cpu_max_err_rel_to_signal_peak"] if cpu else err,
-        "max_coeff_err_kind": ("HIP vs CPU oracle (oracle.build_dt_mpo + apply) on 4 of the 64 damping values, relative to the signal peak"
-                               if cpu else "vs closed form x_j exp(-sigma k j / N) / sqrt(N), relative to the signal peak"),
+        # ONE meaning on every run -- the distance to the closed form; the parity figure has its own key
+        "max_coeff_err": err,
+        "max_coeff_err_kind": "vs closed form x_j exp(-sigma k j / N) / sqrt(N), relative to the signal peak, all values x samples",
+        # ... and in the reference's normalisation (unit-norm input, absolute error: test/test_dt_transformer.jl:234-235, bound 1e-7)
+        "max_coeff_err_unit_norm_signal": err * peak / xnorm,
+        "parity_err_vs_oracle": cpu["hip_vs_cpu_max_err_rel_to_signal_peak"] if cpu else None,
+        "parity_err_vs_oracle_kind": "HIP vs CPU oracle (oracle.build_dt_mpo + apply) on 4 of the damping values, same samples, relative to the signal peak (null: CPU leg not run)",
         "coeff_err": {"vs_closed_form_rel_to_signal_peak": err, "queries": nsig * nsamp,
                       "vs_closed_form_note": "the operator's own truncation at MPO cutoff 1e-14 (identical in the numpy oracle); converges with the "
                                              "cutoff: 2.8e-7 at 1e-18, 1.4e-8 at 1e-22 (tests/test_gpu_parity.py::test_config4_damping_sweep_full_size leg c)",
@@ -787,6 +801,12 @@ def run_sweep(args, rk):
                      "workgroups": len(share), "cu_share": len(share) / 256.0,
                      # one launch of 8 / 64 / 256 values -- the launch is as long as its slowest chain up to one value per CU
                      "builder_launch_ms_by_values": by_values},
+        # strong scaling of configs[3], stated before anybody measures it: T(N) = builder launch (one chain's latency, the same for
+        # 64 / N values) + the rest of this step / N.  No scaling curve has been measured (no multi-GPU node in r01-r06).
+        "expected_speedup_at_8": (None if weak or rk.world != 1 else
+                                  (elapsed / args.steps) / (t_build + max(elapsed / args.steps - t_build, 0.0) / 8.0)),
+        "expected_speedup_model": "T(N) = t_builder_launch + (T(1) - t_builder_launch) / N, from this run's N = 1 figures" if not weak else
+                                  "weak: T(N) = T(1) (64 values per rank, one builder launch per rank)",
         "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<double,double> (the sweep's apply launches; the step is "
                      "dominated by the latency-bound dt_build_persistent chain, see bound_by and DESIGN.md 3.6)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -808,7 +828,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (cfg2 / cfg4 / cfg5 + read-out roofline)")
     ap.add_argument("--random-mpo", action="store_true", help="seeded random MPO instead of the embedded genuine zT MPO")
     args = ap.parse_args()
-    sweep = args.workload == "dt_sweep_n24_s64"
+    sweep = args.workload in ("dt_sweep_n24_s64", "dt_sweep_n24_weak")
     if args.steps is None:
         args.steps = 40 if sweep else 1000
     if args.warmup is None:

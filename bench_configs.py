@@ -52,6 +52,29 @@ def pmc_record():
         return None, None
 
 
+def pmc_traffic(key, algorithmic_bytes=None):
+    """{"traffic", "traffic_over_algorithmic", "traffic_source"}: HBM bytes of workload `key` from the newest
+    profiles/r0*_pmc_traffic.json (tools/collect_pmc.py: WRITE_SIZE + 2 x FETCH_SIZE, separate --pmc passes) IF it was collected with
+    the library binary that is running now; traffic = None otherwise, with the reason in traffic_source."""
+    import glob, hashlib, json, os
+    root = os.path.dirname(os.path.abspath(__file__))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r0*_pmc_traffic.json")))
+    if not paths:
+        return {"traffic": None, "traffic_over_algorithmic": None, "traffic_source": None}
+    try:
+        import qilaplace_jl_amd as qil
+        sha = hashlib.sha256(open(qil.LIB_PATH, "rb").read()).hexdigest()[:16]
+        rec = json.load(open(paths[-1]))
+        name = os.path.basename(paths[-1])
+        if rec.get("lib_sha16") != sha:
+            return {"traffic": None, "traffic_over_algorithmic": None, "traffic_source": f"{name} was collected with another build of libqilhip.so"}
+        t = rec.get(key)
+        return {"traffic": t, "traffic_over_algorithmic": (t / algorithmic_bytes) if (t and algorithmic_bytes) else None,
+                "traffic_source": name}
+    except Exception:                                        # noqa: BLE001
+        return {"traffic": None, "traffic_over_algorithmic": None, "traffic_source": None}
+
+
 def counted_mfma(key, ms):
     """{"mfma_f64_flops", "achieved", "frac", "source"} from the PMC record of this build for workload `key`, over the time measured here."""
     rec, src = pmc_record()
@@ -90,8 +113,12 @@ def readout_roofline(bond_dims, nb, ms, elem_bytes=16, complex_sites=True):
     The GEMM form executes both slices for every query (twice the algorithmic flops) unless the batch is bit-sorted."""
     c = [1] + list(bond_dims) + [1]
     bytes_ = sum(elem_bytes * c[i] * 2 * c[i + 1] for i in range(len(c) - 1))
-    per_mac = 8.0 if complex_sites else 2.0
-    flops = per_mac * nb * sum(c[i] * c[i + 1] for i in range(len(c) - 1))
+    # complex products are executed as Gauss's THREE real multiplications (csrc/qil_linalg.hip): 6 flop issue per complex
+    # multiply-add; the fraction of the matrix peak is quoted on those (ADVICE r05: the conventional 8 overstates the pipe's
+    # utilisation by 4/3 and can exceed 1); the conventional-equivalent rate stays as a labelled extra
+    per_mac = 6.0 if complex_sites else 2.0
+    macs = nb * sum(c[i] * c[i + 1] for i in range(len(c) - 1))
+    flops = per_mac * macs
     t = ms * 1e-3
     hbm, mfma = bytes_ / t / 1e9, flops / t / 1e12
     f_h, f_m = hbm / HBM_PEAK_GBS, mfma / F64_MFMA_PEAK_TFLOPS
@@ -99,10 +126,12 @@ def readout_roofline(bond_dims, nb, ms, elem_bytes=16, complex_sites=True):
     return {"bound": bound, "achieved": mfma if bound == "mfma" else hbm, "peak": F64_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(f_h, f_m),
             "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_h, "algorithmic_bytes": bytes_},
-            "mfma": {"achieved": mfma, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_m, "algorithmic_flops": flops},
-            "model": "bytes = every site tensor read once per batch; flops = one slice per site and query (8 flop per complex "
-                     "multiply-add); time = HIP events around the whole read-out (bit-sorted: two one-slice GEMMs + one row gather per site)",
-            "traffic": None}
+            "mfma": {"achieved": mfma, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_m, "algorithmic_flops": flops,
+                     "conventional_equivalent_tflops": (8.0 if complex_sites else 2.0) * macs / t / 1e12},
+            "model": "bytes = every site tensor read once per batch; flops = one slice per site and query, 6 flop per complex "
+                     "multiply-add (three real multiplications: what the matrix pipe executes; `conventional_equivalent_tflops` counts 8); "
+                     "time = HIP events around the whole read-out (bit-sorted: two one-slice GEMMs + one row gather per site)",
+            "traffic": None, "traffic_over_algorithmic": None, "traffic_source": None}
 
 
 def coefficient_batch_entry(qil, ctx, out, nb=64, reps=3):
@@ -114,6 +143,7 @@ def coefficient_batch_entry(qil, ctx, out, nb=64, reps=3):
     roof = readout_roofline(out.bond_dims, nb, mean, 16 if cx else 8, cx)
     if nb == 64 and max(out.bond_dims) == 8192:
         roof["mfma_counted"] = counted_mfma("coefficient_batch_64_cfg3", mean)      # executed (incl. tile padding), not algorithmic
+        roof.update(pmc_traffic("coefficient_batch_64_cfg3", roof["hbm"]["algorithmic_bytes"]))
     return {"workload": "coefficient_batch on the materialised cfg3 product (zt_n24_chi64_D128, 80 GB)", "queries": nb,
             "ms": mean, "ms_min": best, "repetitions": reps, "product_bond_max": int(max(out.bond_dims)),
             "roofline": roof}
@@ -177,7 +207,9 @@ def cfg2_entry(qil, ctx, n=20, chi=32, D=64, steps=200):
     return {"workload": f"qft_n{n}_chi{chi}_D{D}", "sites": n, "ms_per_apply": wall * 1e3, "kernel_ms": k_ms, "steps": steps,
             "site_contractions_per_s": n / wall, "algorithmic_bytes": ab, "mpo_natural_bond_max": int(max(t.shape[3] for t in w_nat[:-1])),
             "roofline": {"bound": "hbm", "kernel": "site_apply_grouped<c64,double>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "frac_wall": ab / wall / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "frac_wall": ab / wall / 1e9 / HBM_PEAK_GBS,
+                         **(pmc_traffic(f"qft_n{n}_chi{chi}_D{D}", ab) if (n, chi, D) == (20, 32, 64) else
+                            {"traffic": None, "traffic_over_algorithmic": None, "traffic_source": "reduced size: not the profiled workload"}),
                          "note": "a 1.5 GB apply of 0.2-0.3 ms: the launch's fill and drain are a visible share of it"},
             "max_coeff_err": err, "coeff_err_kind": f"all 2^{n} coefficients vs numpy.fft.fft(x) / sqrt(N), relative to max |F|"}
 
@@ -390,6 +422,8 @@ def cfg5_entry(qil, ctx, n=30, k=128, p=5, q=2, reps=2):
         "mfma": {"achieved": mf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf / F64_MFMA_PEAK_TFLOPS, "algorithmic_flops": flops},
         "frac": max(mf / F64_MFMA_PEAK_TFLOPS, hbm / HBM_PEAK_GBS),
         "mfma_counted": counted_mfma("encode_n30_random_k128", r_mean) if (n, k, p, q) == (30, 128, 5, 2) else None,
+        **(pmc_traffic("encode_n30_random_k128", bytes_) if (n, k, p, q) == (30, 128, 5, 2) else
+           {"traffic": None, "traffic_over_algorithmic": None, "traffic_source": "reduced size: not the profiled workload"}),
         "model": f"root split {2 ** (n // 2)} x {2 ** (n - n // 2)}: (2 + 2q) = {2 + 2 * q} sketch products with l = k + p = {k + p} columns, "
                  "2 m n l flops and 8 m n bytes each; time = the WHOLE encode (root + 2 n - 2 smaller splits + normalisation), HIP events"}
     del xr

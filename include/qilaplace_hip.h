@@ -334,14 +334,30 @@ QIL_API int qil_qr_positive(qil_context* ctx, int dtype, int64_t m, int64_t n, c
 typedef struct qil_comm qil_comm;
 QIL_API int qil_comm_unique_id(void* id_out);
 QIL_API int qil_comm_create(qil_context* ctx, int rank, int world, const void* id, qil_comm** out);
-QIL_API int qil_comm_destroy(qil_comm* comm);            /* before the context it was created on is destroyed */
+/* In any order with qil_context_destroy: a context that goes first tears its communicators down and leaves their handles
+ * valid and empty (a GC'd host -- Julia finalizers, Python at shutdown -- cannot promise an order).                 */
+QIL_API int qil_comm_destroy(qil_comm* comm);
 QIL_API int qil_comm_info(const qil_comm* comm, int* rank, int* world);
 /* local: this rank's items in its own order (item rank, rank + world, ...), each `width` complex values (interleaved
  * doubles), host memory.  out: n_items x width complex values in ITEM order, host memory, on every rank.  Collective. */
 QIL_API int qil_gather_coefficients(qil_comm* comm, int64_t n_items, int64_t width, const double* local, double* out);
+/* The same gather for samples that are already in HBM (a sweep's read-outs start there): local_dev = this rank's
+ * ceil-share x width complex values in slot order, out_dev = n_items x width in item order, both DEVICE memory of the
+ * communicator's context; stream-ordered on that context's stream, no host synchronisation, no PCIe trip.  Every rank must
+ * pass the same n_items and width (they size the collective).  A rank that fails before the collective aborts the
+ * communicator (ncclCommAbort) so that its peers fail instead of waiting for ever.                                        */
+QIL_API int qil_gather_coefficients_device(qil_comm* comm, int64_t n_items, int64_t width, const void* local_dev, void* out_dev);
+/* The body of a damping sweep across the ranks of a communicator (docs/src/tutorials/dt.jl:150-197, zt.jl:300-348): Ws[0..nw)
+ * = THIS rank's round-robin share of n_items operators (slot k = item rank + k world; nw must equal that share, else
+ * QIL_EINVAL_LENGTH); every W psi is read out at the nb configurations (as qil_apply_coefficient_sweep), the samples stay in HBM,
+ * ONE all-gather exchanges them, and out[n_items x nb] (item order, complex, host) is filled on every rank.  Collective.       */
+QIL_API int qil_apply_coefficient_sweep_gather(qil_comm* comm, const qil_mpo* const* Ws, int64_t nw, const qil_mps* psi, int64_t nb,
+                                       const uint8_t* bits, int64_t n_items, double* out);
 /* The layout rule of that gather as a host function (no GPU, no RCCL): `gathered` = world blocks of
  * ceil(n_items / world) x width complex values in rank order -> `out` in item order.                                 */
 QIL_API int qil_sweep_unshuffle(int world, int64_t n_items, int64_t width, const double* gathered, double* out);
+/* ... and as the kernel the device gather uses (device buffers of `ctx`, stream-ordered): same rule, tested against the host one. */
+QIL_API int qil_sweep_unshuffle_device(qil_context* ctx, int world, int64_t n_items, int64_t width, const void* gathered_dev, void* out_dev);
 
 #ifdef __cplusplus
 }

@@ -460,6 +460,20 @@ function build_dt_mpo_batch(psi::DeviceMPS, wrs::AbstractVector{<:Real}; cutoff:
                 ctx().h, n, length(w), w, cutoff, maxdim, _site_ids(psi.sites), hs))
     return [finalizer(_free!, DeviceMPO(h, copy(psi.sites), true)) for h in hs]
 end
+# build_zt_mpo(psi::ZTMPS, wr; cutoff, maxdim) (zt_transformer.jl:41-112) for a sweep of damping values, every step on the device
+# behind ONE verb: the DT halves (:74) and the paired QFT chain (:78-99, built once) concurrently on two streams of the context,
+# then per value apply(W_dt, mpo_qft) (:103) and zip_to_compress_mpo "down" (:104) as one batch
+function build_zt_mpo_batch(psi::DeviceMPS, wrs::AbstractVector{<:Real}; cutoff::Float64=1e-14, maxdim::Int=1000)
+    psi.paired || throw(ArgumentError("build_zt_mpo: needs a paired-register (ZTMPS) operand"))
+    n = length(psi.sites) ÷ 2
+    w = Vector{Float64}(wrs)
+    hs = Vector{Ptr{Cvoid}}(undef, length(w))
+    check(ccall((:qil_build_zt_mpo_batch, LIB), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Cdouble, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
+                ctx().h, n, length(w), w, cutoff, maxdim, _site_ids(psi.sites), hs))
+    return [finalizer(_free!, DeviceMPO(h, copy(psi.sites), true)) for h in hs]
+end
+build_zt_mpo_device(psi::DeviceMPS, wr::Real; kwargs...) = build_zt_mpo_batch(psi, [wr]; kwargs...)[1]
 # build_qft_mpo(psi::SignalMPS; cutoff, maxdim) (qft_transformer.jl:121-165) entirely on the device: one launch of the
 # persistent complex chain builder; falls back (fallback flag) only if a bond left its in-LDS capacity, in which case the
 # reference's own host builder is the route to take (build_qft_mpo(n, sites) of QILaplace.jl, then to_device).
@@ -493,6 +507,7 @@ mutable struct Comm
     h::Ptr{Cvoid}
     rank::Int
     world::Int
+    context::Any                # the Context the communicator was created on: kept alive for as long as the communicator is
 end
 const COMM_ID_BYTES = 128
 # rank 0 creates the id and ships it to the other ranks over any host channel (Distributed.remotecall, a file, MPI.Bcast)
@@ -505,8 +520,10 @@ end
 function Comm(rank::Integer, world::Integer, id::Vector{UInt8})
     length(id) == COMM_ID_BYTES || throw(ArgumentError("Comm: the unique id must be $COMM_ID_BYTES bytes"))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:qil_comm_create, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx().h, rank, world, id, h))
-    return finalizer(c -> (ccall((:qil_comm_destroy, LIB), Cint, (Ptr{Cvoid},), c.h); c.h = C_NULL), Comm(h[], rank, world))
+    c = ctx()
+    check(ccall((:qil_comm_create, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), c.h, rank, world, id, h))
+    # (the library also tolerates the other order: a context destroyed first leaves the communicator's handle valid and empty)
+    return finalizer(cm -> (ccall((:qil_comm_destroy, LIB), Cint, (Ptr{Cvoid},), cm.h); cm.h = C_NULL), Comm(h[], rank, world, c))
 end
 shard_items(n_items::Integer, world::Integer, rank::Integer) = collect(rank:world:(n_items - 1))      # zero-based item indices
 # `local_batches`: this rank's coefficient batches in its own order (items rank, rank + world, ...), each of length `width`;
@@ -525,16 +542,36 @@ function gather_coefficients(comm::Comm, local_batches::Vector{Vector{ComplexF64
                 comm.h, n_items, width, loc, out))
     return permutedims(out)
 end
+# the same gather for samples that already live in HBM of the communicator's context (raw device pointers, e.g. from
+# AMDGPU.jl arrays): stream-ordered, nothing crosses PCIe
+function gather_coefficients_device!(comm::Comm, out_dev::Ptr{Cvoid}, local_dev::Ptr{Cvoid}, n_items::Integer, width::Integer)
+    check(ccall((:qil_gather_coefficients_device, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                comm.h, n_items, width, local_dev, out_dev))
+    return out_dev
+end
+# the gather's layout rule on device buffers (world blocks of ceil(n_items / world) x width in rank order -> item order)
+function sweep_unshuffle_device!(out_dev::Ptr{Cvoid}, gathered_dev::Ptr{Cvoid}, world::Integer, n_items::Integer, width::Integer)
+    check(ccall((:qil_sweep_unshuffle_device, LIB), Cint, (Ptr{Cvoid}, Cint, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                ctx().h, world, n_items, width, gathered_dev, out_dev))
+    return out_dev
+end
+# the sweep body across the ranks: Ws = THIS rank's round-robin share of n_items operators; the samples stay in HBM, one
+# all-gather, the (n_items, query) table on every rank (the loops of docs/src/tutorials/dt.jl:150-197, zt.jl:300-348)
+function apply_coefficient_sweep(comm::Comm, Ws::Vector{<:DeviceMPO}, psi::DeviceMPS, bits::AbstractMatrix{<:Integer}, n_items::Integer)
+    nb = size(bits, 1)
+    b = permutedims(UInt8.(bits))                       # query-major, site fastest
+    out = Matrix{ComplexF64}(undef, nb, n_items)
+    hs = Ptr{Cvoid}[W.h for W in Ws]
+    check(ccall((:qil_apply_coefficient_sweep_gather, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int64, Ptr{Cvoid}, Int64, Ptr{UInt8}, Int64, Ptr{Cvoid}),
+                comm.h, hs, length(Ws), psi.h, nb, b, n_items, out))
+    return permutedims(out)                             # (item, query)
+end
 # the whole damping sweep of BASELINE configs[3] on this rank's share + the gather (qilaplace.jl_amd/sweep.py: damping_sweep)
 function damping_sweep(comm::Comm, psi::DeviceMPS, wrs::AbstractVector{<:Real}, bits::AbstractMatrix{<:Integer}; cutoff::Float64=1e-14, maxdim::Int=1000)
     mine = shard_items(length(wrs), comm.world, comm.rank) .+ 1
-    batches = Vector{ComplexF64}[]
-    if !isempty(mine)
-        Ws = build_dt_mpo_batch(psi, wrs[mine]; cutoff=cutoff, maxdim=maxdim)
-        res = apply_coefficient_sweep(Ws, psi, bits)                 # (operator, query)
-        batches = [Vector{ComplexF64}(res[k, :]) for k in 1:length(mine)]
-    end
-    return gather_coefficients(comm, batches, length(wrs), size(bits, 1))
+    Ws = isempty(mine) ? DeviceMPO[] : build_dt_mpo_batch(psi, wrs[mine]; cutoff=cutoff, maxdim=maxdim)
+    return apply_coefficient_sweep(comm, Ws, psi, bits, length(wrs))
 end
 
 end # module

@@ -143,6 +143,9 @@ PROTOTYPES = {
     "qil_comm_destroy": [_vp],
     "qil_comm_info": [_vp, _pint, _pint],
     "qil_gather_coefficients": [_vp, _i64, _i64, _pdbl, _pdbl],
+    "qil_gather_coefficients_device": [_vp, _i64, _i64, _vp, _vp],
+    "qil_apply_coefficient_sweep_gather": [_vp, _pvp, _i64, _vp, _i64, _pu8, _i64, _pdbl],
+    "qil_sweep_unshuffle_device": [_vp, _int, _i64, _i64, _vp, _vp],
     "qil_sweep_unshuffle": [_int, _i64, _i64, _pdbl, _pdbl],
 }
 _RET = {"qil_last_error": C.c_char_p, "qil_version": C.c_char_p}

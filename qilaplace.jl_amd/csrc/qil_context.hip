@@ -101,6 +101,8 @@ extern "C" int qil_context_destroy(qil_context* ctx) {
     ctx->workers.clear();
     hipSetDevice(ctx->device);
     qil_stream_sync(ctx);
+    for (qil_comm* cm : ctx->comms) qil_comm_orphan(cm);  // communicators first: their handles stay valid and empty
+    ctx->comms.clear();
     for (qil_chain* c : ctx->chains) {                    // handles the caller has not destroyed yet: orphan them
         c->ctx = nullptr;
         for (void*& p : c->site) p = nullptr;

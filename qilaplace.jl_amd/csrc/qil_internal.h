@@ -132,6 +132,8 @@ struct qil_context {
     // live chain handles: orphaned (ctx = nullptr, site pointers dropped) when the context is destroyed first,
     // so a handle released after its context touches nothing
     std::set<struct qil_chain*> chains;
+    // communicators created on this context (qil_comm.hip): torn down with it, their handles stay valid and empty
+    std::set<struct qil_comm*> comms;
     // Batch entry points (qil_run_batch): independent chains run concurrently on this context's own stream (calling
     // thread) and on worker contexts (own stream and pool, one host thread each), one batch at a time.  For the duration of
     // a batch the home context's cached blocks are LENT: every participant misses in its own cache first, then takes from
@@ -197,6 +199,7 @@ int qil_run_batch(struct qil_chain* const* items, int64_t nb, const std::functio
 // bound to a worker when the batch ends -- moved there by place(j, slot) beforehand or created by fn -- returns to home.
 int qil_run_batch_on(qil_context* home, int64_t nb, const std::function<void(int64_t, qil_context*)>& place,
                      const std::function<int(int64_t, qil_context*)>& fn);
+void qil_comm_orphan(struct qil_comm* cm);   // (qil_comm.hip) the context of a communicator is going away
 // hand a live pool block of `from` to `to` (bookkeeping only; the caller orders the streams)
 void qil_ctx_transfer(qil_context* from, qil_context* to, void* p);
 // hand a whole chain (its site blocks and its registration) to another context of the same device

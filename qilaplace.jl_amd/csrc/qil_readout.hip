@@ -616,19 +616,16 @@ static int coefficient_impl(const qil_mps* psi, int64_t nb, const uint8_t* bits,
 // batch the product W_j psi is materialised by the apply kernel and read out at the same nb configurations.  One bit
 // upload, one download and ONE host synchronisation for the whole batch; each product's blocks return to the pool in
 // stream order and serve the next one.
-extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw, const qil_mps* psi, int64_t nb,
-                                           const uint8_t* bits, double* out) {
-    QIL_REQUIRE(Ws && psi && (nb == 0 || (bits && out)), QIL_EINVAL_ARG, "apply_coefficient_sweep: null argument");
-    if (nw == 0 || nb == 0) return QIL_OK;
+// The sweep body with its results LEFT IN HBM: dout = nw x nb complex values (operator-major) in psi's context, complete when
+// the call returns (every slot's stream has been synchronised by the batch runner / the home stream holds the rest in order).
+// qil_apply_coefficient_sweep copies them to the host; qil_apply_coefficient_sweep_gather (qil_comm.hip) all-gathers them first.
+int qil_apply_coefficient_sweep_dev(const qil_mpo* const* Ws, int64_t nw, const qil_mps* psi, int64_t nb, const uint8_t* bits,
+                                    void* dout) {
     qil_context* ctx = psi->ctx;
-    QIL_TRY(qil_ctx_activate(ctx));
-    qil_call_scope call_scope(ctx);
     uint8_t* dbits = nullptr;
     QIL_TRY(upload_bits(ctx, nb, psi->n(), bits, &dbits, 1));
     SortPlan plan;                                        // one plan for every operator's read-out (same configurations)
     if (nb >= 4) QIL_TRY(build_sort_plan(ctx, nb, psi->n(), bits, &plan));
-    void* dout = nullptr;
-    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nw * nb) * 16, &dout));
     bool distinct = true;                                 // operators change context for the batch: each must be its own handle
     {
         std::set<const qil_mpo*> seen;
@@ -657,11 +654,24 @@ extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw,
     } else {
         for (int64_t j = 0; j < nw; ++j) QIL_TRY(one(Ws[j], psi, j));
     }
+    qil_ctx_free(ctx, dbits);
+    if (plan.dmap) qil_ctx_free(ctx, plan.dmap);
+    return QIL_OK;
+}
+
+extern "C" int qil_apply_coefficient_sweep(const qil_mpo* const* Ws, int64_t nw, const qil_mps* psi, int64_t nb,
+                                           const uint8_t* bits, double* out) {
+    QIL_REQUIRE(Ws && psi && (nb == 0 || (bits && out)), QIL_EINVAL_ARG, "apply_coefficient_sweep: null argument");
+    if (nw == 0 || nb == 0) return QIL_OK;
+    qil_context* ctx = psi->ctx;
+    QIL_TRY(qil_ctx_activate(ctx));
+    qil_call_scope call_scope(ctx);
+    void* dout = nullptr;
+    QIL_TRY(qil_ctx_alloc(ctx, (size_t)(nw * nb) * 16, &dout));
+    QIL_TRY(qil_apply_coefficient_sweep_dev(Ws, nw, psi, nb, bits, dout));
     QIL_HIP(hipMemcpyAsync(out, dout, (size_t)(nw * nb) * 16, hipMemcpyDeviceToHost, qil_stream(ctx)));
     QIL_HIP(qil_stream_sync(ctx));
     qil_ctx_free(ctx, dout);
-    qil_ctx_free(ctx, dbits);
-    if (plan.dmap) qil_ctx_free(ctx, plan.dmap);
     return QIL_OK;
 }
 

@@ -204,14 +204,26 @@ def apply_coefficient_batch(W, psi, bits):
     return out.real.copy()
 
 
-def apply_coefficient_sweep(Ws, psi, bits):
+def apply_coefficient_sweep(Ws, psi, bits, comm=None, n_items=None):
     """For every operator of `Ws` (e.g. the DT MPOs of a damping sweep): materialise W * psi with the apply kernel
     and read it out at the same configurations -- the loop `out = W * psi; coefficient(out, bits)` of the
     reference's sweeps (docs/src/tutorials/dt.jl:150-197) with one upload, one download and one synchronisation
-    for the whole batch.  Returns a (len(Ws), nb) complex array."""
+    for the whole batch.  Returns a (len(Ws), nb) complex array.
+
+    With `comm` (a `sweep.Comm`) the call is COLLECTIVE: `Ws` is this rank's round-robin share of `n_items` operators, the
+    samples stay in HBM, one all-gather exchanges them (qil_apply_coefficient_sweep_gather) and every rank gets the
+    (n_items, nb) table in item order."""
     Ws = list(Ws)
     b = _bits_array(psi, bits)
     nb = b.shape[0]
+    if comm is not None:
+        if n_items is None:
+            raise ValueError("apply_coefficient_sweep: n_items is required with a communicator")
+        out = np.zeros((int(n_items), nb), dtype=np.complex128)
+        hs = (C.c_void_p * max(len(Ws), 1))(*[W.handle for W in Ws])
+        L.check(L.lib.qil_apply_coefficient_sweep_gather(comm.handle, hs, len(Ws), psi.handle, nb, b.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                         int(n_items), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
     out = np.zeros((len(Ws), nb), dtype=np.complex128)
     if not Ws or nb == 0:
         return out

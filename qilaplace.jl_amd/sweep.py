@@ -130,6 +130,12 @@ class Comm:
                                               loc.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def gather_coefficients_device(self, local_dev_ptr: int, n_items: int, width: int, out_dev_ptr: int):
+        """The same gather on DEVICE buffers of this communicator's context (raw pointers, e.g. `site_device_ptr` or any
+        __cuda_array_interface__ producer): stream-ordered, nothing crosses PCIe (qil_gather_coefficients_device)."""
+        L.check(L.lib.qil_gather_coefficients_device(self.handle, int(n_items), int(width), C.c_void_p(int(local_dev_ptr)),
+                                                     C.c_void_p(int(out_dev_ptr))))
+
     def close(self):
         if getattr(self, "handle", None):
             L.lib.qil_comm_destroy(self.handle)
@@ -258,6 +264,10 @@ def damping_sweep(psi, sigmas, bits, build_mpo=None, dist=None, device=None, cut
     world, rank = _world_rank(dist)
     mine = shard_items(len(sigmas), world, rank)
     local = {}
+    if isinstance(dist, Comm) and (world > 1 or always_gather):
+        # the C ABI's route: this rank's samples never leave HBM before the one all-gather (qil_apply_coefficient_sweep_gather)
+        Ws = build_dt_mpo_batch(psi, [sigmas[i] for i in mine], cutoff, maxdim, psi.ctx) if mine else []
+        return apply_coefficient_sweep(Ws, psi, bits, comm=dist, n_items=len(sigmas))
     if mine:
         Ws = build_dt_mpo_batch(psi, [sigmas[i] for i in mine], cutoff, maxdim, psi.ctx)
         res = apply_coefficient_sweep(Ws, psi, bits)

@@ -28,6 +28,12 @@ def test_default_workload_is_the_metric_configuration():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'default="zt_n24_chi64_D128"' in src
     assert "dt_sweep_n24_s64" in bench.WORKLOADS
+    # the weak-scaling form of the sweep (64 values per rank) beside the strong one, and the expected
+    # strong-scaling speedup stated in the line before anybody measures it
+    assert "dt_sweep_n24_weak" in bench.WORKLOADS
+    assert '"scaling": "weak" if weak else "strong"' in src and '"expected_speedup_at_8"' in src
+    # one meaning of max_coeff_err on every run; the parity figure has its own key; the spawner tags the job
+    assert '"parity_err_vs_oracle"' in src and '"max_coeff_err": err,' in src and "QIL_COMM_TAG=tag" in src
 
 
 def test_spawn_parent_never_imports_torch_or_the_library():
@@ -62,7 +68,8 @@ def test_configs_block_contract():
     # the models behind the two extra rooflines: read-out = sites read once + one slice per query; encode = root split
     r = bc.readout_roofline([4, 4], nb=10, ms=1.0)
     assert r["hbm"]["algorithmic_bytes"] == 16 * (1 * 2 * 4 + 4 * 2 * 4 + 4 * 2 * 1)
-    assert r["mfma"]["algorithmic_flops"] == 8 * 10 * (4 + 16 + 4)
+    assert r["mfma"]["algorithmic_flops"] == 6 * 10 * (4 + 16 + 4)          # three-multiplication complex products: 6 flop issue per MAC
+    assert abs(r["mfma"]["conventional_equivalent_tflops"] / r["mfma"]["achieved"] - 8.0 / 6.0) < 1e-12
     flops, nbytes = bc.rsvd_root_model(30, 128, 5, 2)
     assert nbytes == 6 * 8 * 2 ** 30 and flops == 6 * 2 * 2 ** 30 * 133
     # cfg4's samples: the closed form is not negligible on most of them, for every damping value of the sweep

@@ -509,13 +509,76 @@ def test_cabi_rccl_gather_world_of_one(qil):
     c2.close()
 
 
+def test_cabi_device_gather_and_sweep_gather(qil):
+    """the sweep's samples stay in HBM between the read-out and the gathered table.
+    qil_sweep_unshuffle_device (the kernel form of the layout rule) against the host rule for worlds 1 / 2 / 3 / 8 with ragged
+    shares; qil_gather_coefficients_device and qil_apply_coefficient_sweep_gather in a world of one (all a 1-GPU box holds)
+    against the plain sweep; a wrong share size is an argument error; a communicator outlives its context."""
+    import ctypes as C
+    import importlib
+    L = importlib.import_module("qilaplace_jl_amd._lib")
+    ctx = qil.default_context()
+    rng = np.random.default_rng(8)
+
+    def dev_buffer(v):
+        """complex values -> a chain whose first site buffer holds them contiguously (site memory = A[0, s, beta] at s + 2 beta)"""
+        v = np.asarray(v, dtype=np.complex128).reshape(-1)
+        if v.size % 2:
+            v = np.append(v, 0.0)
+        m = max(v.size // 2, 1)
+        if v.size == 0:
+            v = np.zeros(2, dtype=np.complex128)
+        return qil.SignalMPS([v.reshape((1, 2, m), order="F"), np.zeros((m, 2, 1), dtype=np.complex128)])
+
+    def read_buffer(own, count):
+        return own.site(0).reshape(-1, order="F")[:count]
+
+    # the layout rule as a kernel = the host rule (which the CPU suite ties to the gloo gather)
+    for world, n_items, width in ((1, 5, 3), (2, 7, 4), (3, 10, 1), (8, 64, 16), (8, 5, 2)):
+        per = -(-n_items // world)
+        gathered = rng.standard_normal((world * per, width)) + 1j * rng.standard_normal((world * per, width))
+        want = qil.unshuffle(world, n_items, width, gathered)
+        g_own, o_own = dev_buffer(gathered), dev_buffer(np.zeros(n_items * width))
+        L.check(L.lib.qil_sweep_unshuffle_device(ctx.handle, world, n_items, width, C.c_void_p(g_own.site_device_ptr(0)),
+                                                 C.c_void_p(o_own.site_device_ptr(0))))
+        ctx.synchronize()
+        assert np.array_equal(read_buffer(o_own, n_items * width).reshape(n_items, width), want), (world, n_items, width)
+    comm = qil.Comm(ctx, 0, 1, qil.Comm.unique_id())
+    # device gather in a world of one: identity on the item table, through ncclAllGather + the kernel
+    items = rng.standard_normal((7, 33)) + 1j * rng.standard_normal((7, 33))
+    l_own, o_own = dev_buffer(items), dev_buffer(np.zeros(items.size))
+    comm.gather_coefficients_device(l_own.site_device_ptr(0), 7, 33, o_own.site_device_ptr(0))
+    ctx.synchronize()
+    assert np.array_equal(read_buffer(o_own, items.size).reshape(7, 33), items)
+    # the sweep body + gather as one collective verb = the plain sweep
+    n = 5
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    psi = qil.signal_ztmps(x, cutoff=1e-14)
+    sig = np.linspace(0.25, 4.0, 6)
+    bits, _, _ = qil.damping_sample_bits(n, 64, seed=3, kmax=2 ** n)
+    Ws = qil.build_dt_mpo_batch(psi, sig)
+    plain = qil.apply_coefficient_sweep(Ws, psi, bits)
+    through = qil.apply_coefficient_sweep(Ws, psi, bits, comm=comm, n_items=len(sig))
+    assert np.array_equal(plain, through)
+    assert np.array_equal(qil.damping_sweep(psi, sig, bits, dist=comm, always_gather=True), plain)
+    with pytest.raises(ValueError, match="owns 6 of 6 items"):
+        qil.apply_coefficient_sweep(Ws[:3], psi, bits, comm=comm, n_items=len(sig))
+    comm.close()
+    # lifetime: the context goes first, the communicator's handle stays valid and empty
+    c2 = qil.Context(0)
+    cm2 = qil.Comm(c2, 0, 1, qil.Comm.unique_id())
+    c2.close()
+    cm2.close()
+    assert ctx.unowned_bytes() == 0
+
+
 def test_config4_damping_sweep_full_size(qil):
     """BASELINE.json configs[3] at full size on one GPU: n = 24, 64 damping values through `damping_sweep` with the
     batched device builder, 1024 sampled coefficients per value, checked where the output is NOT negligible
     (test/test_dt_transformer.jl:211-238 checks every entry of small cases; uniformly random (k, j) at n = 24 make every
     closed-form value underflow to 0.0 -- VERDICT r04 -- so the samples are `damping_sample_bits` and the share of
     non-negligible reference values is asserted per damping value).  Three legs:
-      (a) 4 of the 64 operators against the oracle's build_dt_mpo (numpy restatement of dt_transformer.jl:312-412) on the SAME
+      (a) 8 of the 64 operators against the oracle's build_dt_mpo (numpy restatement of dt_transformer.jl:312-412) on the SAME
           encoded psi through the oracle's lazy <bits|W psi>: 1e-9 of the signal peak -- the parity statement;
       (b) all 64 against the closed form x_j e^{-sigma k j / N} / sqrt(N) (test_dt_transformer.jl:60-92).  At the reference's
           default MPO cutoff 1e-14 the operator's own truncation limits this: 3.5e-5 of the signal peak at sigma = 0.25 falling
@@ -533,21 +596,30 @@ def test_config4_damping_sweep_full_size(qil):
     got = qil.damping_sweep(psi, sig, bits)
     assert got.shape == (64, 1024)
     peak = np.abs(x).max() / np.sqrt(N)
-    # (a) parity with the oracle's operators, non-vacuous
+    # (a) parity with the oracle's operators, non-vacuous: 8 of the 64 damping values, spread over the sweep (r06: was 4)
     ph = O.SignalMPS(psi.to_host(), amplitude=psi.amplitude)
-    for r in (0, 21, 42, 63):
+    closed = lambda s: x[jj] * np.exp(-s * kk * jj / N) / np.sqrt(N)
+    e_orc = {}
+    for r in (0, 9, 18, 27, 36, 45, 54, 63):
         ref = O.lazy_coefficient_batch(O.build_dt_mpo(n, float(sig[r])), ph, bits)
         assert (np.abs(ref) > 1e-6 * peak).mean() >= 0.5
         err = np.abs(got[r] - ref).max() / peak
         assert err < 1e-9, (r, sig[r], err)
-    # (b) closed form
+        e_orc[r] = np.abs(ref - closed(sig[r])).max() / peak          # the ORACLE's own distance to the closed form
+    assert 2e-5 < e_orc[0] < 5e-5 and e_orc[63] < 3e-6, e_orc        # (r05 / r06 measurements: 3.48e-5 and 1.32e-6)
+    # (b) closed form, bound per damping value (r06, VERDICT r05 item 7 / ADVICE r05): 1.2 x the oracle's own closed-form error,
+    # known at both ends of the sweep and interpolated log-linearly in sigma between them -- 4.2e-5 of the peak at 0.25 falling
+    # to 1.6e-6 at 16 (measured HIP profile: 3.5e-5, 2.3e-5, 1.2e-5, 4.5e-6, 6.4e-6 ... then a plateau of 1.3e-6 = the encode's own
+    # truncation, profiles/r06_cfg4_err_profile.json) instead of the flat 1e-4 of r05
     for r, s in enumerate(sig):
-        ref = x[jj] * np.exp(-s * kk * jj / N) / np.sqrt(N)
+        ref = closed(s)
         live = np.abs(ref) > 1e-6 * peak
         assert live.mean() >= 0.5, (r, s, live.mean())                    # never against zeros again
         assert (np.abs(ref) > 1e-2 * peak).mean() >= 0.2, (r, s)          # ... and a fifth of them of the signal's own size
         err = np.abs(got[r] - ref).max()
-        assert err < 1e-4 * peak, (r, s, err / peak)
+        t = (s - sig[0]) / (sig[-1] - sig[0])
+        bound = 1.2 * np.exp((1 - t) * np.log(e_orc[0]) + t * np.log(e_orc[63]))
+        assert err < bound * peak, (r, s, err / peak, bound)
         assert err / psi.amplitude < 1e-7 * max(1.0, np.abs(ref).max() / psi.amplitude)      # the reference's own bound
     # (c) convergence with the cutoffs
     psi2 = qil.signal_ztmps(x, method="rsvd", k=25, p=5, q=2, cutoff=1e-16)
