@@ -570,6 +570,16 @@ int rsvd_rowmajor(qil_context* ctx, int dt, int64_t m, int64_t n, const void* Z,
             for (int64_t j = 0; j < l0; ++j)
                 if (d2[(size_t)j] > 1e-26 * dmax && d2[(size_t)j] > 0.0) keep.push_back(j);
             if (keep.empty()) keep.push_back(0);
+            // never fewer columns than the caller's mindim keeps (the reference's svd(B; mindim) returns mindim
+            // columns whatever the spectrum, rsvd.jl:103-111): dropped columns come back in index order (they are orthonormal
+            // columns of Q like the others)
+            if ((int64_t)keep.size() < std::min<int64_t>(mindim, l0)) {
+                std::vector<char> in((size_t)l0, 0);
+                for (int64_t j : keep) in[(size_t)j] = 1;
+                for (int64_t j = 0; j < l0 && (int64_t)keep.size() < std::min<int64_t>(mindim, l0); ++j)
+                    if (!in[(size_t)j]) keep.push_back(j);
+                std::sort(keep.begin(), keep.end());
+            }
             if ((int64_t)keep.size() < l0) {
                 for (size_t t = 0; t < keep.size(); ++t)                                 // compact the kept columns to the front (usually a prefix already)
                     if (keep[t] != (int64_t)t)

@@ -1381,6 +1381,15 @@ def test_rsvd_wide_sketch_on_low_rank_signal(qil):
     psi = qil.signal_mps(x, method="rsvd", cutoff=1e-9, maxdim=64)
     assert np.abs(qil.mps_to_vector(psi) - x).max() < 1e-4 * np.abs(x).max()
     assert abs(psi.amplitude - np.linalg.norm(x)) < 1e-10
+    # mindim is a floor whatever the sketch deflation found (rsvd.jl:103-111 keeps mindim columns): the rank-2
+    # operand with mindim = 6 returns 6 orthonormal columns like the oracle, and the same product
+    for kw in (dict(k=20, p=10, q=0), dict(k=20, p=10, q=2)):
+        U, S, Vh = qil.rsvd(A, cutoff=1e-9, maxdim=64, mindim=6, **kw)
+        Uo, So, Vo = O.rsvd(A, cutoff=1e-9, maxdim=64, mindim=6, **kw)
+        assert len(S) == len(So) == 6
+        assert np.abs((U * S) @ Vh - A).max() < 1e-6 and np.abs(S[:2] - So[:2]).max() < 1e-9 * So[0]
+        live = S > 1e-12 * S[0]                          # (directions of exactly-zero singular values come back as zero columns)
+        assert live.sum() >= 2 and np.abs(U[:, live].T @ U[:, live] - np.eye(live.sum())).max() < 1e-10
 
 
 def test_zt_tutorial_big_signal_through_hip(qil, pins):
