@@ -74,7 +74,7 @@ def lib_sha16():
 
 def pmc_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of THIS round
-    (profiles/r02_pmc_traffic.json, written by tools/collect_pmc.py from separate WRITE_SIZE / FETCH_SIZE passes
+    (profiles/<round>_pmc_traffic.json, written by tools/collect_pmc.py from separate WRITE_SIZE / FETCH_SIZE passes
     with the guide's unit and gfx950 corrections).  Only reported when the counters were collected with the
     library binary that is running now (sha recorded next to them); otherwise null."""
     import glob
@@ -679,6 +679,8 @@ def run_apply(args, rk):
              else mpo_cls.alloc(db, dtype=np.complex128, ctx=ctx).fill_random(777))
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(W, psi, cb, db, L)
+    import bench_configs as _bc
+    res["summary"] = _bc.summary(res)          # LAST key: the tail of the line (what a truncated record keeps) carries every headline figure
     emit(res)
 
 
@@ -724,7 +726,7 @@ def run_sweep(args, rk):
     k_ms = kernel_ms / max(n_launch, 1)
     achieved = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     # what bounds the step: the per-value builder chain (one launch of dt_build_persistent per sweep), timed here with
-    # host clocks around a synchronised build of this rank's share (the kernel is >= 99 % of it, profiles/r03_kernel_stats_dt_sweep*)
+    # host clocks around a synchronised build of this rank's share (the kernel is >= 99 % of it, the kernel stats of the sweep, profiles/r0*_kernel_stats_dt_sweep_n24_s64.csv)
     xnorm = float(np.linalg.norm(x))
     share = [sig[i] for i in range(rk.rank, nsig, rk.world)]
     tb = []

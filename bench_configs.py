@@ -29,6 +29,7 @@ CONFIGS_BLOCK_KEYS = {
     "cfg4": ["workload", "ms_per_sweep", "site_contractions_per_s", "bound_by", "max_coeff_err", "reference_samples_above_1e-6_peak"],
     "cfg5": ["workload", "encode_ms", "encode_roofline", "zt_build_ms", "lazy_readout_ms", "max_coeff_err"],
     "coefficient_batch": ["workload", "queries", "ms", "roofline"],
+    "zt_build": ["workload", "ms_single", "ms_batch64", "max_bond", "stages_ms"],
 }
 
 
@@ -472,6 +473,43 @@ def cfg5_entry(qil, ctx, n=30, k=128, p=5, q=2, reps=2):
     return res
 
 
+# ---------------------------------------------------------------------------------------------- build_zt_mpo on the device
+def zt_build_entry(qil, ctx, n=24, nvalues=64, reps=3):
+    """build_zt_mpo(n, 2 pi) and a sweep of `nvalues` damping values through ONE C verb each (qil_build_zt_mpo_batch: DT halves ||
+    paired QFT chain on two streams, product, batched compression; zt_transformer.jl:41-112), wall clock, synchronised, best of
+    `reps` after a dry run; beside them the stages called one after another from their own entries."""
+    wr = 2 * np.pi
+
+    def best(fn, r):
+        out = []
+        for _ in range(r + 1):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            keep = fn()
+            ctx.synchronize()
+            out.append(time.perf_counter() - t0)
+            del keep
+        return min(out[1:]), out[0]
+
+    t1, t1_first = best(lambda: qil.build_zt_mpo(n, wr, ctx=ctx), reps)
+    W = qil.build_zt_mpo(n, wr, ctx=ctx)
+    bond = int(max(W.bond_dims))
+    del W
+    sig = np.linspace(0.25, 16.0, nvalues)
+    tb, _ = best(lambda: qil.build_zt_mpo_batch(n, sig, ctx=ctx), max(1, reps - 1))
+    st = {}
+    ctx.synchronize(); t0 = time.perf_counter(); dts = qil.build_dt_mpo_batch(n, [wr], ctx=ctx); ctx.synchronize(); st["dt_half"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); Q = qil.zt_qft_chain_device(n, dts[0].site_ids, ctx=ctx); ctx.synchronize(); st["paired_qft_chain"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); P = qil.apply(dts[0], Q); ctx.synchronize(); st["product"] = (time.perf_counter() - t0) * 1e3
+    b0 = int(max(P.bond_dims))
+    t0 = time.perf_counter(); qil.mpo_compress(P, "down", 1e-14, 1000); ctx.synchronize(); st["compress"] = (time.perf_counter() - t0) * 1e3
+    return {"workload": f"build_zt_mpo(n={n}, 2 pi) / sweep of {nvalues} damping values in linspace(0.25, 16), cutoff 1e-14",
+            "ms_single": t1 * 1e3, "ms_single_first_call": t1_first * 1e3, "ms_batch64": tb * 1e3, "values": int(nvalues),
+            "max_bond": bond, "product_bond_before_compression": b0, "stages_ms": st,
+            "note": "single = max(DT half, paired QFT chain) + product + compression: the two persistent builders run concurrently on two "
+                    "streams; nothing but 2 x 2 gate entries is computed on the host"}
+
+
 # ---------------------------------------------------------------------------------------------- the block
 def configs_block(qil, ctx, small=False, readout=None, log=None):
     """All entries; `small` runs the same code at sizes a test can afford (n = 12 / 10 / 16).  `readout`: the coefficient_batch entry
@@ -481,6 +519,7 @@ def configs_block(qil, ctx, small=False, readout=None, log=None):
         "cfg2": (lambda: cfg2_entry(qil, ctx, n=12, chi=16, D=32, steps=20)) if small else (lambda: cfg2_entry(qil, ctx)),
         "cfg4": (lambda: cfg4_entry(qil, ctx, n=10, nsig=8, nsamp=256, steps=1)) if small else (lambda: cfg4_entry(qil, ctx)),
         "cfg5": (lambda: cfg5_entry(qil, ctx, n=16, k=24, reps=1)) if small else (lambda: cfg5_entry(qil, ctx)),
+        "zt_build": (lambda: zt_build_entry(qil, ctx, n=8, nvalues=6, reps=1)) if small else (lambda: zt_build_entry(qil, ctx)),
     }
     block = {}
     for name, fn in todo.items():
@@ -500,3 +539,35 @@ def configs_block(qil, ctx, small=False, readout=None, log=None):
     if readout is not None:
         block["coefficient_batch"] = readout
     return block
+
+
+def summary(res):
+    """The figures a reader of the LAST 2 000 characters of the line needs (the driver's record keeps a tail of
+    stdout): one compact object, appended as the line's last key."""
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return round(d, 4) if isinstance(d, float) else d
+    c = res.get("configs") or {}
+    t = res.get("truncate") or {}
+    return {
+        "apply_ms": g(res, "ms_per_step"), "apply_frac_of_8TBps": g(res, "roofline", "frac"),
+        "apply_frac_of_box_store_peak": g(res, "roofline", "frac_of_box_store_peak"), "box_store_peak_GBps": g(res, "roofline", "box_store_peak"),
+        "apply_traffic_over_algorithmic": (g(res, "roofline", "traffic") / g(res, "roofline", "algorithmic_bytes_per_launch")
+                                            if g(res, "roofline", "traffic") else None),
+        "cpu_sites_per_s": g(res, "cpu_baseline", "value"), "max_coeff_err": g(res, "max_coeff_err"),
+        "cfg2": {"ms": g(c, "cfg2", "ms_per_apply"), "frac": g(c, "cfg2", "roofline", "frac"), "traffic_ratio": g(c, "cfg2", "roofline", "traffic_over_algorithmic"),
+                 "err": g(c, "cfg2", "max_coeff_err")},
+        "cfg4": {"ms_per_sweep": g(c, "cfg4", "ms_per_sweep"), "builder_ms": g(c, "cfg4", "bound_by", "ms"), "err": g(c, "cfg4", "max_coeff_err")},
+        "cfg5": {"encode_ms": g(c, "cfg5", "encode_ms"), "encode_random_ms": g(c, "cfg5", "encode_random_ms"),
+                 "encode_frac": g(c, "cfg5", "encode_roofline", "frac"), "encode_traffic_ratio": g(c, "cfg5", "encode_roofline", "traffic_over_algorithmic"),
+                 "zt_build_ms": g(c, "cfg5", "zt_build_ms"), "lazy_readout_ms": g(c, "cfg5", "lazy_readout_ms"),
+                 "apply_saturated_frac": g(c, "cfg5", "apply_saturated", "roofline", "frac"), "err": g(c, "cfg5", "max_coeff_err")},
+        "readout64": {"ms": g(c, "coefficient_batch", "ms"), "frac": g(c, "coefficient_batch", "roofline", "frac"),
+                      "traffic_ratio": g(c, "coefficient_batch", "roofline", "traffic_over_algorithmic")},
+        "zt_build_n24": {"ms_single": g(c, "zt_build", "ms_single"), "ms_batch64": g(c, "zt_build", "ms_batch64"), "stages_ms": g(c, "zt_build", "stages_ms")},
+        "truncate": {"fused_ms": g(t, "fused_apply_compress_ms"), "exact_ms": g(t, "exact_compress_ms"),
+                     "compress_chi256_ms": g(t, "compress_chi256_to_128_24_sites_ms"), "batch64_pairs_per_s": g(t, "batch64", "pairs_per_s")},
+    }

@@ -5,6 +5,7 @@ Tolerances (fp64): apply / coefficient / dense read-out 1e-12 relative (exact li
 different summation order only); transforms vs closed forms 1e-10 (QFT, n <= 5 builders at
 cutoff 1e-14 ... 1e-7 for DT / 2e-7 for zT, the reference's own bounds, MPO-cutoff limited);
 truncating ops compared through gauge-invariant quantities only."""
+import os
 import warnings
 import numpy as np
 import pytest
@@ -570,6 +571,49 @@ def test_cabi_device_gather_and_sweep_gather(qil):
     c2.close()
     cm2.close()
     assert ctx.unowned_bytes() == 0
+
+
+def test_cabi_rccl_two_ranks_when_two_gpus_are_visible(qil, tmp_path):
+    """the world > 1 path of the C ABI's communicator (file rendezvous + ncclCommInitRank + the sweep-gather verb)
+    with two REAL ranks, one process per GPU -- runs wherever at least two devices are visible (the driver's 8-GPU node), skipped
+    on the 1-GPU boxes of the pool.  Both ranks must return the single-process table."""
+    import subprocess
+    import sys
+    if qil.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import qilaplace_jl_amd as qil\n"
+        "import oracle as O\n"
+        "r = int(os.environ['RANK'])\n"
+        "ctx = qil.Context(r); qil.set_default_context(ctx)\n"
+        "comm = qil.Comm.from_env(ctx)\n"
+        "n = 6\n"
+        "x = O.generate_signal(n, kind='sin_decay', freq=[1.0, 2.5], decay_rate=[0.08, 0.03])\n"
+        "psi = qil.signal_ztmps(x, cutoff=1e-14)\n"
+        "sig = np.linspace(0.25, 4.0, 7)\n"
+        "bits, _, _ = qil.damping_sample_bits(n, 64, seed=3, kmax=2 ** n)\n"
+        "got = qil.damping_sweep(psi, sig, bits, dist=comm)\n"
+        "np.save(os.environ['QIL_TEST_OUT'] + '.%%d.npy' %% r, got)\n"
+        "comm.close()\n" % root)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", MASTER_PORT="29533",
+                   QIL_COMM_TAG=f"t{os.getpid()}", QIL_TEST_OUT=str(tmp_path / "out"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", child], env=env, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+    n = 6
+    x = O.generate_signal(n, kind="sin_decay", freq=[1.0, 2.5], decay_rate=[0.08, 0.03])
+    psi = qil.signal_ztmps(x, cutoff=1e-14)
+    bits, _, _ = qil.damping_sample_bits(n, 64, seed=3, kmax=2 ** n)
+    want = qil.damping_sweep(psi, np.linspace(0.25, 4.0, 7), bits)
+    for r in range(2):
+        got = np.load(str(tmp_path / "out") + f".{r}.npy")
+        assert np.abs(got - want).max() < 1e-12 * np.abs(want).max(), r
 
 
 def test_config4_damping_sweep_full_size(qil):
@@ -1255,9 +1299,10 @@ def test_bench_configs_block_small(qil):
     import bench_configs as bc
     ctx = qil.default_context()
     blk = bc.configs_block(qil, ctx, small=True)
-    for name in ("cfg2", "cfg4", "cfg5"):
+    for name in ("cfg2", "cfg4", "cfg5", "zt_build"):
         assert "error" not in blk[name], blk[name]
         assert set(bc.CONFIGS_BLOCK_KEYS[name]) <= set(blk[name])
+    assert blk["zt_build"]["ms_single"] > 0 and blk["zt_build"]["ms_batch64"] > 0 and set(blk["zt_build"]["stages_ms"]) == {"dt_half", "paired_qft_chain", "product", "compress"}
     assert blk["cfg2"]["max_coeff_err"] < 1e-9 and 0 < blk["cfg2"]["roofline"]["frac"] < 1.2
     assert blk["cfg4"]["max_coeff_err"] < 1e-5 and blk["cfg4"]["reference_samples_above_1e-6_peak"]["count"] > 0
     assert blk["cfg5"]["max_coeff_err"] < 2e-7 and blk["cfg5"]["lazy_vs_materialised_rel"] < 1e-11

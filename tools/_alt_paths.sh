@@ -9,3 +9,4 @@ run QIL_ENCODE_PAR_DEPTH=5
 run QIL_DT_BUILDER=launches              # the launch-per-step DT builder (the fallback for truncated bonds > 26) for every build
 run QIL_DT_DCAP=24                       # smaller in-LDS plan: more builds overflow into the fallback
 run QIL_CPU_BUDGET=2                     # one launcher thread, one lock-step group (a rank that gets 2 CPUs of an 8-rank node's quota)
+run QIL_SVD_NOSORT=1                     # r06: no norm-sorted columns before the QR of graded operands (the r05 one-factor SVD)

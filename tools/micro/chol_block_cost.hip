@@ -1,6 +1,6 @@
 // The 64-column diagonal block of the Cholesky + inverse (chol_inv_block16, qil_linalg.hip) on a Hermitian positive definite
 // block: checked against R^H R = G, R X = I, then timed as a launch train (the register-tiled kernel it replaced: 35.1 us
-// f64 / 46.9 us c64 at 64 columns, profiles/r03_chol_block_cost.txt).  Includes the library source so that the product's own kernel runs:
+// f64 / 46.9 us c64 at 64 columns, r03 measurement, profiles/archive_r01-r04.tar.gz).  Includes the library source so that the product's own kernel runs:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -I include -I qilaplace.jl_amd/csrc \
 //         tools/micro/chol_block_cost.hip -o tools/micro/chol_block_cost.bin -L qilaplace.jl_amd/lib -lqilhip \
 //         -Wl,-rpath,'$ORIGIN/../../qilaplace.jl_amd/lib'
