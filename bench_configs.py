@@ -549,7 +549,7 @@ def summary(res):
             if not isinstance(d, dict) or k not in d:
                 return None
             d = d[k]
-        return round(d, 4) if isinstance(d, float) else d
+        return float(f"{d:.5g}") if isinstance(d, float) else d
     c = res.get("configs") or {}
     t = res.get("truncate") or {}
     return {
