@@ -65,7 +65,7 @@ def test_configs_block_contract():
     fake = {"ms_per_step": 12.3456789, "roofline": {"frac": 0.81234567, "traffic": 80.2e9, "algorithmic_bytes_per_launch": 80.1e9},
             "configs": {"zt_build": {"ms_single": 187.1, "ms_batch64": 378.0, "stages_ms": {"dt_half": 124.0}}}}
     sm = bc.summary(fake)
-    assert sm["zt_build_n24"]["ms_single"] == 187.1 and sm["apply_ms"] == 12.3457 and len(json.dumps(sm)) < 2000
+    assert sm["zt_build_n24"]["ms_single"] == 187.1 and sm["apply_ms"] == 12.346 and len(json.dumps(sm)) < 2000
     assert {"ms_per_apply", "roofline", "max_coeff_err"} <= set(bc.CONFIGS_BLOCK_KEYS["cfg2"])
     assert {"ms_per_sweep", "bound_by", "max_coeff_err", "reference_samples_above_1e-6_peak"} <= set(bc.CONFIGS_BLOCK_KEYS["cfg4"])
     assert {"encode_ms", "encode_roofline", "lazy_readout_ms", "max_coeff_err"} <= set(bc.CONFIGS_BLOCK_KEYS["cfg5"])
