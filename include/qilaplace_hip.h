@@ -281,8 +281,11 @@ QIL_API int qil_svd_trunc(qil_context* ctx, const void* A, int64_t m, int64_t n,
  * out[nb] receives PairedSiteMPO handles (f64, 2n tensors), each with its own bond dimensions -- those of a
  * single build_dt_mpo call.  site_ids: the 2n labels of the operand the MPOs will act on (build_dt_mpo(psi::ZTMPS,
  * ...) builds on psi's own sites, dt_transformer.jl:409-412); NULL => 1..2n.  maxdim <= 0: no cap.
- * Bonds beyond the in-LDS capacity (truncated bond > 20; never at the reference's cutoffs) take a launch-per-step
- * route that pads every MPO of the batch to a common bond profile with zero components (same operators).      */
+ * Bonds beyond the in-LDS capacity (truncated bond > 26; never at the reference's cutoffs) take a launch-per-step
+ * route that pads every MPO of the batch to a common bond profile with zero components (same operators).
+ * The persistent builders (this one, qil_build_qft_mpo, qil_build_zt_qft_chain, qil_build_zt_mpo_batch) run their truncation rule
+ * at max(cutoff, 1e-28): directions below 1e-28 of a bond's weight are rounding residue of exactly rank-deficient product bonds
+ * (the reference's LAPACK SVD would keep them at cutoff = 0 as noise-level singular values; the operator is the same to rounding). */
 QIL_API int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, const double* wrs, double cutoff,
                            int64_t maxdim, const int64_t* site_ids, qil_mpo** out);
 

@@ -734,7 +734,9 @@ extern "C" int qil_build_dt_mpo_batch(qil_context* ctx, int64_t n, int64_t nb, c
         QIL_TRY(qil_build_dt_persistent(ctx, n, nb, wrs, cutoff, maxdim, site_ids, out, &fallback));
         if (!fallback) return QIL_OK;
     }
-    Builder bd{ctx, (int)nb, cutoff, maxdim <= 0 ? INT64_MAX : maxdim};
+    // (the rule never runs below 1e-28: the batched Jacobi leaves rounding residue of rank-deficient bonds un-orthogonalised, see
+    // qil_build_persist.hip persist_chunk)
+    Builder bd{ctx, (int)nb, std::max(cutoff, 1e-28), maxdim <= 0 ? INT64_MAX : maxdim};
     const int B = (int)nb;
     std::vector<BSite> M;
     int st = bd.make_block(2, [&](int b, int site, int* dl, int* dr, std::vector<double>* o) {

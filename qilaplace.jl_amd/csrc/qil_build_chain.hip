@@ -651,7 +651,7 @@ int qil_build_chain_persistent(qil_context* ctx, int kind, int64_t n, double cut
     a.blocks = static_cast<const c64*>(dblk);
     a.blkdims = static_cast<const int*>(ddim);
     a.ws = static_cast<c64*>(ws);
-    a.cutoff = cutoff;
+    a.cutoff = std::max(cutoff, 1e-28);              // (never below what the sweeps orthogonalise: see qil_build_persist.hip, persist_chunk)
     a.maxdim = maxdim <= 0 ? INT64_MAX : maxdim;
     a.dims_out = static_cast<int*>(dmeta);
     hipLaunchKernelGGL(chain_build_persistent, dim3(1), dim3(CB_NT), lds_bytes, s, a);

@@ -1053,7 +1053,11 @@ static int persist_chunk(qil_context* ctx, int64_t n, int64_t nb, const double* 
     a.L = L;
     a.dcap = dcap;
     a.site_cap = site_cap;
-    a.cutoff = cutoff;
+    // The tournament leaves columns below 1e-30 of the operand's weight alone (rounding residue of exactly rank-deficient product
+    // bonds: not directions, hence not orthogonalised); a cutoff below that would KEEP them as columns of an "isometry" that is none
+    // (found r06: cutoff = 0 gave wrong operators).  The rule therefore never runs below 1e-28: what it drops beyond the caller's
+    // cutoff carries < 1e-28 of the weight, which no gauge-invariant quantity sees (same rule as the complex chain builder's zip).
+    a.cutoff = std::max(cutoff, 1e-28);
     a.maxdim = maxdim <= 0 ? INT64_MAX : maxdim;
     a.gates = static_cast<const double*>(dg);
     a.ws = static_cast<double*>(ws);

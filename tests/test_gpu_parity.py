@@ -1874,6 +1874,16 @@ def test_build_zt_mpo_one_verb_all_device(qil, pins):
     Wg = qil.build_zt_mpo(n, 1.3, cutoff=1e-30, maxdim=None)
     Wh = qil.zt_mpo_tensors(n, 1.3, 1e-30, None)
     assert np.abs(dense_mpo(Wg.to_host()) - dense_mpo(Wh)).max() < 1e-12
+    # cutoff = 0 (r06: the persistent builders used to keep un-orthogonalised rounding residue as directions below 1e-30 and
+    # returned WRONG operators; their rule now never runs below 1e-28): the exact operator, whatever the bond dimensions
+    for n in (2, 3):
+        want = dense_mpo(qil.zt_mpo_tensors(n, 1.1, 1e-30, None))
+        for c in (0.0, 1e-300, 1e-40):
+            assert np.abs(dense_mpo(qil.build_zt_mpo(n, 1.1, cutoff=c, maxdim=None).to_host()) - want).max() < 1e-12, (n, c)
+        wantd = dense_mpo(qil.dt_mpo_tensors(n, 1.1, 1e-30, None))
+        assert np.abs(dense_mpo(qil.build_dt_mpo(n, 1.1, cutoff=0.0, maxdim=None).to_host()) - wantd).max() < 1e-12
+        wantq = dense_mpo(qil.qft_mpo_tensors(n, 1e-30, None))
+        assert np.abs(dense_mpo(qil.build_qft_mpo(n, cutoff=0.0, maxdim=None).to_host()) - wantq).max() < 1e-12
     # batches: one QFT chain shared by every value; 2 values (streams) and 6 (lock-step groups) equal the single builds
     # (bit for bit with the persistent DT builder, where every value is its own chain; the launch-per-step builder of the
     # alternative paths QIL_DT_BUILDER=launches / QIL_DT_DCAP pads the values of a batch to a common bond profile: same operators)
