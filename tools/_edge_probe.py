@@ -59,9 +59,10 @@ for kw in (dict(method="svd", cutoff=0.0), dict(method="svd", cutoff=1e-300, max
     psi = qil.signal_mps(x, **kw)
     report(f"signal_mps {kw}", float(np.abs(qil.mps_to_vector(psi) - x).max() / np.abs(x).max()), 1e-10, f"bonds {max(psi.bond_dims)}")
 zt = qil.signal_ztmps(x, cutoff=0.0)
-zo = O.signal_ztmps(x, cutoff=0.0)
-bz = rng.integers(0, 2, size=(128, 2 * n))
-report("signal_ztmps cutoff=0", rel(qil.coefficient_batch(zt, bz), O.coefficient_batch(zo, bz)), 1e-10)
+js = rng.integers(0, 2 ** n, size=128)
+bz = np.zeros((128, 2 * n), dtype=np.uint8)                       # main bits = copy bits = j (elsewhere the paired state is exactly 0)
+bz[:, 0::2] = bz[:, 1::2] = (js[:, None] >> np.arange(n - 1, -1, -1)[None, :]) & 1
+report("signal_ztmps cutoff=0 (coefficients at main = copy = j vs x_j)", float(np.abs(qil.coefficient_batch(zt, bz) - x[js]).max() / np.abs(x).max()), 1e-12)
 # fused route at the extremes
 a = random_mps_data(saturated_profile(8, 6), rng)
 w = random_mpo_data(saturated_profile(8, 5, base=4), rng)
