@@ -1908,6 +1908,21 @@ def test_build_zt_mpo_one_verb_all_device(qil, pins):
     assert qil.default_context().unowned_bytes() == 0
 
 
+def test_unusual_parameters_against_oracle():
+    """cutoff / tol = 0, maxdim = 1, no cap, sketches wider than the operand, mindim above the rank: the truncating entry points
+    (compress!, canonicalize!, zip_to_compress_mpo, signal_mps / signal_ztmps, the fused route, svd) against the oracle on small
+    problems, gauge-invariantly (tools/_edge_probe.py, 28 cases; the same kind of probe found r06's cutoff = 0 bug of the device
+    DT builders).  Run as its own process: it is also a tool."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "_edge_probe.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("ok ", "BAD", "EXC", "edge probe"))]
+    assert lines and lines[-1] == "edge probe: 0 bad", "\n".join(l for l in lines if not l.startswith("ok "))
+    assert sum(l.startswith("ok ") for l in lines) >= 28
+
+
 def test_failed_calls_leave_no_device_memory_behind(qil):
     """Error-path reclamation: whichever allocation inside a call fails, the pool's in-use byte count returns to
     what the live handles account for, in-place operands stay usable, and the same call succeeds afterwards."""

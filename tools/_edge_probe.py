@@ -1,9 +1,11 @@
 """Unusual-parameter probe of the truncating entry points against the oracle (small problems, gauge-invariant comparison):
 cutoff / tol = 0, maxdim = 1, no cap, sketches wider than the operand.  Prints one line per case; nothing here is timed.
 (r06: the same kind of probe found the cutoff = 0 bug of the device DT builders.)"""
+import os
 import sys
 import numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import qilaplace_jl_amd as qil
 import oracle as O
 from helpers import random_mps_data, random_mpo_data, saturated_profile, dense_mpo

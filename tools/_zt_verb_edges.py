@@ -1,5 +1,6 @@
-import sys, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os, sys, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import qilaplace_jl_amd as qil, oracle as O
 from helpers import dense_mpo
 ctx = qil.default_context()
