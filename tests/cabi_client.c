@@ -105,6 +105,30 @@ int main(void) {
         }
         CHECK(qil_mpo_destroy(W2));
     }
+    /* build_zt_mpo behind its one verb (r06), against a published output of the reference: build_zt_mpo(n = 2, wr = 2 pi,
+     * cutoff = 1e-14) has bonds copy_1 = 2, main_1 = 8, copy_2 = 2 (docs/src/tutorials/zt.md:185-190); n = 0 is the reference's
+     * ArgumentError (zt_transformer.jl:49) */
+    {
+        const double wr[2] = {6.283185307179586, 0.5};
+        qil_mpo* Wz[2] = {NULL, NULL};
+        int64_t zb[3] = {0, 0, 0}, nz = 0;
+        int paired = 0;
+        CHECK(qil_build_zt_mpo_batch(ctx, 2, 2, wr, 1e-14, 1000, NULL, Wz));
+        CHECK(qil_mpo_nsites(Wz[0], &nz));
+        CHECK(qil_mpo_is_paired(Wz[0], &paired));
+        CHECK(qil_mpo_bond_dims(Wz[0], zb));
+        if (nz != 4 || !paired || zb[0] != 2 || zb[1] != 8 || zb[2] != 2) {
+            fprintf(stderr, "build_zt_mpo(2, 2 pi): %lld tensors, paired %d, bonds %lld %lld %lld (published: 2 8 2)\n", (long long)nz, paired,
+                    (long long)zb[0], (long long)zb[1], (long long)zb[2]);
+            return 1;
+        }
+        CHECK(qil_mpo_destroy(Wz[0]));
+        CHECK(qil_mpo_destroy(Wz[1]));
+        if (qil_build_zt_mpo_batch(ctx, 0, 1, wr, 1e-14, 1000, NULL, Wz) != QIL_EINVAL_ARG || strlen(qil_last_error()) == 0) {
+            fprintf(stderr, "build_zt_mpo(0, ...): expected QIL_EINVAL_ARG with a message\n");
+            return 1;
+        }
+    }
     CHECK(qil_mps_destroy(out));
     CHECK(qil_mps_destroy(psi));
     CHECK(qil_mpo_destroy(Wd));
