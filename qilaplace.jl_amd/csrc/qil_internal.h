@@ -86,6 +86,7 @@ struct qil_context {
     hipEvent_t sync_event = nullptr;   // qil_stream_sync inside a lock-step batch
     uint64_t progress_key = 0;    // where the chain driven through this context is (qil_progress)
     int cholqr_skip = 0;          // Cholesky QR attempts to skip after a refusal (qr_impl)
+    bool qr_orthonormal = false;  // the last qr_impl took CholeskyQR2 with its first-order second pass: Q^H Q = I to O(|E|^2) < 1e-15 by construction (qr_reorthogonalise)
     double svd_deflate = 0.0;     // weight (relative) the one-factor SVD may drop with negligible rows of R: set by the truncating caller
     // CholeskyQR2 has R^-1 = X1 X2 at hand: a caller that is about to run the truncation certificate on R asks for it
     // (want_rinv) and takes the block over (rinv, valid for the R at rinv_for; the caller frees it)

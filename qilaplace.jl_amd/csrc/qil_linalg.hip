@@ -1887,6 +1887,11 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
     static const bool reorth = true;
     if (orthonormal) *orthonormal = true;
     if (!reorth || n < 2) return QIL_OK;
+    // r06: nothing to measure after a CholeskyQR2 whose second pass was the first-order one (A/B with the check forced on,
+    // profiles/r06_qr_recheck_ab.txt: bit-identical results, zT compression 64.2 -> 62.6 ms, compress! chi 256 45.2 -> 44.4 ms)
+    const bool known = ctx->qr_orthonormal;
+    ctx->qr_orthonormal = false;
+    if (known) return QIL_OK;
     void *gbuf = nullptr, *mx = nullptr;
     QIL_TRY(qil_ctx_alloc(ctx, (size_t)(n * n) * sizeof(T), &gbuf));
     QIL_TRY(qil_ctx_alloc(ctx, 256, &mx));
@@ -1915,6 +1920,7 @@ int qr_reorthogonalise(qil_context* ctx, long long m, long long n, T* Q, long lo
     }
     qil_ctx_free(ctx, gbuf);
     qil_ctx_free(ctx, mx);
+    ctx->qr_orthonormal = false;                                 // (a re-factorisation above may have set it: it is consumed here)
     return QIL_OK;
 }
 
@@ -2466,6 +2472,7 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     QIL_TRY((qil_klaunch<chol_near_identity_k<T>>(ctx, dim3((unsigned)std::min<long long>((n * n + 255) / 256, 1024)), dim3(256), 0, (const T*)G, (int)n, R2, X2, 3e-8 / (double)n, (int*)fl)));
     int bad = 0;
     QIL_TRY(qil_read_back(ctx, &bad, fl, sizeof(int)));
+    const bool first_order = bad == 0;                           // no bad pivot, every |e_ik| <= 3e-8 / n
     if (!(bad & 1) && (bad & 2)) {
         QIL_TRY(qil_dev_zero(ctx, fl, sizeof(int)));
         QIL_TRY(chol_inv<T>(ctx, G, (int)n, R2, X2, (int*)fl));
@@ -2487,6 +2494,9 @@ int cholqr2(qil_context* ctx, long long m, long long n, T* A, long long lda, T* 
     }
     release();
     *done = true;
+    // Q2 = Q1 (I - U) with Q1^H Q1 = I + E measured, n max |e| <= 3e-8: Q2^H Q2 = I + O(|E|^2), below 1e-15 -- the check that
+    // qr_reorthogonalise would run (a Gram product, a max-reduction, a read-back: ~25 us per QR) can only confirm it
+    ctx->qr_orthonormal = first_order;
     return QIL_OK;
 }
 
@@ -4207,6 +4217,7 @@ template <class T>
 int qr_impl(qil_context* ctx, long long m, long long n, T* A, long long lda, T* R, long long ldr) {
     static const long long TALL = 2048;
     static const bool hh_panels = true;
+    ctx->qr_orthonormal = false;
     // Cholesky QR first where it pays (from a few panels on) and while it keeps succeeding on this context: a numerically
     // rank-deficient operand (product bonds, deficient sketches) costs the attempt a Gram product, a partial factorisation and
     // one synchronisation, so after a refusal the next attempts are skipped
