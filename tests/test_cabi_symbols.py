@@ -56,6 +56,26 @@ def test_library_exports_nothing_but_the_declared_symbols():
     assert exported == set(_declared_symbols()), exported ^ set(_declared_symbols())
 
 
+def test_library_build_is_reproducible(tmp_path):
+    """r06: -ffile-prefix-map and a fixed -cuid per source make libqilhip.so bit-reproducible whatever directory it is built in, so the
+    sha256 the evidence under profiles/ is keyed to (bench.py: `config.lib_sha16`, `roofline.traffic_source`) can be re-derived from
+    the sources: `git archive HEAD` into a scratch directory, `make`, compare.  Two and a half minutes of hipcc: opt-in
+    (QIL_TEST_REBUILD=1)."""
+    import hashlib
+    import shutil
+    import subprocess
+    if os.environ.get("QIL_TEST_REBUILD") != "1":
+        pytest.skip("set QIL_TEST_REBUILD=1 (rebuilds the whole library, ~2.5 min)")
+    import qilaplace_jl_amd as qil
+    src = os.path.join(str(tmp_path), "src")
+    os.makedirs(src)
+    for d in ("include", os.path.join("qilaplace.jl_amd", "csrc")):
+        shutil.copytree(os.path.join(ROOT, d), os.path.join(src, d))
+    subprocess.run(["make", "-C", os.path.join(src, "qilaplace.jl_amd", "csrc"), "-j", "8"], check=True, capture_output=True)
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+    assert sha(os.path.join(src, "qilaplace.jl_amd", "lib", "libqilhip.so")) == sha(qil.LIB_PATH)
+
+
 def test_python_prototypes_cover_the_header():
     import importlib
     L = importlib.import_module("qilaplace_jl_amd._lib")
