@@ -2,11 +2,11 @@
 
 Reference: src/transforms/qft_transformer.jl:121-165, dt_transformer.jl:312-412, zt_transformer.jl:41-112, with the gate
 blocks of src/circuits/{qft,dt,zt}_gates.jl -- CPU chains of tiny latency-bound QR / SVD steps (D <= 8 / 18 / 92).
-``build_qft_mpo`` / ``build_dt_mpo(_batch)`` / ``build_zt_mpo(_batch)`` build in HBM (the persistent
-kernels of csrc/qil_build_persist.hip and qil_build_chain.hip, one launch per chain / per damping sweep; only 2 x 2 gate
-blocks come from the host) and return device handles (SingleSiteMPO / PairedSiteMPO).  The numpy chains of this file
-(``*_tensors``, ``device=False``) remain as the independent restatement the device builders are tested against and as the
-route for tiny n; they return the site tensors W[a, s_in, s_out, b].
+``build_qft_mpo`` / ``build_dt_mpo(_batch)`` / ``build_zt_mpo(_batch)`` build in HBM for EVERY n (the persistent
+kernels of csrc/qil_build_persist.hip and qil_build_chain.hip, one launch per chain / per damping sweep; r06: the whole
+build_zt_mpo behind one C verb, qil_build_zt_mpo_batch; only 2 x 2 gate entries come from the host) and return device handles
+(SingleSiteMPO / PairedSiteMPO).  The numpy chains of this file (``*_tensors``, ``device=False``) remain as the independent
+restatement the device builders are tested against; they return the site tensors W[a, s_in, s_out, b].
 
 Implementation notes: every sweep is written once, for the left-to-right direction; the right-to-left
 ("up") variants of the reference run the same routine on the mirrored chain.  Truncation is the
